@@ -1,0 +1,59 @@
+// Shared helpers for the ESS HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ess_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void ess_set_error(const char* fmt, ...);
+
+#define ESS_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      ess_set_error(__VA_ARGS__);           \
+      return ESS_EINVAL;                    \
+    }                                       \
+  } while (0)
+
+static inline int ess_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ess_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return ESS_ELAUNCH;
+  }
+  return ESS_OK;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float ess_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// wave64 all-lanes sum (butterfly through DPP/shuffles)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of a double; blockDim.x must be a multiple of 64, <= 1024; red: >= 16 doubles of LDS.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}

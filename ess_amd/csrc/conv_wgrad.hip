@@ -1,0 +1,314 @@
+// Weight gradient of the direct convolution on the fp32 matrix cores.
+//
+// GEMM view:  dW[tap][co][ci] = sum_px dY[co][px] * X[ci][px (+) tap],  reduction K = pixels.
+//   A = dY (M = co), B = X (N = ci): lanes run over channels, so both LDS tiles use an ODD per-channel
+//   pitch (bank-conflict free), and one A fragment is reused by all k*k taps.
+// Workgroup = 4 waves = a 64(co) x 64(ci) tile, one 32x32 (co,ci) pair per wave, k*k accumulator
+// blocks per wave.  The pixel range is split over blockIdx.y; partial slabs go to the workspace and a
+// second kernel reduces them in a fixed order (deterministic, no float atomics).
+// The 7x7 / C_in = 1 stem of the image encoder uses the "taps as N" variant instead.
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  const float* src0;
+  const float* src1;
+  const float* dy;
+  float* ws;      // [nsplit][taps][Cout][Cin]
+  float* ws_b;    // [nsplit][Cout] or null
+  int N, Hin, Win, C0, C1, mode0, mode1, Cout, Hout, Wout, pad;
+  int twl;        // pixel tile = (64>>twl) rows x (1<<twl) cols
+  int tiles_x, tiles_y, ntiles;
+  int IH, IW, plx;  // X tile rows/cols, per-channel pitch (odd)
+  int ci_tiles;
+};
+
+__device__ __forceinline__ float load_virtual(const WgradArgs& a, int n, int c, int gy, int gx) {
+  // value of the (virtually upsampled, concatenated) conv input at channel c, position (gy, gx)
+  if (gy < 0 || gy >= a.Hin || gx < 0 || gx >= a.Win) return 0.f;
+  const bool first = c < a.C0;
+  const int mode = first ? a.mode0 : a.mode1;
+  if (mode == ESS_SRC_ZERO_UP2 && ((gy | gx) & 1)) return 0.f;
+  const int sh = mode != ESS_SRC_DIRECT ? 1 : 0;
+  const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
+  const float* sp = first ? a.src0 : a.src1;
+  const int cc = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
+  return sp[(((size_t)n * Cs + cc) * Hp + (gy >> sh)) * Wp + (gx >> sh)];
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = KS * KS;
+  constexpr int PY = 65;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x - cot * a.ci_tiles;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int cb = wave >> 1, ib = wave & 1;
+  const int TWp = 1 << a.twl, THp = 64 >> a.twl;
+  const int Cin = a.C0 + a.C1;
+  float* dy_t = smem;            // [64][PY]
+  float* x_t = smem + 64 * PY;   // [64][plx]
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const size_t HWo = (size_t)a.Hout * a.Wout;
+  for (int tile = split; tile < a.ntiles; tile += nsplit) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * THp, x0 = tx * TWp;
+    __syncthreads();
+    // ---- dY tile: 64 channels x 64 pixels, lanes along x
+    {
+      const int qx = tid & (TWp - 1);
+      const int rows_per_it = 256 >> a.twl;
+      for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
+        const int co = r / THp, qy = r - co * THp;  // THp is a power of two
+        const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
+        float v = 0.f;
+        if (cg < a.Cout && y < a.Hout && x < a.Wout) v = a.dy[((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x];
+        dy_t[co * PY + qy * TWp + qx] = v;
+      }
+    }
+    // ---- X tile: 64 channels x IH x IW (halo included), lanes along x
+    {
+      const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
+      for (int r = wave; r < 64 * a.IH; r += 4) {
+        const int ci = r / a.IH, iy = r - ci * a.IH;
+        const int cg = cit * 64 + ci;
+        float* dst = x_t + ci * a.plx + iy * a.IW;
+        for (int ix = lane; ix < a.IW; ix += 64)
+          dst[ix] = cg < Cin ? load_virtual(a, n, cg, iy0 + iy, ix0 + ix) : 0.f;
+      }
+    }
+    __syncthreads();
+    const float* ap = dy_t + (cb * 32 + p) * PY;
+    const float* xp = x_t + (ib * 32 + p) * a.plx;
+#pragma unroll 2
+    for (int kk = 0; kk < 32; ++kk) {
+      const int q = 2 * kk + half;
+      const int qy = q >> a.twl, qx = q & (TWp - 1);
+      const float av = ap[q];
+      bsum += av;
+      const float* xq = xp + qy * S * a.IW + qx * S;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+          acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xq[ky * a.IW + kx], acc[ky * KS + kx], 0, 0, 0);
+    }
+  }
+  // ---- partial slab: ws[split][tap][co][ci]
+  const int ci = cit * 64 + ib * 32 + p;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * T + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+    }
+  if (a.ws_b && cit == 0 && ib == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);  // both pixel parities
+    const int co = cot * 64 + cb * 32 + p;
+    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
+  }
+}
+
+// "taps as N" variant for a single input channel (7x7 stem): dW[co][tap] = sum_px dY[co][px] X[px (+) tap]
+template <int KS, int S>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = KS * KS;
+  constexpr int PY = 65;
+  static_assert(T <= 64, "taps must fit two MFMA column blocks");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int cot = blockIdx.x;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int cb = wave >> 1, tb = wave & 1;
+  const int TWp = 1 << a.twl, THp = 64 >> a.twl;
+  float* dy_t = smem;
+  float* x_t = smem + 64 * PY;  // [IH][IW]
+  const int tap = tb * 32 + p;
+  const int tky = tap / KS, tkx = tap - tky * KS;
+  const bool tap_ok = tap < T;
+  const int toff = tap_ok ? tky * a.IW + tkx : 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const size_t HWo = (size_t)a.Hout * a.Wout;
+  for (int tile = split; tile < a.ntiles; tile += nsplit) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * THp, x0 = tx * TWp;
+    __syncthreads();
+    {
+      const int qx = tid & (TWp - 1);
+      const int rows_per_it = 256 >> a.twl;
+      for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
+        const int co = r / THp, qy = r - co * THp;
+        const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
+        float v = 0.f;
+        if (cg < a.Cout && y < a.Hout && x < a.Wout) v = a.dy[((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x];
+        dy_t[co * PY + qy * TWp + qx] = v;
+      }
+      const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
+      for (int iy = wave; iy < a.IH; iy += 4)
+        for (int ix = lane; ix < a.IW; ix += 64) x_t[iy * a.IW + ix] = load_virtual(a, n, 0, iy0 + iy, ix0 + ix);
+    }
+    __syncthreads();
+    const float* ap = dy_t + (cb * 32 + p) * PY;
+#pragma unroll 4
+    for (int kk = 0; kk < 32; ++kk) {
+      const int q = 2 * kk + half;
+      const int qy = q >> a.twl, qx = q & (TWp - 1);
+      const float bv = tap_ok ? x_t[qy * S * a.IW + qx * S + toff] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[q], bv, acc, 0, 0, 0);
+    }
+  }
+  // slab layout [split][tap][co][ci=1]
+  if (tap_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout) a.ws[((size_t)split * T + tap) * a.Cout + co] = acc[r];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
+                                    int Cin, int accumulate) {
+  const size_t total = (size_t)T * Cout * Cin;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
+    const int t = i / ((size_t)Cout * Cin);
+    const size_t rem = i - (size_t)t * Cout * Cin;  // co*Cin + ci
+    float* dst = dw + rem * T + t;
+    *dst = accumulate ? *dst + s : s;
+  }
+  if (db && ws_b && i < (size_t)Cout) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws_b[(size_t)k * Cout + i];
+    db[i] = accumulate ? db[i] + s : s;
+  }
+}
+
+struct WPlan {
+  int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
+  bool taps_variant;
+  size_t slab_floats;
+};
+
+int wvalidate(const EssConvDesc* d) {
+  ESS_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
+  ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && d->out_split == 0, "wgrad: only plain convolutions have a weight gradient here");
+  const int cin = d->C0 + d->C1;
+  const bool taps = cin == 1 && d->ksize == 7;
+  ESS_CHECK_ARG(taps || d->ksize == 1 || d->ksize == 3, "wgrad: k=%d with C_in=%d unsupported", d->ksize, cin);
+  ESS_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride %d unsupported", d->stride);
+  return ESS_OK;
+}
+
+WPlan wplan(const EssConvDesc* d) {
+  WPlan w{};
+  const int cin = d->C0 + d->C1, KS = d->ksize, S = d->stride;
+  w.taps_variant = (cin == 1 && KS == 7);
+  // pixel tile of 64: pick the width that wastes the least
+  double best = 1e300;
+  for (int twl = 5; twl >= 3; --twl) {
+    const int tw = 1 << twl, th = 64 >> twl;
+    const double c = (double)ceil_div(d->W_out, tw) * tw * ceil_div(d->H_out, th) * th + 1e-3 * (5 - twl);
+    if (c < best) { best = c; w.twl = twl; }
+  }
+  const int tw = 1 << w.twl, th = 64 >> w.twl;
+  w.tiles_x = ceil_div(d->W_out, tw); w.tiles_y = ceil_div(d->H_out, th);
+  w.ntiles = d->N * w.tiles_x * w.tiles_y;
+  w.IH = (th - 1) * S + KS; w.IW = (tw - 1) * S + KS;
+  w.plx = (w.IH * w.IW) | 1;
+  w.co_tiles = ceil_div(d->C_out, 64);
+  w.ci_tiles = w.taps_variant ? 1 : ceil_div(cin, 64);
+  w.slab_floats = (size_t)KS * KS * d->C_out * cin + d->C_out;
+  const int pairs = w.co_tiles * w.ci_tiles;
+  int ns = ceil_div(2048, pairs);
+  if (ns > w.ntiles) ns = w.ntiles;
+  const size_t cap = ((size_t)64 << 20) / (w.slab_floats * 4);
+  if ((size_t)ns > cap) ns = (int)(cap ? cap : 1);
+  if (ns < 1) ns = 1;
+  w.nsplit = ns;
+  w.lds_bytes = (64 * 65 + (w.taps_variant ? w.IH * w.IW : 64 * w.plx)) * 4;
+  return w;
+}
+
+template <typename K>
+int raise_lds(K kernel, int bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      ess_set_error("hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+      return ESS_ELAUNCH;
+    }
+  }
+  return ESS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
+  if (wvalidate(d)) return 0;
+  const WPlan w = wplan(d);
+  return (size_t)w.nsplit * w.slab_floats * 4;
+}
+
+extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1, const float* dy, float* dw,
+                                float* db, int accumulate, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
+  int rc = wvalidate(d);
+  if (rc) return rc;
+  ESS_CHECK_ARG(src0 && dy && dw && workspace, "wgrad: null pointer");
+  ESS_CHECK_ARG(d->C1 == 0 || src1, "wgrad: second source missing");
+  const WPlan w = wplan(d);
+  ESS_CHECK_ARG(workspace_bytes >= (size_t)w.nsplit * w.slab_floats * 4, "wgrad: workspace too small");
+  ESS_CHECK_ARG(w.lds_bytes <= 160 * 1024, "wgrad: LDS tile %d B too large", w.lds_bytes);
+  const int cin = d->C0 + d->C1, T = d->ksize * d->ksize;
+  WgradArgs a{};
+  a.src0 = src0; a.src1 = src1; a.dy = dy;
+  a.ws = (float*)workspace;
+  a.ws_b = db ? a.ws + (size_t)w.nsplit * T * d->C_out * cin : nullptr;
+  a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
+  a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
+  a.twl = w.twl; a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
+  a.IH = w.IH; a.IW = w.IW; a.plx = w.plx; a.ci_tiles = w.ci_tiles;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(w.co_tiles * w.ci_tiles, w.nsplit);
+#define ESS_WG(KS_, S_)                                                                               \
+  do {                                                                                                \
+    if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
+    hipLaunchKernelGGL((wgrad_f32_kernel<KS_, S_>), grid, dim3(256), w.lds_bytes, st, a);             \
+  } while (0)
+  if (w.taps_variant) {
+    ESS_CHECK_ARG(d->stride == 2, "wgrad: 7x7 stem variant is stride 2 only");
+    if ((rc = raise_lds(wgrad_taps_kernel<7, 2>, w.lds_bytes))) return rc;
+    hipLaunchKernelGGL((wgrad_taps_kernel<7, 2>), grid, dim3(256), w.lds_bytes, st, a);
+    // the taps variant has no bias path
+    a.ws_b = nullptr;
+  } else if (d->ksize == 3 && d->stride == 1) ESS_WG(3, 1);
+  else if (d->ksize == 3 && d->stride == 2) ESS_WG(3, 2);
+  else if (d->ksize == 1 && d->stride == 1) ESS_WG(1, 1);
+  else ESS_WG(1, 2);
+#undef ESS_WG
+  rc = ess_launch_status("conv2d_wgrad");
+  if (rc) return rc;
+  ESS_CHECK_ARG(!(w.taps_variant && db), "wgrad: the stem variant has no bias gradient");
+  const size_t total = (size_t)T * d->C_out * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total > (size_t)d->C_out ? total : d->C_out, 256)),
+                     dim3(256), 0, st, a.ws, a.ws_b, dw, db, w.nsplit, T, d->C_out, cin, accumulate);
+  return ess_launch_status("conv2d_wgrad_reduce");
+}

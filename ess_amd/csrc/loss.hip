@@ -1,0 +1,340 @@
+// Fused loss kernels (forward value + gradient w.r.t. the first argument), the flat RAdam update
+// and the argmax/confusion epilogue.  All HBM-bound; each reads its inputs once or twice.
+#include "common.h"
+
+namespace {
+
+constexpr int KMAX = 32;  // max classes held in registers
+
+// ------------------------------------------------------------------ TaskLoss = Dice + CE
+// ws (double): [0] ce_sum, [1] valid_count, [2+3k] I_k = sum p_k t_k, [3+3k] sum p_k^2, [4+3k] sum t_k
+// KM = compile-time class capacity: per-pixel class vectors stay in registers (no runtime indexing).
+template <int KM, bool GRAD>
+__global__ __launch_bounds__(256) void task_loss_kernel(const float* __restrict__ z, const int64_t* __restrict__ lab,
+                                                        double* ws, float* loss, float* __restrict__ dz, float scale, int N,
+                                                        int K, int hw, int ignore, int use_dice, int use_ce) {
+  __shared__ double sh[2 + 3 * KMAX];
+  __shared__ float coefA[KMAX], coefB[KMAX];  // dice: dL/dp_k = coefA_k * t_k + coefB_k * p_k
+  __shared__ float inv_valid;
+  if (!GRAD) {
+    for (int i = threadIdx.x; i < 2 + 3 * K; i += blockDim.x) sh[i] = 0;
+  } else {
+    if (threadIdx.x < K) {
+      const int k = threadIdx.x;
+      const double num = 2 * ws[2 + 3 * k] + 1, den = ws[3 + 3 * k] + ws[4 + 3 * k] + 1;
+      coefA[k] = (k == ignore) ? 0.f : (float)(-2.0 / den / K);
+      coefB[k] = (k == ignore) ? 0.f : (float)(2.0 * num / (den * den) / K);
+    }
+    if (threadIdx.x == 0) inv_valid = (float)(1.0 / ws[1]);
+  }
+  __syncthreads();
+  const size_t total = (size_t)N * hw;
+  double ce = 0, cnt = 0;
+  float accI[KM], accP[KM], accT[KM];
+  if (!GRAD) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k) { accI[k] = 0.f; accP[k] = 0.f; accT[k] = 0.f; }
+  }
+  // block-uniform trip count: every lane stays in the loop, `active` masks the tail
+  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < total; base += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = base + threadIdx.x;
+    const bool active = i < total;
+    const size_t ii = active ? i : total - 1;
+    const size_t n = ii / hw, px = ii - n * hw;
+    const float* zp = z + n * (size_t)K * hw + px;
+    const int l = (int)lab[ii];
+    const bool valid = active && l != ignore;
+    float v[KM];
+    float m = -INFINITY, zl = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (k < K) {
+        v[k] = zp[(size_t)k * hw];
+        m = fmaxf(m, v[k]);
+        if (k == l) zl = v[k];
+      } else {
+        v[k] = -INFINITY;
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      v[k] = (k < K) ? expf(v[k] - m) : 0.f;
+      se += v[k];
+    }
+    const float inv = 1.f / se;
+    if (!GRAD) {
+      if (valid) {
+        cnt += 1;
+        ce += (double)(logf(se) - (zl - m));  // -log softmax at the label
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+          const float p = v[k] * inv;
+          accP[k] += p * p;
+          if (k == l) { accI[k] += p; accT[k] += 1.f; }
+        }
+      }
+    } else if (active) {
+      float* gp = dz + n * (size_t)K * hw + px;
+      // a_k = dL/dp_k ; dz_j = p_j (a_j - sum_k a_k p_k) + CE term; ignored pixels get zero
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        if (k < K) {
+          const float p = v[k] * inv;
+          const float a = use_dice ? coefA[k] * (l == k ? 1.f : 0.f) + coefB[k] * p : 0.f;
+          dot += a * p;
+          v[k] = p;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        if (k < K) {
+          const float p = v[k];
+          const float a = use_dice ? coefA[k] * (l == k ? 1.f : 0.f) + coefB[k] * p : 0.f;
+          float g = p * (a - dot);
+          if (use_ce) g += (p - (l == k ? 1.f : 0.f)) * inv_valid;
+          gp[(size_t)k * hw] = valid ? g * scale : 0.f;
+        }
+      }
+    }
+  }
+  if (!GRAD) {
+    ce = wave_sum_d(ce);
+    cnt = wave_sum_d(cnt);
+    const bool lead = (threadIdx.x & 63) == 0;
+    if (lead) { atomicAdd(&sh[0], ce); atomicAdd(&sh[1], cnt); }
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (k < K) {
+        const float a = wave_sum(accI[k]), b = wave_sum(accP[k]), c = wave_sum(accT[k]);
+        if (lead) { atomicAdd(&sh[2 + 3 * k], (double)a); atomicAdd(&sh[3 + 3 * k], (double)b); atomicAdd(&sh[4 + 3 * k], (double)c); }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 + 3 * K; i += blockDim.x) atomicAdd(ws + i, sh[i]);
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double L = 0;
+    if (use_dice) {
+      for (int k = 0; k < K; ++k) {
+        if (k == ignore) continue;
+        L += 1.0 - (2 * ws[2 + 3 * k] + 1) / (ws[3 + 3 * k] + ws[4 + 3 * k] + 1);
+      }
+      L /= K;
+    }
+    if (use_ce) L += ws[0] / ws[1];
+    *loss = (float)(L * scale);
+  }
+}
+
+__global__ void task_loss_value_kernel(const double* ws, float* loss, float scale, int K, int ignore, int use_dice,
+                                       int use_ce) {
+  double L = 0;
+  if (use_dice) {
+    for (int k = 0; k < K; ++k) {
+      if (k == ignore) continue;
+      L += 1.0 - (2 * ws[2 + 3 * k] + 1) / (ws[3 + 3 * k] + ws[4 + 3 * k] + 1);
+    }
+    L /= K;
+  }
+  if (use_ce) L += ws[0] / ws[1];
+  *loss = (float)(L * scale);
+}
+
+// ------------------------------------------------------------------ symmetric JS (as two mean-KL terms)
+template <int KM>
+__global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ za, const float* __restrict__ zb, double* ws,
+                                                     float* __restrict__ da, float scale, int N, int K, int hw) {
+  __shared__ double red[16];
+  const size_t total = (size_t)N * hw;
+  const float invM = 1.f / ((float)total * K);
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / hw, px = i - n * hw;
+    const float* ap = za + n * (size_t)K * hw + px;
+    const float* bp = zb + n * (size_t)K * hw + px;
+    float va[KM], vb[KM];
+    float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      va[k] = (k < K) ? ap[(size_t)k * hw] : -INFINITY;
+      vb[k] = (k < K) ? bp[(size_t)k * hw] : -INFINITY;
+      ma = fmaxf(ma, va[k]); mb = fmaxf(mb, vb[k]);
+    }
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      va[k] = (k < K) ? expf(va[k] - ma) : 0.f;
+      vb[k] = (k < K) ? expf(vb[k] - mb) : 0.f;
+      sa += va[k]; sb += vb[k];
+    }
+    const float ia = 1.f / sa, ib = 1.f / sb;
+    float dot = 0.f, l = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (k >= K) continue;
+      const float pa_raw = va[k] * ia, pb_raw = vb[k] * ib;
+      const float pa = fmaxf(pa_raw, 1e-10f), pb = fmaxf(pb_raw, 1e-10f);
+      const float la = logf(pa), lb = logf(pb);
+      l += 0.5f * (pb * (lb - la) + pa * (la - lb));
+      // d/dpa of 0.5*[pb(lb - la) + pa(la - lb)] = 0.5*(-pb/pa + la - lb + 1); zero where clamped
+      const float g = pa_raw > 1e-10f ? 0.5f * (-pb / pa + la - lb + 1.f) : 0.f;
+      vb[k] = g;
+      va[k] = pa_raw;
+      dot += g * pa_raw;
+    }
+    acc += l;
+    if (da) {
+      float* gp = da + n * (size_t)K * hw + px;
+#pragma unroll
+      for (int k = 0; k < KM; ++k)
+        if (k < K) gp[(size_t)k * hw] = va[k] * (vb[k] - dot) * invM * scale;
+    }
+  }
+  acc = block_sum_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(ws, acc);
+}
+
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, double* ws,
+                                                 float* __restrict__ da, float scale, int64_t n) {
+  __shared__ double red[16];
+  const float gs = scale / (float)n;
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    acc += fabsf(d);
+    if (da) da[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+  }
+  acc = block_sum_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(ws, acc);
+}
+
+__global__ void mean_finalize_kernel(const double* ws, float* loss, double denom, float scale) {
+  *loss = (float)(ws[0] / denom * scale);
+}
+
+// ------------------------------------------------------------------ RAdam over a flat buffer
+__global__ void radam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float neg_step, float b1, float b2, float eps, int rect) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float vi = v[i] * b2 + (1.f - b2) * (gi * gi);
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    v[i] = vi;
+    m[i] = mi;
+    p[i] = rect ? p[i] + neg_step * (mi / (sqrtf(vi) + eps)) : p[i] + neg_step * mi;
+  }
+}
+
+// ------------------------------------------------------------------ argmax + confusion
+__global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restrict__ z, const int64_t* __restrict__ lab,
+                                                          int64_t* __restrict__ pred, unsigned long long* conf, int N, int K,
+                                                          int hw, int ignore) {
+  extern __shared__ unsigned int hist[];  // K*K
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const size_t total = (size_t)N * hw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / hw, px = i - n * hw;
+    const float* zp = z + n * (size_t)K * hw + px;
+    float best = zp[0];
+    int bi = 0;
+    for (int k = 1; k < K; ++k) {
+      const float t = zp[(size_t)k * hw];
+      if (t > best) { best = t; bi = k; }  // first maximum wins, as torch.argmax
+    }
+    if (pred) pred[i] = bi;
+    if (lab && conf) {
+      const int64_t l = lab[i];
+      if (l != ignore && l >= 0 && l < K) atomicAdd(&hist[l * K + bi], 1u);
+    }
+  }
+  __syncthreads();
+  if (conf)
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+      if (hist[i]) atomicAdd(conf + i, (unsigned long long)hist[i]);
+}
+
+inline unsigned wave_uniform_grid(size_t total, int cap) {
+  // blocks of 256 threads such that grid*256 divides the work into equal trip counts where possible
+  size_t g = (total + 255) / 256;
+  if (g > (size_t)cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" size_t ess_task_loss_workspace(int32_t K) { return (size_t)(2 + 3 * (K > 0 ? K : 0)) * sizeof(double); }
+
+extern "C" int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
+                             int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
+                             void* workspace, ess_stream_t stream) {
+  ESS_CHECK_ARG(logits && labels && loss && workspace && N > 0 && hw > 0, "task_loss: bad arguments");
+  ESS_CHECK_ARG(K > 0 && K <= KMAX, "task_loss: K=%d unsupported (max %d)", K, KMAX);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, ess_task_loss_workspace(K), st) != hipSuccess) {
+    ess_set_error("task_loss: memset failed");
+    return ESS_ELAUNCH;
+  }
+  const size_t total = (size_t)N * hw;
+  const unsigned grid = wave_uniform_grid(total, 2048);
+#define ESS_TL(KM_, G_, DZ_)                                                                                      \
+  hipLaunchKernelGGL((task_loss_kernel<KM_, G_>), dim3(grid), dim3(256), 0, st, logits, labels, (double*)workspace, loss, \
+                     DZ_, loss_scale, N, K, hw, ignore_index, use_dice, use_ce)
+  if (K <= 16) ESS_TL(16, false, nullptr); else ESS_TL(32, false, nullptr);
+  if (dlogits) {
+    if (K <= 16) ESS_TL(16, true, dlogits); else ESS_TL(32, true, dlogits);
+  } else
+#undef ESS_TL
+    hipLaunchKernelGGL(task_loss_value_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, loss_scale, K,
+                       ignore_index, use_dice, use_ce);
+  return ess_launch_status("task_loss");
+}
+
+extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int32_t N, int32_t K,
+                               int32_t hw, void* workspace, ess_stream_t stream) {
+  ESS_CHECK_ARG(a && b && loss && workspace && N > 0 && hw > 0, "sym_js_loss: bad arguments");
+  ESS_CHECK_ARG(K > 0 && K <= KMAX, "sym_js_loss: K=%d unsupported (max %d)", K, KMAX);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("sym_js_loss: memset failed"); return ESS_ELAUNCH; }
+  const size_t total = (size_t)N * hw;
+  if (K <= 16)
+    hipLaunchKernelGGL((sym_js_kernel<16>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+                       loss_scale, N, K, hw);
+  else
+    hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+                       loss_scale, N, K, hw);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)total * K,
+                     loss_scale);
+  return ess_launch_status("sym_js_loss");
+}
+
+extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n, void* workspace,
+                           ess_stream_t stream) {
+  ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("l1_loss: memset failed"); return ESS_ELAUNCH; }
+  hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+                     loss_scale, n);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
+  return ess_launch_status("l1_loss");
+}
+
+extern "C" int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float step_size, int32_t n_sma_ge5, ess_stream_t stream) {
+  ESS_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0, "radam_step: bad arguments");
+  const float neg_step = (float)(-(double)step_size * (double)lr);
+  hipLaunchKernelGGL(radam_kernel, dim3(wave_uniform_grid((size_t)n, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg,
+                     exp_avg_sq, n, neg_step, beta1, beta2, eps, n_sma_ge5);
+  return ess_launch_status("radam_step");
+}
+
+extern "C" int ess_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred_lbl, int64_t* conf, int32_t N,
+                                    int32_t K, int32_t hw, int32_t ignore_index, ess_stream_t stream) {
+  ESS_CHECK_ARG(logits && N > 0 && K > 0 && hw > 0, "argmax_confusion: bad arguments");
+  ESS_CHECK_ARG(K <= 64, "argmax_confusion: K=%d too large", K);
+  ESS_CHECK_ARG((conf == nullptr) || labels, "argmax_confusion: confusion needs labels");
+  hipLaunchKernelGGL(argmax_conf_kernel, dim3(wave_uniform_grid((size_t)N * hw, 1024)), dim3(256), K * K * sizeof(unsigned),
+                     (hipStream_t)stream, logits, labels, pred_lbl, (unsigned long long*)conf, N, K, hw, ignore_index);
+  return ess_launch_status("argmax_confusion");
+}

@@ -1,0 +1,118 @@
+// HBM-bound glue kernels: bilinear x2 (+skip sum), 2x2 sum pool, add, event normalisation.
+#include "common.h"
+
+namespace {
+
+// y[2H][2W] = bilinear_x2(a + b), align_corners=False: source coordinate max(0, (dst+0.5)/2 - 0.5),
+// second tap clamped at the border (torch upsample_bilinear2d semantics).
+__global__ void up2_bilinear_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                        int planes, int H, int W) {
+  const int W2 = 2 * W, H2 = 2 * H;
+  const size_t total = (size_t)planes * H2 * W2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W2;
+    const size_t t = i / W2;
+    const int yy = t % H2;
+    const size_t pl = t / H2;
+    const float sy = fmaxf(0.f, (yy + 0.5f) * 0.5f - 0.5f), sx = fmaxf(0.f, (x + 0.5f) * 0.5f - 0.5f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* pa = a + pl * H * W;
+    float v00 = pa[y0 * W + x0], v01 = pa[y0 * W + x1], v10 = pa[y1 * W + x0], v11 = pa[y1 * W + x1];
+    if (b) {
+      const float* pb = b + pl * H * W;
+      v00 += pb[y0 * W + x0]; v01 += pb[y0 * W + x1]; v10 += pb[y1 * W + x0]; v11 += pb[y1 * W + x1];
+    }
+    y[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  }
+}
+
+__global__ void sumpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Ho, int Wo, int acc) {
+  const size_t total = (size_t)planes * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xo = i % Wo;
+    const size_t t = i / Wo;
+    const int yo = t % Ho;
+    const size_t pl = t / Ho;
+    const float* p = x + (pl * 2 * Ho + 2 * yo) * (size_t)(2 * Wo) + 2 * xo;
+    const float s = (p[0] + p[1]) + (p[2 * Wo] + p[2 * Wo + 1]);
+    y[i] = acc ? y[i] + s : s;
+  }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a[i] + b[i];
+}
+
+// workspace: double[3] = {count, sum, sumsq}
+__global__ __launch_bounds__(256) void evnorm_reduce_kernel(const float* __restrict__ x, int64_t n, double* ws) {
+  __shared__ double red[16];
+  double c = 0, s = 0, ss = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    if (v != 0.f) { c += 1; s += v; ss += (double)v * v; }
+  }
+  c = block_sum_d(c, red);
+  s = block_sum_d(s, red);
+  ss = block_sum_d(ss, red);
+  if (threadIdx.x == 0) { atomicAdd(ws, c); atomicAdd(ws + 1, s); atomicAdd(ws + 2, ss); }
+}
+
+__global__ void evnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, const double* ws) {
+  const double cnt = ws[0];
+  float mean = 0.f, sd = 1.f;
+  const bool on = cnt > 0;
+  if (on) {
+    // fp32 arithmetic on the totals, as the reference does (inference_utils.py:104-105)
+    const float fs = (float)ws[1], fss = (float)ws[2], fc = (float)cnt;
+    mean = fs / fc;
+    sd = sqrtf(fss / fc - mean * mean);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = on ? (v != 0.f ? (v - mean) / sd : 0.f) : v;
+  }
+}
+
+inline unsigned grid_for(int64_t n, int bs = 256, int cap = 256 * 16) {
+  int64_t g = ceil_div64(n, bs);
+  return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int ess_upsample_bilinear2x_add(const float* a, const float* b, float* y, int32_t planes, int32_t H, int32_t W,
+                                           ess_stream_t stream) {
+  ESS_CHECK_ARG(a && y && planes > 0 && H > 0 && W > 0, "upsample_bilinear2x_add: bad arguments");
+  hipLaunchKernelGGL(up2_bilinear_add_kernel, dim3(grid_for((int64_t)planes * H * W * 4)), dim3(256), 0, (hipStream_t)stream, a,
+                     b, y, planes, H, W);
+  return ess_launch_status("upsample_bilinear2x_add");
+}
+
+extern "C" int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int32_t W_out, int32_t accumulate,
+                              ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && planes > 0 && H_out > 0 && W_out > 0, "sumpool2x2: bad arguments");
+  hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((int64_t)planes * H_out * W_out)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     planes, H_out, W_out, accumulate);
+  return ess_launch_status("sumpool2x2");
+}
+
+extern "C" int ess_add(const float* a, const float* b, float* y, int64_t n, ess_stream_t stream) {
+  ESS_CHECK_ARG(a && b && y && n > 0, "add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+  return ess_launch_status("add");
+}
+
+extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && workspace && n > 0, "event_normalize: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, 32, st) != hipSuccess) {
+    ess_set_error("event_normalize: memset failed");
+    return ESS_ELAUNCH;
+  }
+  hipLaunchKernelGGL(evnorm_reduce_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, n, (double*)workspace);
+  hipLaunchKernelGGL(evnorm_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, (const double*)workspace);
+  return ess_launch_status("event_normalize");
+}

@@ -1,0 +1,203 @@
+"""
+Autograd-aware wrappers over the HIP kernels (ess_amd.hip).  torch.autograd is used only as the tape:
+every forward and backward body is one or more libess_hip.so launches.
+"""
+import weakref
+
+import torch
+
+from . import hip
+
+_pack_cache = {}
+
+
+def packed_weight(spec, w, w2=None, kind=hip.W_CONV):
+    """Tile-major re-layout of a weight tensor, cached until the tensor is modified in place
+    (``_version`` bump: optimiser step, load_state_dict) or freed."""
+    ent = _pack_cache.get(id(w))
+    ver = (w._version, w2._version if w2 is not None else -1, w.data_ptr())
+    if ent is None or ent[0]() is not w or ent[1] != ver:
+        ent = (weakref.ref(w, lambda _, k=id(w): _pack_cache.pop(k, None)), ver, {})
+        _pack_cache[id(w)] = ent
+    key = (spec.key, kind)
+    pw = ent[2].get(key)
+    if pw is None:
+        pw = ent[2][key] = hip.pack_weights(spec, w.detach(), None if w2 is None else w2.detach(), kind)
+    return pw
+
+
+def _virt(x, mode):
+    m = 2 if mode != hip.SRC_DIRECT else 1
+    return x.shape[2] * m, x.shape[3] * m
+
+
+class Conv2dFn(torch.autograd.Function):
+    """conv2d(+bias) over the channel concat of (x0[, x1]), each optionally nearest-x2 upsampled on the
+    fly.  Replaces nn.Conv2d / torch.cat / F.interpolate(nearest) (models/style_networks.py:69-88,
+    158-193) and the ResNet prefix convs (:116-121).  Backward = data-gradient (same kernel, flipped
+    transposed weights) + weight gradient kernel, each only when needed."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1):
+        N, C0 = x0.shape[0], x0.shape[1]
+        C1 = x1.shape[1] if x1 is not None else 0
+        Hv, Wv = _virt(x0, mode0)
+        if x1 is not None and _virt(x1, mode1) != (Hv, Wv):
+            raise hip.EssHipError('Conv2dFn: the two sources disagree on the (virtual) extent')
+        Cout, k = weight.shape[0], weight.shape[2]
+        if weight.shape[1] != C0 + C1:
+            raise hip.EssHipError(f'Conv2dFn: weight expects {weight.shape[1]} input channels, got {C0}+{C1}')
+        spec = hip.conv_spec(N, Hv, Wv, C0, C1, Cout, k, stride, pad, mode0, mode1)
+        out = torch.empty(N, Cout, spec.H_out, spec.W_out, dtype=torch.float32, device=x0.device)
+        shift = hip.pack_rows(spec, bias.detach()) if bias is not None else None
+        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out)
+        ctx.spec = spec
+        ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
+        ctx.save_for_backward(x0, x1, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight = ctx.saved_tensors
+        spec = ctx.spec
+        (N, Hv, Wv, C0, C1, mode0, mode1, Cout, k, s, p, _, _, _, _) = spec.key
+        dy = dy.contiguous()
+        need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_x1, \
+            ctx.needs_input_grad[2], ctx.needs_input_grad[3] and ctx.has_bias
+        d0 = d1 = dw = db = None
+        if need0 or need1:
+            split = C0 if C1 > 0 else 0
+            if s == 1:
+                dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p, out_split=split)
+            else:
+                if (Hv & 1) or (Wv & 1):
+                    raise hip.EssHipError('data-gradient of a stride-2 conv needs even input extents')
+                dspec = hip.conv_spec(N, 2 * spec.H_out, 2 * spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p,
+                                      mode0=hip.SRC_ZERO_UP2, out_split=split)
+            assert (dspec.H_out, dspec.W_out) == (Hv, Wv), (dspec.H_out, dspec.W_out, Hv, Wv)
+            dv0 = torch.empty(N, C0, Hv, Wv, dtype=torch.float32, device=dy.device)
+            dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if C1 > 0 else None
+            hip.conv_forward(dspec, dy, None, packed_weight(dspec, weight, kind=hip.W_TRANSPOSED), out=dv0, out2=dv1)
+            if need0:
+                d0 = hip.sumpool2x2(dv0) if mode0 == hip.SRC_NEAREST_UP2 else dv0
+            if need1:
+                d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
+        if needw or needb:
+            dw = torch.empty_like(weight)
+            db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
+            hip.conv_wgrad(spec, x0, x1, dy, dw, db)
+            if not needw:
+                dw = None
+            if not needb:
+                db = None
+        return d0, d1, dw, db, None, None, None, None
+
+
+def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT):
+    return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1)
+
+
+class InstanceNormFn(torch.autograd.Function):
+    """y = act(InstanceNorm(x)) + residual   (models/style_networks.py:163-164,180-182,192)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, relu, eps):
+        y, stats = hip.instnorm_forward(x, residual, relu, eps)
+        ctx.relu = relu
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = hip.instnorm_backward(x, dy, stats, ctx.relu) if ctx.needs_input_grad[0] else None
+        dres = dy if ctx.needs_input_grad[1] else None
+        return dx, dres, None, None
+
+
+def instance_norm(x, residual=None, relu=False, eps=1e-5):
+    return InstanceNormFn.apply(x, residual, relu, eps)
+
+
+class BatchNormTrainFn(torch.autograd.Function):
+    """y = act(BatchNorm_train(x) + residual), running stats updated in place (torchvision BasicBlock
+    as used by StyleEncoderE2VID, models/style_networks.py:116-121)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
+                                               momentum, eps, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, y, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_dx, need_dres, need_g, need_b = ctx.needs_input_grad[0:4]
+        dgamma = torch.empty_like(gamma) if (need_g or need_b) else None
+        dbeta = torch.empty_like(gamma) if (need_g or need_b) else None
+        dx, dres = hip.batchnorm_train_backward(x, y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, dgamma, dbeta)
+        return dx, dres, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1, eps=1e-5):
+    return BatchNormTrainFn.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
+
+
+class TaskLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, use_dice, use_ce):
+        loss, dz = hip.task_loss(logits, labels, ctx.needs_input_grad[0], 1.0, ignore_index, use_dice, use_ce)
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dz, = ctx.saved_tensors
+        return dz * g, None, None, None, None
+
+
+class SymJSFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, da = hip.sym_js_loss(a, b, ctx.needs_input_grad[0], 1.0)
+        ctx.save_for_backward(da)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, = ctx.saved_tensors
+        return da * g, None
+
+
+class L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, da = hip.l1_loss(a, b, ctx.needs_input_grad[0], 1.0)
+        ctx.save_for_backward(da)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        da, = ctx.saved_tensors
+        return da * g, None
+
+
+def task_loss(logits, labels, ignore_index=255, use_dice=True, use_ce=True):
+    return TaskLossFn.apply(logits.contiguous(), labels.contiguous(), ignore_index, use_dice, use_ce)
+
+
+def sym_js_div(a, b):
+    """Gradient flows to `a` only; `b` is always a no-grad prediction in the trainers."""
+    if b.requires_grad:
+        raise hip.EssHipError('sym_js_div: the second argument must not require grad (training/ess_trainer.py:234-237)')
+    return SymJSFn.apply(a.contiguous(), b.contiguous())
+
+
+def l1_loss(a, b):
+    if b.requires_grad:
+        raise hip.EssHipError('l1_loss: the second argument must not require grad')
+    return L1Fn.apply(a.contiguous(), b.contiguous())

@@ -1,0 +1,300 @@
+"""
+ctypes binding of libess_hip.so (include/ess_hip.h).  This is the only place the C ABI is touched.
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).  There is
+NO fallback: if the library is missing, or a tensor is not a contiguous fp32 CUDA(HIP) tensor, the
+call raises.  PyTorch only supplies device memory and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libess_hip.so')
+
+SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
+EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+W_CONV, W_TRANSPOSED = 0, 1
+
+EXPORTS = [
+    'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',
+    'ess_conv2d_forward', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_instnorm_forward',
+    'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
+    'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
+    'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
+]
+
+
+class EssConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in (
+        'N', 'H_in', 'W_in', 'C0', 'C1', 'mode0', 'mode1', 'C_out', 'H_out', 'W_out', 'ksize', 'stride', 'pad',
+        'epilogue', 'act', 'hidden', 'out_split')]
+
+
+class EssConvPlan(Structure):
+    _fields_ = [('cout_tile', c_int32), ('ck', c_int32), ('n_chunks', c_int32), ('n_cout_tiles', c_int32),
+                ('packed_elems', c_int64), ('rows_padded', c_int32), ('lds_bytes', c_int32)]
+
+
+class EssHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libess_hip.so once.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EssHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950). ess_amd has no CPU or eager fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        L.ess_last_error.restype = c_char_p
+        L.ess_conv2d_wgrad_workspace.restype = c_size_t
+        L.ess_conv2d_wgrad_workspace.argtypes = [POINTER(EssConvDesc)]
+        L.ess_task_loss_workspace.restype = c_size_t
+        L.ess_task_loss_workspace.argtypes = [c_int32]
+        P, F, I, I64 = c_void_p, c_float, c_int32, c_int64
+        D = POINTER(EssConvDesc)
+        sig = {
+            'ess_conv2d_plan': [D, POINTER(EssConvPlan)],
+            'ess_conv2d_pack_weights': [D, c_int, P, P, P, P],
+            'ess_conv2d_pack_rows': [D, P, P, F, P, P],
+            'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P],
+            'ess_conv2d_wgrad': [D, P, P, P, P, P, c_int, P, c_size_t, P],
+            'ess_instnorm_forward': [P, P, P, P, I, I, F, I, P],
+            'ess_instnorm_backward': [P, P, P, P, I, I, I, P],
+            'ess_batchnorm_train_forward': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P],
+            'ess_batchnorm_train_backward': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+            'ess_upsample_bilinear2x_add': [P, P, P, I, I, I, P],
+            'ess_sumpool2x2': [P, P, I, I, I, I, P],
+            'ess_add': [P, P, P, I64, P],
+            'ess_event_normalize': [P, P, I64, P, P],
+            'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, P],
+            'ess_sym_js_loss': [P, P, P, P, F, I, I, I, P, P],
+            'ess_l1_loss': [P, P, P, P, F, I64, P, P],
+            'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
+            'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
+        }
+        for name, argtypes in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EssHipError(f'{what} failed (rc={rc}): {lib().ess_last_error().decode()}')
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32, allow_none=True):
+    """Device pointer of a contiguous CUDA tensor (or NULL)."""
+    if t is None:
+        if not allow_none:
+            raise EssHipError('required tensor is None')
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise EssHipError('ess_amd kernels need CUDA(HIP) tensors; there is no CPU path (got a CPU tensor)')
+    if t.dtype != dtype:
+        raise EssHipError(f'expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise EssHipError('expected a contiguous tensor')
+    return c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------ conv
+_desc_cache = {}
+
+
+class ConvSpec:
+    """Descriptor + plan of one convolution shape (cached)."""
+
+    def __init__(self, key):
+        (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split) = key
+        H_out = (H_in + 2 * p - k) // s + 1
+        W_out = (W_in + 2 * p - k) // s + 1
+        self.desc = EssConvDesc(N, H_in, W_in, C0, C1, mode0, mode1, C_out, H_out, W_out, k, s, p, epi, act, hidden,
+                                out_split)
+        self.plan = EssConvPlan()
+        _check(lib().ess_conv2d_plan(byref(self.desc), byref(self.plan)), 'ess_conv2d_plan')
+        self.key = key
+        self.H_out, self.W_out = H_out, W_out
+        self.wgrad_ws = None
+
+
+def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC_DIRECT, epi=EPI_LINEAR, act=ACT_NONE,
+              hidden=0, out_split=0):
+    key = (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split)
+    sp = _desc_cache.get(key)
+    if sp is None:
+        sp = _desc_cache[key] = ConvSpec(key)
+    return sp
+
+
+def pack_weights(spec, w, w2=None, kind=W_CONV):
+    out = torch.empty(spec.plan.packed_elems, dtype=torch.float32, device=w.device)
+    _check(lib().ess_conv2d_pack_weights(byref(spec.desc), kind, ptr(w), ptr(w2), ptr(out), stream()),
+           'ess_conv2d_pack_weights')
+    return out
+
+
+def pack_rows(spec, v, v2=None, fill=0.0):
+    out = torch.empty(spec.plan.rows_padded, dtype=torch.float32, device=v.device)
+    _check(lib().ess_conv2d_pack_rows(byref(spec.desc), ptr(v), ptr(v2), c_float(fill), ptr(out), stream()),
+           'ess_conv2d_pack_rows')
+    return out
+
+
+def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None,
+                 out2=None):
+    _check(lib().ess_conv2d_forward(byref(spec.desc), ptr(src0), ptr(src1), ptr(packed_w), ptr(scale), ptr(shift),
+                                    ptr(residual), ptr(aux0), ptr(aux1), ptr(out), ptr(out2), stream()),
+           'ess_conv2d_forward')
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='ws'):
+    """Grow-only scratch buffer per (device, stream, tag): kernels on one stream are ordered, so reuse is safe."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(spec, src0, src1, dy, dw, db=None, accumulate=False):
+    nbytes = lib().ess_conv2d_wgrad_workspace(byref(spec.desc))
+    if nbytes == 0:
+        raise EssHipError('ess_conv2d_wgrad_workspace: ' + lib().ess_last_error().decode())
+    ws = workspace(nbytes, dy.device, 'wgrad')
+    _check(lib().ess_conv2d_wgrad(byref(spec.desc), ptr(src0), ptr(src1), ptr(dy), ptr(dw), ptr(db), int(accumulate),
+                                  c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_conv2d_wgrad')
+
+
+# ------------------------------------------------------------------------------------------ norms
+def instnorm_forward(x, residual, relu, eps=1e-5):
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
+    _check(lib().ess_instnorm_forward(ptr(x), ptr(residual), ptr(y), ptr(stats), N * C, H * W, c_float(eps), int(relu),
+                                      stream()), 'ess_instnorm_forward')
+    return y, stats
+
+
+def instnorm_backward(x, dy, stats, relu):
+    N, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().ess_instnorm_backward(ptr(x), ptr(dy), ptr(stats), ptr(dx), N * C, H * W, int(relu), stream()),
+           'ess_instnorm_backward')
+    return dx
+
+
+def batchnorm_train_forward(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    _check(lib().ess_batchnorm_train_forward(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean),
+                                             ptr(running_var), c_float(momentum), c_float(eps), ptr(y), ptr(stats), N, C,
+                                             H * W, int(relu), stream()), 'ess_batchnorm_train_forward')
+    return y, stats
+
+
+def batchnorm_train_backward(x, y, dy, gamma, stats, relu, need_dx=True, need_dres=False, dgamma=None, dbeta=None,
+                             accumulate=False):
+    N, C, H, W = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dres = torch.empty_like(x) if need_dres else None
+    _check(lib().ess_batchnorm_train_backward(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dres),
+                                              ptr(dgamma), ptr(dbeta), int(accumulate), N, C, H * W, int(relu), stream()),
+           'ess_batchnorm_train_backward')
+    return dx, dres
+
+
+# ------------------------------------------------------------------------------------------ glue
+def upsample_bilinear2x_add(a, b=None):
+    N, C, H, W = a.shape
+    y = torch.empty(N, C, 2 * H, 2 * W, dtype=torch.float32, device=a.device)
+    _check(lib().ess_upsample_bilinear2x_add(ptr(a), ptr(b), ptr(y), N * C, H, W, stream()), 'ess_upsample_bilinear2x_add')
+    return y
+
+
+def sumpool2x2(x, out=None, accumulate=False):
+    N, C, H, W = x.shape
+    if out is None:
+        out = torch.empty(N, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+    _check(lib().ess_sumpool2x2(ptr(x), ptr(out), N * C, H // 2, W // 2, int(accumulate), stream()), 'ess_sumpool2x2')
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _check(lib().ess_add(ptr(a), ptr(b), ptr(out), a.numel(), stream()), 'ess_add')
+    return out
+
+
+def event_normalize(x):
+    y = torch.empty_like(x)
+    ws = workspace(64, x.device, 'evnorm')
+    _check(lib().ess_event_normalize(ptr(x), ptr(y), x.numel(), c_void_p(ws.data_ptr()), stream()), 'ess_event_normalize')
+    return y
+
+
+# ------------------------------------------------------------------------------------------ losses / optimiser / metrics
+def task_loss(logits, labels, want_grad, scale=1.0, ignore_index=255, use_dice=True, use_ce=True):
+    N, K, H, W = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dz = torch.empty_like(logits) if want_grad else None
+    ws = workspace(lib().ess_task_loss_workspace(K), logits.device, 'loss')
+    _check(lib().ess_task_loss(ptr(logits), ptr(labels, torch.int64), ptr(loss), ptr(dz), c_float(scale), N, K, H * W,
+                               int(ignore_index), int(use_dice), int(use_ce), c_void_p(ws.data_ptr()), stream()),
+           'ess_task_loss')
+    return loss, dz
+
+
+def sym_js_loss(a, b, want_grad, scale=1.0):
+    N, K, H, W = a.shape
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    ws = workspace(64, a.device, 'loss')
+    _check(lib().ess_sym_js_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), N, K, H * W, c_void_p(ws.data_ptr()),
+                                 stream()), 'ess_sym_js_loss')
+    return loss, da
+
+
+def l1_loss(a, b, want_grad, scale=1.0):
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    ws = workspace(64, a.device, 'loss')
+    _check(lib().ess_l1_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), a.numel(), c_void_p(ws.data_ptr()),
+                             stream()), 'ess_l1_loss')
+    return loss, da
+
+
+def radam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_size, n_sma_ge5):
+    _check(lib().ess_radam_step(ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), p.numel(), c_float(lr), c_float(beta1),
+                                c_float(beta2), c_float(eps), c_float(step_size), int(n_sma_ge5), stream()),
+           'ess_radam_step')
+
+
+def argmax_confusion(logits, labels=None, conf=None, ignore_index=255, want_pred=True):
+    N, K, H, W = logits.shape
+    pred = torch.empty(N, H, W, dtype=torch.int64, device=logits.device) if want_pred else None
+    _check(lib().ess_argmax_confusion(ptr(logits), ptr(labels, torch.int64), ptr(pred, torch.int64), ptr(conf, torch.int64),
+                                      N, K, H * W, int(ignore_index), stream()), 'ess_argmax_confusion')
+    return pred

@@ -1,0 +1,179 @@
+/*
+ * ess_hip.h -- C ABI of libess_hip.so: the MI355X (gfx950) kernels under the ESS hot path.
+ *
+ * The reference (uzh-rpg/ess) has no FFI: its hot path is PyTorch modules calling cuDNN through
+ * torch ops.  Each entry point below names the torch op sequence of the reference it replaces
+ * (file:line under the reference root) so that a maintainer can bind it from the reference's own
+ * nn.Module.forward (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions:
+ *   - all pointers are DEVICE pointers into caller-owned storage (PyTorch caching allocator);
+ *     nothing is allocated, freed or retained by the library; workspaces are caller-provided;
+ *   - tensors are dense NCHW fp32 unless stated; labels are int64;
+ *   - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream); the library
+ *     never synchronises, never calls hipSetDevice and keeps no mutable global state (re-entrant);
+ *   - return value: 0 on success, negative ESS_E* otherwise; ess_last_error() gives a thread-local
+ *     message.  Nothing throws across the ABI.
+ */
+#ifndef ESS_HIP_H
+#define ESS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ess_stream_t; /* hipStream_t */
+
+enum { ESS_OK = 0, ESS_EINVAL = -22, ESS_ENOTSUP = -95, ESS_ELAUNCH = -5 };
+
+/* how a conv source is read (fused into the LDS tile load) */
+enum { ESS_SRC_DIRECT = 0, ESS_SRC_NEAREST_UP2 = 1, ESS_SRC_ZERO_UP2 = 2 };
+/* conv epilogues (fused into the accumulator write-out) */
+enum {
+  ESS_EPI_LINEAR = 0,  /* y = act(acc*scale + shift (+ residual))                                   */
+  ESS_EPI_LSTM = 1,    /* ConvLSTM gates -> (h', c')            e2vid/model/submodules.py:212-230     */
+  ESS_EPI_GRU_UR = 2,  /* ConvGRU update/reset -> (u, r*h)      e2vid/model/submodules.py:268-270     */
+  ESS_EPI_GRU_OUT = 3  /* ConvGRU candidate -> h'               e2vid/model/submodules.py:270-271     */
+};
+enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3 };
+/* weight sources for ess_conv2d_pack_weights */
+enum {
+  ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
+  ESS_W_TRANSPOSED = 1   /* weight [C_in][C_out][k][k] used spatially flipped: nn.ConvTranspose2d
+                            forward, or the data-gradient of a Conv2d (pass its weight)              */
+};
+
+/* One 2-D convolution over the channel-concatenation of up to two sources.
+ * Replaces nn.Conv2d / torch.cat / F.interpolate(nearest) / BatchNorm2d(eval) / activation chains:
+ *   ConvLayer.forward            e2vid/model/submodules.py:24-31
+ *   ResidualBlock.forward        e2vid/model/submodules.py:157-172
+ *   ConvLSTM.forward             e2vid/model/submodules.py:190-230
+ *   ConvGRU.forward              e2vid/model/submodules.py:255-273
+ *   ReLUINSConv2d / INSResBlock convs, cat+nearest-up of SemSegE2VID.forward
+ *                                models/style_networks.py:69-88,158-193                             */
+typedef struct EssConvDesc {
+  int32_t N;
+  int32_t H_in, W_in;   /* extent the filter slides over (i.e. AFTER per-source x2 upsampling)       */
+  int32_t C0, C1;       /* channels of source 0 / source 1 (C1 = 0: single source)                   */
+  int32_t mode0, mode1; /* ESS_SRC_*: a *_UP2 source is stored at (H_in/2, W_in/2)                   */
+  int32_t C_out, H_out, W_out;
+  int32_t ksize, stride, pad;
+  int32_t epilogue;     /* ESS_EPI_*                                                                 */
+  int32_t act;          /* ESS_ACT_* (LINEAR epilogue only)                                          */
+  int32_t hidden;       /* recurrent epilogues: hidden channels (C_out = 4*hidden LSTM, 2*hidden
+                           GRU_UR, hidden GRU_OUT)                                                   */
+  int32_t out_split;    /* LINEAR: >0 writes channels [0,out_split) to `out` and the rest to `out2`
+                           (data-gradient of a two-source conv)                                      */
+} EssConvDesc;
+
+typedef struct EssConvPlan {
+  int32_t cout_tile;    /* output channels per workgroup (32 or 64)                                  */
+  int32_t ck;           /* input channels per LDS chunk                                              */
+  int32_t n_chunks, n_cout_tiles;
+  int64_t packed_elems; /* floats in the packed weight buffer                                        */
+  int32_t rows_padded;  /* n_cout_tiles * cout_tile = length of packed scale/shift vectors           */
+  int32_t lds_bytes;
+} EssConvPlan;
+
+const char* ess_last_error(void);
+int ess_version(void);
+
+int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
+
+/* Re-layout a weight tensor for ess_conv2d_forward (tile-major, epilogue row permutation applied).
+ * w_kind ESS_W_CONV: w is [C_out][C0+C1][k][k]; ESS_W_TRANSPOSED: w is [C0+C1][C_out][k][k].
+ * For ESS_EPI_GRU_UR pass w = update_gate.weight and w2 = reset_gate.weight.                        */
+int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const float* w, const float* w2,
+                            float* packed, ess_stream_t stream);
+/* Same permutation/padding for a per-output-channel vector (bias, folded BN scale/shift).
+ * v2: second vector for GRU_UR (reset gate); fill: value for padded rows.                           */
+int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, float fill,
+                         float* packed, ess_stream_t stream);
+
+/* src1 may be NULL when C1 == 0.  scale/shift: packed (ess_conv2d_pack_rows) or NULL.
+ * residual: [N][C_out][H_out][W_out] or NULL (LINEAR).
+ * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev ; aux1: GRU_OUT u.
+ * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h | LINEAR split.  */
+int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const float* src1, const float* packed_w,
+                       const float* scale, const float* shift, const float* residual, const float* aux0,
+                       const float* aux1, float* out, float* out2, ess_stream_t stream);
+
+/* Weight gradient of the same convolution (replaces cuDNN wgrad under autograd for
+ * models/style_networks.py:158-193 and the ResNet prefix :116-121).
+ * dy: [N][C_out][H_out][W_out].  dw: [C_out][C0+C1][k][k] (overwritten, or accumulated when
+ * accumulate != 0).  db: [C_out] or NULL.  workspace: ess_conv2d_wgrad_workspace() bytes.          */
+size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d);
+int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1, const float* dy,
+                     float* dw, float* db, int accumulate, void* workspace, size_t workspace_bytes,
+                     ess_stream_t stream);
+
+/* InstanceNorm2d(affine=False, eps) (+residual)(+ReLU): models/style_networks.py:163-164,180-182,192.
+ * y = act(IN(x)) + residual.  stats: [N*C][2] = (mean, rstd) saved for backward.                    */
+int ess_instnorm_forward(const float* x, const float* residual, float* y, float* stats, int32_t planes,
+                         int32_t hw, float eps, int32_t relu, ess_stream_t stream);
+/* dx from dy (gradient w.r.t. y; the residual branch gradient is dy itself, handled by the caller). */
+int ess_instnorm_backward(const float* x, const float* dy, const float* stats, float* dx, int32_t planes,
+                          int32_t hw, int32_t relu, ess_stream_t stream);
+
+/* BatchNorm2d, training mode (ResNet prefix of StyleEncoderE2VID, models/style_networks.py:116-121):
+ * batch statistics, running-stat update with momentum (unbiased var), y = act(bn(x) + residual).
+ * stats: [C][2] = (mean, rstd).                                                                     */
+int ess_batchnorm_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* y,
+                                float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, ess_stream_t stream);
+/* dy is the gradient w.r.t. y; `y` is needed for the ReLU mask; d_residual (nullable) receives the
+ * masked gradient.  dgamma/dbeta: [C] overwritten or accumulated.                                   */
+int ess_batchnorm_train_backward(const float* x, const float* y, const float* dy, const float* gamma,
+                                 const float* stats, float* dx, float* d_residual, float* dgamma, float* dbeta,
+                                 int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu,
+                                 ess_stream_t stream);
+
+/* y = bilinear_x2(a + b), align_corners=False (UpsampleConvLayer input: e2vid/model/submodules.py:84,
+ * skip_sum e2vid/model/unet.py:12-13,176).  b may be NULL.  a: [planes][H][W] -> y: [planes][2H][2W] */
+int ess_upsample_bilinear2x_add(const float* a, const float* b, float* y, int32_t planes, int32_t H,
+                                int32_t W, ess_stream_t stream);
+/* 2x2 sum pooling = backward of nearest x2 upsampling (F.interpolate, models/style_networks.py:77).
+ * accumulate != 0 adds into y.                                                                      */
+int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int32_t W_out, int32_t accumulate,
+                   ess_stream_t stream);
+/* y = a + b (skip_sum, e2vid/model/unet.py:12-13); in place allowed.                                */
+int ess_add(const float* a, const float* b, float* y, int64_t n, ess_stream_t stream);
+
+/* EventPreprocessor.__call__ normalisation (e2vid/utils/inference_utils.py:96-107) over the whole
+ * tensor of n floats: non-zero mean/std, y = (x!=0)*(x-mean)/std; identity copy when all-zero.
+ * workspace: >= 32 bytes, zeroed by the call.  No host synchronisation.                             */
+int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream);
+
+/* TaskLoss = Dice + CrossEntropy (utils/loss_functions.py:6-24,96-135), forward AND gradient w.r.t.
+ * logits in one pass pair.  logits [N][K][H][W], labels int64 [N][H][W].  loss: 1 float.
+ * dlogits (nullable): d(loss*loss_scale)/dlogits.  workspace: ess_task_loss_workspace(K) bytes.     */
+size_t ess_task_loss_workspace(int32_t K);
+int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
+                  int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
+                  void* workspace, ess_stream_t stream);
+/* symJSDivLoss (utils/loss_functions.py:27-37): loss (1 float) and gradient w.r.t. `a` only
+ * (the other argument is always computed under no_grad by the trainers).                            */
+int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int32_t N,
+                    int32_t K, int32_t hw, void* workspace, ess_stream_t stream);
+/* L1Loss mean (training/ess_trainer.py:217-229): loss and gradient w.r.t. a.                        */
+int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n,
+                void* workspace, ess_stream_t stream);
+
+/* RAdam.step over ONE flat parameter buffer (utils/radam.py:15-80, weight_decay = 0).
+ * step_size / n_sma_ge5 are computed by the host exactly as radam.py:49-64.                         */
+int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float step_size, int32_t n_sma_ge5,
+                   ess_stream_t stream);
+
+/* argmax over K + confusion-matrix accumulation (training/ess_trainer.py:485; evaluation/metrics.py:4-24)
+ * pred_lbl (nullable): int64 [N][H][W]; conf: int64 [K][K], accumulated (conf[label][pred]).         */
+int ess_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred_lbl, int64_t* conf,
+                         int32_t N, int32_t K, int32_t hw, int32_t ignore_index, ess_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESS_HIP_H */

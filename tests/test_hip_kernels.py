@@ -1,0 +1,295 @@
+"""GPU tier: every HIP kernel (through the C ABI) against plain fp32 torch-CPU restatements of the same op
+(for the composite ops: the oracle).  fp32 tolerance: 1e-4 relative to the output scale unless stated."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ess_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def H():
+    from ess_amd import hip
+    hip.lib()
+    return hip
+
+
+def dev(t):
+    return None if t is None else t.cuda().contiguous()
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-6)).item()
+
+
+def _up(x, mode):
+    if mode == 1:
+        return F.interpolate(x, scale_factor=2, mode='nearest')
+    if mode == 2:
+        z = torch.zeros(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])
+        z[:, :, ::2, ::2] = x
+        return z
+    return x
+
+
+CONV_CASES = [
+    # N, C0, C1, Cout, H, W (virtual), k, s, p, mode0, mode1, act, affine, residual
+    (2, 2, 0, 32, 24, 40, 5, 1, 2, 0, 0, 1, False, False),     # head
+    (1, 5, 0, 32, 22, 36, 5, 1, 2, 0, 0, 1, True, False),      # head with 5 bins, odd-ish size
+    (2, 32, 0, 64, 24, 40, 5, 2, 2, 0, 0, 1, True, False),     # encoder conv 5x5 s2 + BN + relu
+    (1, 64, 0, 128, 25, 44, 5, 2, 2, 0, 0, 1, True, False),    # odd extent
+    (2, 256, 0, 256, 6, 10, 3, 1, 1, 0, 0, 1, True, True),     # resblock conv2 + BN + residual + relu
+    (2, 64, 0, 32, 48, 80, 5, 1, 2, 0, 0, 1, True, False),     # decoder conv 5x5
+    (2, 32, 0, 1, 48, 80, 1, 1, 0, 0, 0, 2, True, False),      # pred 1x1 + sigmoid
+    (2, 128, 128, 128, 12, 20, 3, 1, 1, 1, 0, 0, True, False),  # decoder: cat(nearest_up(x), skip)
+    (1, 64, 0, 32, 16, 24, 3, 1, 1, 1, 0, 0, True, False),     # nearest-up single source
+    (2, 32, 0, 11, 24, 40, 1, 1, 0, 0, 0, 0, True, False),     # final 1x1 32->11
+    (2, 1, 0, 64, 24, 40, 7, 2, 3, 0, 0, 0, False, False),     # resnet stem 7x7 s2
+    (2, 64, 0, 128, 12, 20, 3, 2, 1, 0, 0, 0, False, False),   # resnet 3x3 s2
+    (2, 64, 0, 128, 12, 20, 1, 2, 0, 0, 0, 0, False, False),   # resnet downsample 1x1 s2
+    (1, 16, 16, 64, 9, 13, 3, 1, 1, 0, 0, 3, True, False),     # small odd, tanh
+    (1, 24, 0, 40, 33, 70, 3, 1, 1, 0, 0, 0, True, False),     # channels not multiples of the chunk/tile
+    (1, 8, 0, 16, 64, 64, 3, 1, 1, 2, 0, 0, False, False),     # zero-insert source
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward(H, case):
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, act, affine, res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    d0 = 2 if m0 else 1
+    d1 = 2 if m1 else 1
+    x0 = torch.randn(N, C0, Hv // d0, Wv // d0, generator=g)
+    x1 = torch.randn(N, C1, Hv // d1, Wv // d1, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, k, k, generator=g) / math.sqrt((C0 + C1) * k * k)
+    scale = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    shift = torch.randn(Cout, generator=g) if affine else None
+    xin = _up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), _up(x1, m1)], 1)
+    ref = F.conv2d(xin, w, None, s, p)
+    if affine:
+        ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r
+    ref = [ref, torch.relu(ref), torch.sigmoid(ref), torch.tanh(ref)][act]
+    spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, k, s, p, m0, m1, act=act)
+    pw = H.pack_weights(spec, dev(w))
+    out = torch.full(ref.shape, float('nan')).cuda()
+    H.conv_forward(spec, dev(x0), dev(x1), pw, H.pack_rows(spec, dev(scale), fill=1.0) if affine else None,
+                   H.pack_rows(spec, dev(shift)) if affine else None, dev(r), out=out)
+    assert relerr(out, ref) < 2e-5
+
+
+def test_conv_transposed_forward(H):
+    # TransposedConvLayer: ConvTranspose2d k5 s2 p2 output_padding 1 (e2vid/model/submodules.py:34-62)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 12, 20, generator=g)
+    wt = torch.randn(32, 16, 5, 5, generator=g) * 0.05
+    b = torch.randn(16, generator=g)
+    ref = torch.relu(F.conv_transpose2d(x, wt, b, stride=2, padding=2, output_padding=1))
+    spec = H.conv_spec(2, 24, 40, 32, 0, 16, 5, 1, 2, H.SRC_ZERO_UP2, act=H.ACT_RELU)
+    out = torch.empty(2, 16, 24, 40).cuda()
+    H.conv_forward(spec, dev(x), None, H.pack_weights(spec, dev(wt), kind=H.W_TRANSPOSED), None,
+                   H.pack_rows(spec, dev(b)), out=out)
+    assert relerr(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize('hid,Hh,Ww,first', [(64, 12, 20, False), (16, 9, 13, False), (256, 3, 5, True), (8, 6, 10, False)])
+def test_conv_lstm(H, hid, Hh, Ww, first):
+    g = torch.Generator().manual_seed(hid)
+    sd = {'r.Gates.weight': torch.randn(4 * hid, 2 * hid, 3, 3, generator=g) / math.sqrt(18 * hid),
+          'r.Gates.bias': torch.randn(4 * hid, generator=g) * 0.1}
+    x = torch.randn(2, hid, Hh, Ww, generator=g)
+    st = None if first else (torch.randn(2, hid, Hh, Ww, generator=g), torch.randn(2, hid, Hh, Ww, generator=g))
+    h_ref, c_ref = O.conv_lstm(sd, 'r', x, st)
+    spec = H.conv_spec(2, Hh, Ww, hid, hid, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid)
+    hp = dev(st[0]) if st else torch.zeros(2, hid, Hh, Ww).cuda()
+    h = torch.empty(2, hid, Hh, Ww).cuda()
+    c = torch.empty_like(h)
+    H.conv_forward(spec, dev(x), hp, H.pack_weights(spec, dev(sd['r.Gates.weight'])), None,
+                   H.pack_rows(spec, dev(sd['r.Gates.bias'])), aux0=dev(st[1]) if st else None, out=h, out2=c)
+    assert relerr(h, h_ref) < 2e-5 and relerr(c, c_ref) < 2e-5
+
+
+@pytest.mark.parametrize('hid,Hh,Ww', [(64, 12, 20), (16, 9, 13), (8, 6, 10), (256, 3, 5)])
+def test_conv_gru(H, hid, Hh, Ww):
+    g = torch.Generator().manual_seed(hid + 1)
+    sd = {}
+    for n in ('update_gate', 'reset_gate', 'out_gate'):
+        sd[f'r.{n}.weight'] = torch.randn(hid, 2 * hid, 3, 3, generator=g) / math.sqrt(18 * hid)
+        sd[f'r.{n}.bias'] = torch.randn(hid, generator=g) * 0.1
+    x = torch.randn(2, hid, Hh, Ww, generator=g)
+    hprev = torch.randn(2, hid, Hh, Ww, generator=g)
+    ref = O.conv_gru(sd, 'r', x, hprev)
+    s1 = H.conv_spec(2, Hh, Ww, hid, hid, 2 * hid, 3, 1, 1, epi=H.EPI_GRU_UR, hidden=hid)
+    s2 = H.conv_spec(2, Hh, Ww, hid, hid, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, hidden=hid)
+    xd, hd = dev(x), dev(hprev)
+    u = torch.empty_like(hd)
+    rh = torch.empty_like(hd)
+    H.conv_forward(s1, xd, hd, H.pack_weights(s1, dev(sd['r.update_gate.weight']), dev(sd['r.reset_gate.weight'])), None,
+                   H.pack_rows(s1, dev(sd['r.update_gate.bias']), dev(sd['r.reset_gate.bias'])), aux0=hd, out=u, out2=rh)
+    hn = torch.empty_like(hd)
+    H.conv_forward(s2, xd, rh, H.pack_weights(s2, dev(sd['r.out_gate.weight'])), None,
+                   H.pack_rows(s2, dev(sd['r.out_gate.bias'])), aux0=hd, aux1=u, out=hn)
+    assert relerr(hn, ref) < 2e-5
+
+
+GRAD_CASES = [
+    # N, C0, C1, Cout, H, W (virtual), k, s, p, mode0, bias
+    (2, 256, 0, 256, 6, 10, 3, 1, 1, 0, True),
+    (2, 128, 128, 128, 12, 20, 3, 1, 1, 1, True),
+    (2, 64, 0, 32, 24, 40, 3, 1, 1, 1, True),
+    (2, 32, 0, 11, 24, 40, 1, 1, 0, 0, True),
+    (2, 1, 0, 64, 24, 40, 7, 2, 3, 0, False),
+    (2, 64, 0, 128, 12, 20, 3, 2, 1, 0, False),
+    (2, 64, 0, 128, 12, 20, 1, 2, 0, 0, False),
+    (1, 24, 0, 40, 9, 14, 3, 1, 1, 0, True),
+    (3, 64, 64, 64, 25, 44, 3, 1, 1, 0, True),
+]
+
+
+@pytest.mark.parametrize('case', GRAD_CASES)
+def test_conv_backward(H, case):
+    from ess_amd import functional as Fn
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, has_b = case
+    g = torch.Generator().manual_seed(sum(case))
+    d0 = 2 if m0 else 1
+    x0 = torch.randn(N, C0, Hv // d0, Wv // d0, generator=g, requires_grad=True)
+    x1 = torch.randn(N, C1, Hv, Wv, generator=g, requires_grad=True) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, k, k, generator=g) / math.sqrt((C0 + C1) * k * k)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True) if has_b else None
+    xin = _up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), x1], 1)
+    y = F.conv2d(xin, w, b, s, p)
+    gy = torch.randn(y.shape, generator=g)
+    refs = torch.autograd.grad(y, [t for t in (x0, x1, w, b) if t is not None], gy)
+    a0, a1, aw, ab = [None if t is None else t.detach().cuda().requires_grad_(True) for t in (x0, x1, w, b)]
+    yd = Fn.conv2d(a0, aw, ab, s, p, x1=a1, mode0=m0)
+    assert relerr(yd, y) < 2e-5
+    outs = torch.autograd.grad(yd, [t for t in (a0, a1, aw, ab) if t is not None], gy.cuda())
+    for name, o, r in zip([n for n, t in zip('x0 x1 w b'.split(), (x0, x1, w, b)) if t is not None], outs, refs):
+        assert relerr(o, r) < 5e-5, name
+
+
+@pytest.mark.parametrize('shape,relu,res', [((2, 64, 12, 20), True, False), ((2, 256, 3, 5), False, True),
+                                            ((1, 7, 9, 13), True, True), ((2, 32, 48, 80), True, False)])
+def test_instance_norm(H, shape, relu, res):
+    from ess_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(shape, generator=g) * 2 + 0.3).requires_grad_(True)
+    r = torch.randn(shape, generator=g, requires_grad=True) if res else None
+    y = F.instance_norm(x, eps=1e-5)
+    if relu:
+        y = torch.relu(y)
+    if res:
+        y = y + r
+    gy = torch.randn(shape, generator=g)
+    refs = torch.autograd.grad(y, [x] + ([r] if res else []), gy)
+    xd = x.detach().cuda().requires_grad_(True)
+    rd = r.detach().cuda().requires_grad_(True) if res else None
+    yd = Fn.instance_norm(xd, rd, relu)
+    assert relerr(yd, y) < 1e-5
+    outs = torch.autograd.grad(yd, [xd] + ([rd] if res else []), gy.cuda())
+    for o, rr in zip(outs, refs):
+        assert relerr(o, rr) < 5e-5
+
+
+@pytest.mark.parametrize('shape,relu,res', [((2, 64, 12, 20), True, False), ((3, 128, 6, 10), True, True),
+                                            ((2, 5, 7, 9), False, False)])
+def test_batch_norm_train(H, shape, relu, res):
+    from ess_amd import functional as Fn
+    g = torch.Generator().manual_seed(6)
+    C = shape[1]
+    x = (torch.randn(shape, generator=g) * 1.5 - 0.2).requires_grad_(True)
+    r = torch.randn(shape, generator=g, requires_grad=True) if res else None
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_d, rv_d = rm.clone().cuda(), rv.clone().cuda()
+    y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = torch.relu(y)
+    gy = torch.randn(shape, generator=g)
+    ins = [x, gamma, beta] + ([r] if res else [])
+    refs = torch.autograd.grad(y, ins, gy)
+    xd, gd, bd = [t.detach().cuda().requires_grad_(True) for t in (x, gamma, beta)]
+    rd = r.detach().cuda().requires_grad_(True) if res else None
+    yd = Fn.batch_norm_train(xd, gd, bd, rm_d, rv_d, rd, relu)
+    assert relerr(yd, y) < 1e-5
+    assert relerr(rm_d, rm) < 1e-5 and relerr(rv_d, rv) < 1e-5
+    outs = torch.autograd.grad(yd, [xd, gd, bd] + ([rd] if res else []), gy.cuda())
+    for o, rr in zip(outs, refs):
+        assert relerr(o, rr) < 5e-5
+
+
+def test_glue(H):
+    g = torch.Generator().manual_seed(8)
+    a, b = torch.randn(2, 5, 6, 10, generator=g), torch.randn(2, 5, 6, 10, generator=g)
+    ref = F.interpolate(a + b, scale_factor=2, mode='bilinear', align_corners=False)
+    assert relerr(H.upsample_bilinear2x_add(dev(a), dev(b)), ref) < 1e-6
+    assert relerr(H.upsample_bilinear2x_add(dev(a)), F.interpolate(a, scale_factor=2, mode='bilinear',
+                                                                   align_corners=False)) < 1e-6
+    x = torch.randn(2, 3, 8, 12, generator=g)
+    assert relerr(H.sumpool2x2(dev(x)), F.avg_pool2d(x, 2) * 4) < 1e-6
+    assert torch.equal(H.add(dev(a), dev(b)).cpu(), a + b)
+    for ev in (torch.randn(2, 2, 24, 40, generator=g) * (torch.rand(2, 2, 24, 40, generator=g) < 0.1).float(),
+               torch.zeros(1, 5, 4, 6), torch.randn(1, 3, 5, 7, generator=g)):
+        assert relerr(H.event_normalize(dev(ev)), O.event_normalize(ev.clone())) < 1e-5 or ev.abs().max() == 0
+        if ev.abs().max() == 0:
+            assert torch.equal(H.event_normalize(dev(ev)).cpu(), ev)
+
+
+def test_losses_against_golden_and_oracle(H, golden):
+    from ess_amd import functional as Fn
+    for gd in golden('losses'):
+        a = gd['a'].cuda().requires_grad_(True)
+        lt = Fn.task_loss(a, gd['lab'].cuda())
+        assert abs(lt.item() - gd['task'].item()) < 5e-6
+        ga, = torch.autograd.grad(lt, a)
+        assert relerr(ga, gd['task_grad']) < 5e-5
+        a2 = gd['a'].cuda().requires_grad_(True)
+        js = Fn.sym_js_div(a2, gd['b'].cuda())
+        assert abs(js.item() - gd['js'].item()) < 2e-6
+        gj, = torch.autograd.grad(js, a2)
+        assert relerr(gj, gd['js_grad_a']) < 5e-5
+        a3 = gd['a'].cuda().requires_grad_(True)
+        l1 = Fn.l1_loss(a3, gd['b'].cuda())
+        assert abs(l1.item() - (gd['a'] - gd['b']).abs().mean().item()) < 1e-6
+        g1, = torch.autograd.grad(l1 * 3.0, a3)
+        assert relerr(g1, 3.0 * torch.sign(gd['a'] - gd['b']) / gd['a'].numel()) < 1e-6
+    # dice only / ce only switches
+    gd = golden('losses')[0]
+    l, _ = H.task_loss(gd['a'].cuda(), gd['lab'].cuda(), False, use_ce=False)
+    assert abs(l.item() - gd['dice'].item()) < 5e-6
+
+
+def test_radam_flat(H, golden):
+    g = golden('radam')
+    flat = torch.cat([p.flatten() for p in g['p0']]).cuda()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    for step, gs in enumerate(g['grads'], 1):
+        n_sma, ss = O.radam_step_size(step, 0.0, 0.999)
+        H.radam_step(flat, torch.cat([x.flatten() for x in gs]).cuda(), m, v, g['lr'], 0.0, 0.999, 1e-8, ss, n_sma >= 5)
+        ref = torch.cat([p.flatten() for p in g['traj'][step - 1]])
+        assert (flat.cpu() - ref).abs().max().item() < 2e-7, step
+
+
+def test_argmax_confusion(H, golden):
+    g = golden('metrics')
+    K = g['K']
+    gen = torch.Generator().manual_seed(1)
+    logits = torch.randn(2, K, 10, 14, generator=gen)
+    logits.scatter_(1, g['pred'].unsqueeze(1), 10.0)
+    conf = torch.zeros(K, K, dtype=torch.int64).cuda()
+    pred = H.argmax_confusion(logits.cuda(), g['lab'].cuda(), conf)
+    assert torch.equal(pred.cpu(), g['pred'])
+    H.argmax_confusion(logits.flip(0).cuda(), g['lab'].cuda(), conf)
+    assert torch.equal(conf.cpu(), g['cm'])
+    miou, _, acc = O.miou_acc(conf.cpu())
+    assert miou.item() == g['miou'].item()
