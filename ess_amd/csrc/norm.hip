@@ -39,17 +39,22 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float t = (v[j] - mean) * rstd;
-        if (relu) t = fmaxf(t, 0.f);
+        if (relu == 1) t = fmaxf(t, 0.f);
         v[j] = t;
       }
       if (rp) { const f32x4 r = *(const f32x4*)(rp + i); v += r; }
+      if (relu == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
       *(f32x4*)(yp + i) = v;
     }
   } else {
     for (int i = threadIdx.x; i < hw; i += NT) {
       float t = (xp[i] - mean) * rstd;
-      if (relu) t = fmaxf(t, 0.f);
+      if (relu == 1) t = fmaxf(t, 0.f);
       if (rp) t += rp[i];
+      if (relu == 2) t = fmaxf(t, 0.f);
       yp[i] = t;
     }
   }
@@ -171,6 +176,7 @@ extern "C" int ess_instnorm_forward(const float* x, const float* residual, float
 extern "C" int ess_instnorm_backward(const float* x, const float* dy, const float* stats, float* dx, int32_t planes, int32_t hw,
                                      int32_t relu, ess_stream_t stream) {
   ESS_CHECK_ARG(x && dy && stats && dx && planes > 0 && hw > 0, "instnorm_backward: bad arguments");
+  ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_backward: relu-after-residual (2) is forward only");
   hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, dy, stats, dx, hw, relu);
   return ess_launch_status("instnorm_backward");
 }

@@ -108,9 +108,12 @@ extern "C" int ess_add(const float* a, const float* b, float* y, int64_t n, ess_
 extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && workspace && n > 0, "event_normalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, 32, st) != hipSuccess) {
-    ess_set_error("event_normalize: memset failed");
-    return ESS_ELAUNCH;
+  {
+    hipError_t e = hipMemsetAsync(workspace, 0, 32, st);
+    if (e != hipSuccess) {
+      ess_set_error("event_normalize: memset failed: %s", hipGetErrorString(e));
+      return ESS_ELAUNCH;
+    }
   }
   hipLaunchKernelGGL(evnorm_reduce_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, n, (double*)workspace);
   hipLaunchKernelGGL(evnorm_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, (const double*)workspace);

@@ -1,0 +1,313 @@
+"""
+MI355X counterparts of the E2VID building blocks (reference: e2vid/model/submodules.py).
+
+Same class names, constructor signatures and state_dict key layout as the reference, so checkpoints
+(`unetrecurrent.encoders.0.conv.conv2d.weight`, ...) load unchanged.  The nn.Conv2d / nn.BatchNorm2d
+children are parameter containers only: every forward is a fused libess_hip.so launch
+(conv + eval-norm + activation, or conv + LSTM/GRU gate maths).  The encoder is frozen and runs
+under no_grad in ESS (training/ess_trainer.py:52-54,277-280), so these modules are inference-only:
+asking autograd to differentiate through them raises.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from ... import hip
+from ...functional import packed_weight
+
+_ACT = {None: hip.ACT_NONE, 'relu': hip.ACT_RELU, 'sigmoid': hip.ACT_SIGMOID, 'tanh': hip.ACT_TANH}
+EPS = 1e-5
+
+
+def _inference_only(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError('the E2VID encoder kernels are forward-only (the encoder is frozen and runs under '
+                                  'torch.no_grad() in ESS: training/ess_trainer.py:52-54,277-280)')
+
+
+class _Fold:
+    """Per-output-channel (scale, shift) of an eval-mode norm folded behind a conv, packed for the kernel
+    and cached until one of the source tensors changes."""
+
+    def __init__(self):
+        self._ver = None
+        self._val = (None, None)
+
+    def get(self, spec, bias, norm_kind, norm_layer):
+        src = [bias]
+        if norm_kind in ('BN', 'IN'):
+            src += [norm_layer.running_mean, norm_layer.running_var]
+        if norm_kind == 'BN':
+            src += [norm_layer.weight, norm_layer.bias]
+        ver = (spec.key,) + tuple((id(t), t._version, t.data_ptr()) for t in src if t is not None)
+        if ver != self._ver:
+            with torch.no_grad():
+                scale = shift = None
+                if norm_kind == 'BN':  # y = (x - rm) / sqrt(rv + eps) * g + b
+                    scale = norm_layer.weight / torch.sqrt(norm_layer.running_var + EPS)
+                    shift = norm_layer.bias - norm_layer.running_mean * scale
+                elif norm_kind == 'IN':  # InstanceNorm2d(track_running_stats=True).eval(): running stats, no affine
+                    scale = 1.0 / torch.sqrt(norm_layer.running_var + EPS)
+                    shift = -norm_layer.running_mean * scale
+                if bias is not None:
+                    shift = bias * scale + shift if scale is not None else bias
+                ps = hip.pack_rows(spec, scale.contiguous(), fill=1.0) if scale is not None else None
+                pb = hip.pack_rows(spec, shift.contiguous()) if shift is not None else None
+            self._ver, self._val = ver, (ps, pb)
+        return self._val
+
+
+def _norm_container(norm, ch):
+    if norm == 'BN':
+        return nn.BatchNorm2d(ch)
+    if norm == 'IN':
+        return nn.InstanceNorm2d(ch, track_running_stats=True)
+    return None
+
+
+def _check_eval(mod, norm):
+    if mod.training and norm in ('BN', 'IN'):
+        raise NotImplementedError('E2VID norm layers only exist in eval mode here (front_sensor_b.eval(), '
+                                  'training/ess_trainer.py:54); call .eval() on the encoder')
+
+
+class ConvLayer(nn.Module):
+    """conv2d (+BN/IN eval) (+activation) in one kernel.  Reference: submodules.py:7-31."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=(norm != 'BN'))
+        self.activation = activation
+        self.norm = norm
+        nl = _norm_container(norm, out_channels)
+        if nl is not None:
+            self.norm_layer = nl
+        self._fold = _Fold()
+
+    def forward(self, x, x1=None, residual=None):
+        """x1: optional second source, channel-concatenated on the fly."""
+        _inference_only(x, x1)
+        _check_eval(self, self.norm)
+        c = self.conv2d
+        N, C0, H, W = x.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        spec = hip.conv_spec(N, H, W, C0, C1, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0],
+                             act=_ACT[self.activation])
+        scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
+        out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
+        return hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out)
+
+
+class TransposedConvLayer(nn.Module):
+    """ConvTranspose2d(k, stride 2, output_padding 1) (+norm) (+activation): the zero-insertion is done
+    while staging the LDS tile.  Reference: submodules.py:34-62."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=padding,
+                                                    output_padding=1, bias=(norm != 'BN'))
+        self.activation = activation
+        self.norm = norm
+        nl = _norm_container(norm, out_channels)
+        if nl is not None:
+            self.norm_layer = nl
+        self._fold = _Fold()
+
+    def forward(self, x):
+        _inference_only(x)
+        _check_eval(self, self.norm)
+        t = self.transposed_conv2d
+        N, C, H, W = x.shape
+        k, p = t.kernel_size[0], t.padding[0]
+        if k != 2 * p + 1:
+            raise hip.EssHipError('TransposedConvLayer: only k = 2p+1 geometries (output = 2x input) are supported')
+        spec = hip.conv_spec(N, 2 * H, 2 * W, C, 0, t.out_channels, k, 1, k - 1 - p, hip.SRC_ZERO_UP2,
+                             act=_ACT[self.activation])
+        scale, shift = self._fold.get(spec, t.bias, self.norm, getattr(self, 'norm_layer', None))
+        out = torch.empty(N, t.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
+        return hip.conv_forward(spec, x, None, packed_weight(spec, t.weight, kind=hip.W_TRANSPOSED), scale, shift, out=out)
+
+    def forward_sum(self, x, skip):
+        return self.forward(hip.add(x, skip))
+
+
+class UpsampleConvLayer(nn.Module):
+    """bilinear x2 (align_corners=False) -> conv (+norm) (+activation).  Reference: submodules.py:65-93."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=(norm != 'BN'))
+        self.activation = activation
+        self.norm = norm
+        nl = _norm_container(norm, out_channels)
+        if nl is not None:
+            self.norm_layer = nl
+        self._fold = _Fold()
+
+    def _conv(self, up0, up1=None):
+        c = self.conv2d
+        N, C0, H, W = up0.shape
+        C1 = 0 if up1 is None else up1.shape[1]
+        spec = hip.conv_spec(N, H, W, C0, C1, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0],
+                             act=_ACT[self.activation])
+        scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
+        out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=up0.device)
+        return hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=out)
+
+    def forward(self, x):
+        _inference_only(x)
+        _check_eval(self, self.norm)
+        return self._conv(hip.upsample_bilinear2x_add(x))
+
+    def forward_sum(self, x, skip):
+        """decoder(skip_sum(x, skip)) with the sum fused into the upsampling pass (unet.py:12-13,176)."""
+        _inference_only(x, skip)
+        _check_eval(self, self.norm)
+        return self._conv(hip.upsample_bilinear2x_add(x, skip))
+
+    def forward_cat(self, x, skip):
+        """decoder(skip_concat(x, skip)): bilinear commutes with the channel concat."""
+        _inference_only(x, skip)
+        _check_eval(self, self.norm)
+        return self._conv(hip.upsample_bilinear2x_add(x), hip.upsample_bilinear2x_add(skip))
+
+
+class ConvLSTM(nn.Module):
+    """Gates conv over cat(x, h) + sigmoid/tanh + cell/hidden update in ONE kernel; the concat and the
+    4*hidden gate tensor never exist in memory.  Reference: submodules.py:175-230."""
+
+    def __init__(self, input_size, hidden_size, kernel_size):
+        super().__init__()
+        if kernel_size != 3:
+            raise hip.EssHipError('ConvLSTM: the fused kernel is 3x3 (as used by RecurrentConvLayer)')
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.zero_tensors = {}
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=kernel_size // 2)
+        self._bias_ver, self._bias = None, None
+
+    def forward(self, input_, prev_state=None):
+        _inference_only(input_)
+        N, C, H, W = input_.shape
+        hid = self.hidden_size
+        if prev_state is None:
+            key = (N, hid, H, W, input_.device)
+            if key not in self.zero_tensors:
+                self.zero_tensors[key] = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
+            prev_hidden, prev_cell = self.zero_tensors[key], None  # a NULL cell pointer reads as zeros
+        else:
+            prev_hidden, prev_cell = prev_state
+        spec = hip.conv_spec(N, H, W, C, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
+        b = self.Gates.bias
+        ver = (spec.key, b._version, b.data_ptr())
+        if ver != self._bias_ver:
+            self._bias_ver, self._bias = ver, hip.pack_rows(spec, b.detach())
+        hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
+        cell = torch.empty_like(hidden)
+        hip.conv_forward(spec, input_, prev_hidden, packed_weight(spec, self.Gates.weight), None, self._bias,
+                         aux0=prev_cell, out=hidden, out2=cell)
+        return hidden, cell
+
+
+class ConvGRU(nn.Module):
+    """Two fused kernels: (update, reset) gates -> (u, r*h); candidate -> h'.  Reference: submodules.py:233-273."""
+
+    def __init__(self, input_size, hidden_size, kernel_size):
+        super().__init__()
+        if kernel_size != 3:
+            raise hip.EssHipError('ConvGRU: the fused kernels are 3x3 (as used by RecurrentConvLayer)')
+        padding = kernel_size // 2
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.reset_gate = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size, padding=padding)
+        self.update_gate = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size, padding=padding)
+        self.out_gate = nn.Conv2d(input_size + hidden_size, hidden_size, kernel_size, padding=padding)
+        for g in (self.reset_gate, self.update_gate, self.out_gate):
+            init.orthogonal_(g.weight)
+            init.constant_(g.bias, 0.)
+        self._ver, self._b1, self._b2 = None, None, None
+
+    def forward(self, input_, prev_state):
+        _inference_only(input_)
+        N, C, H, W = input_.shape
+        hid = self.hidden_size
+        if prev_state is None:
+            prev_state = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
+        s1 = hip.conv_spec(N, H, W, C, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
+        s2 = hip.conv_spec(N, H, W, C, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+        bu, br, bo = self.update_gate.bias, self.reset_gate.bias, self.out_gate.bias
+        ver = (s1.key, bu._version, br._version, bo._version, bu.data_ptr())
+        if ver != self._ver:
+            self._ver = ver
+            self._b1 = hip.pack_rows(s1, bu.detach(), br.detach())
+            self._b2 = hip.pack_rows(s2, bo.detach())
+        u = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
+        rh = torch.empty_like(u)
+        hip.conv_forward(s1, input_, prev_state, packed_weight(s1, self.update_gate.weight, self.reset_gate.weight), None,
+                         self._b1, aux0=prev_state, out=u, out2=rh)
+        new_state = torch.empty_like(u)
+        hip.conv_forward(s2, input_, rh, packed_weight(s2, self.out_gate.weight), None, self._b2, aux0=prev_state, aux1=u,
+                         out=new_state)
+        return new_state
+
+
+class RecurrentConvLayer(nn.Module):
+    """ConvLayer (k5, s2) followed by a ConvLSTM / ConvGRU.  Reference: submodules.py:96-115."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, recurrent_block_type='convlstm',
+                 activation='relu', norm=None):
+        super().__init__()
+        assert recurrent_block_type in ['convlstm', 'convgru']
+        self.recurrent_block_type = recurrent_block_type
+        block = ConvLSTM if recurrent_block_type == 'convlstm' else ConvGRU
+        self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, padding, activation, norm)
+        self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
+
+    def forward(self, x, prev_state):
+        x = self.conv(x)
+        state = self.recurrent_block(x, prev_state)
+        x = state[0] if self.recurrent_block_type == 'convlstm' else state
+        return x, state
+
+
+class ResidualBlock(nn.Module):
+    """conv3x3 -norm-ReLU- conv3x3 -norm- (+x) -ReLU as two fused kernels (BN/no norm), or with the
+    InstanceNorm plane kernel in between (norm='IN').  Reference: submodules.py:140-172."""
+
+    def __init__(self, in_channels, out_channels, stride=1, downsample=None, norm=None):
+        super().__init__()
+        if downsample is not None or stride != 1:
+            raise hip.EssHipError('ResidualBlock: E2VID only builds stride-1 blocks without downsample')
+        bias = norm != 'BN'
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=stride, padding=1, bias=bias)
+        self.norm = norm
+        if norm == 'BN':
+            self.bn1 = nn.BatchNorm2d(out_channels)
+            self.bn2 = nn.BatchNorm2d(out_channels)
+        elif norm == 'IN':
+            self.bn1 = nn.InstanceNorm2d(out_channels)
+            self.bn2 = nn.InstanceNorm2d(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.downsample = downsample
+        self._f1, self._f2 = _Fold(), _Fold()
+
+    def forward(self, x):
+        _inference_only(x)
+        N, C, H, W = x.shape
+        bn = self.norm == 'BN'
+        if bn and self.training:
+            raise NotImplementedError('E2VID BatchNorm only exists in eval mode here; call .eval() on the encoder')
+        fused = self.norm != 'IN'
+        s1 = hip.conv_spec(N, H, W, C, 0, self.conv1.out_channels, 3, 1, 1, act=hip.ACT_RELU if fused else hip.ACT_NONE)
+        s2 = hip.conv_spec(N, H, W, self.conv1.out_channels, 0, self.conv2.out_channels, 3, 1, 1,
+                           act=hip.ACT_RELU if fused else hip.ACT_NONE)
+        sc1, sh1 = self._f1.get(s1, self.conv1.bias, 'BN' if bn else None, getattr(self, 'bn1', None))
+        sc2, sh2 = self._f2.get(s2, self.conv2.bias, 'BN' if bn else None, getattr(self, 'bn2', None))
+        o = torch.empty(N, self.conv1.out_channels, H, W, dtype=torch.float32, device=x.device)
+        hip.conv_forward(s1, x, None, packed_weight(s1, self.conv1.weight), sc1, sh1, out=o)
+        if not fused:
+            o, _ = hip.instnorm_forward(o, None, 1, EPS)
+        out = torch.empty(N, self.conv2.out_channels, H, W, dtype=torch.float32, device=x.device)
+        hip.conv_forward(s2, o, None, packed_weight(s2, self.conv2.weight), sc2, sh2, x if fused else None, out=out)
+        if not fused:
+            out, _ = hip.instnorm_forward(out, x, 2, EPS)
+        return out

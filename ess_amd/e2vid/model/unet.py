@@ -1,0 +1,150 @@
+"""
+Recurrent UNet of E2VID on the HIP kernels (reference: e2vid/model/unet.py).
+
+Only the architectures that sit on the ESS path are built: UNetRecurrent (the frozen event encoder),
+UNet (its non-recurrent sibling, selectable through the checkpoint's `arch`) and UNetDecoder (always
+instantiated by load_model).  Channel plan and module names follow BaseUNet (unet.py:16-67) so the
+state_dict layout is identical.
+"""
+import torch
+import torch.nn as nn
+
+from ... import hip
+from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, TransposedConvLayer, UpsampleConvLayer
+
+_ACT = {'sigmoid': hip.ACT_SIGMOID, 'tanh': hip.ACT_TANH, 'relu': hip.ACT_RELU}
+
+
+class BaseUNet(nn.Module):
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', activation='sigmoid', num_encoders=4,
+                 base_num_channels=32, num_residual_blocks=2, norm=None, use_upsample_conv=True):
+        super().__init__()
+        assert num_input_channels > 0 and num_output_channels > 0
+        self.num_input_channels = num_input_channels
+        self.num_output_channels = num_output_channels
+        self.skip_type = skip_type
+        self.activation = activation
+        self.norm = norm
+        self.UpsampleLayer = UpsampleConvLayer if use_upsample_conv else TransposedConvLayer
+        self.num_encoders = num_encoders
+        self.base_num_channels = base_num_channels
+        self.num_residual_blocks = num_residual_blocks
+        self.max_num_channels = base_num_channels * 2 ** num_encoders
+        self.encoder_input_sizes = [base_num_channels * 2 ** i for i in range(num_encoders)]
+        self.encoder_output_sizes = [base_num_channels * 2 ** (i + 1) for i in range(num_encoders)]
+
+    def build_resblocks(self):
+        self.resblocks = nn.ModuleList(ResidualBlock(self.max_num_channels, self.max_num_channels, norm=self.norm)
+                                       for _ in range(self.num_residual_blocks))
+
+    def build_decoders(self):
+        mul = 1 if self.skip_type == 'sum' else 2
+        self.decoders = nn.ModuleList(self.UpsampleLayer(mul * c, c // 2, kernel_size=5, padding=2, norm=self.norm)
+                                      for c in reversed(self.encoder_output_sizes))
+
+    def build_prediction_layer(self):
+        mul = 1 if self.skip_type == 'sum' else 2
+        self.pred = ConvLayer(mul * self.base_num_channels, self.num_output_channels, 1, activation=None, norm=self.norm)
+
+    # ---- shared tail: residual blocks -> decoders (with skips) -> prediction + output activation
+    def _skip_decode(self, decoder, x, skip):
+        if self.skip_type == 'sum':
+            return decoder.forward_sum(x, skip)
+        if hasattr(decoder, 'forward_cat'):
+            return decoder.forward_cat(x, skip)
+        return decoder(torch.cat([x, skip], dim=1))
+
+    def _tail(self, x, blocks, head):
+        for resblock in self.resblocks:
+            x = resblock(x)
+        for i, decoder in enumerate(self.decoders):
+            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1])
+        # pred(skip(x, head)) + output activation fused into the 1x1 conv epilogue
+        saved = self.pred.activation
+        self.pred.activation = self.activation
+        try:
+            if self.skip_type == 'sum':
+                img = self.pred(hip.add(x, head))
+            else:
+                img = self.pred(x, x1=head)
+        finally:
+            self.pred.activation = saved
+        return img
+
+
+class UNet(BaseUNet):
+    """Non-recurrent variant (reference unet.py:70-114)."""
+
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', activation='sigmoid', num_encoders=4,
+                 base_num_channels=32, num_residual_blocks=2, norm=None, use_upsample_conv=True):
+        super().__init__(num_input_channels, num_output_channels, skip_type, activation, num_encoders, base_num_channels,
+                         num_residual_blocks, norm, use_upsample_conv)
+        self.head = ConvLayer(num_input_channels, base_num_channels, kernel_size=5, stride=1, padding=2)
+        self.encoders = nn.ModuleList(ConvLayer(i, o, kernel_size=5, stride=2, padding=2, norm=norm)
+                                      for i, o in zip(self.encoder_input_sizes, self.encoder_output_sizes))
+        self.build_resblocks()
+        self.build_decoders()
+        self.build_prediction_layer()
+
+    def forward(self, x):
+        x = self.head(x)
+        head = x
+        blocks = []
+        for encoder in self.encoders:
+            x = encoder(x)
+            blocks.append(x)
+        return self._tail(x, blocks, head)
+
+
+class UNetRecurrent(BaseUNet):
+    """head -> 3x(conv5x5/s2 + ConvLSTM|ConvGRU) -> resblocks -> decoders -> pred (reference unet.py:117-181).
+
+    forward(x, prev_states, encoder_only=False): with encoder_only=True the residual blocks, decoders
+    and prediction layer are skipped and img is None -- their outputs do not feed the recurrent state,
+    so the trainers use it for every time step but the last (result-identical, 42 % fewer MACs)."""
+
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
+                 activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
+                 use_upsample_conv=True):
+        super().__init__(num_input_channels, num_output_channels, skip_type, activation, num_encoders, base_num_channels,
+                         num_residual_blocks, norm, use_upsample_conv)
+        self.head = ConvLayer(num_input_channels, base_num_channels, kernel_size=5, stride=1, padding=2)
+        self.encoders = nn.ModuleList(
+            RecurrentConvLayer(i, o, kernel_size=5, stride=2, padding=2, recurrent_block_type=recurrent_block_type, norm=norm)
+            for i, o in zip(self.encoder_input_sizes, self.encoder_output_sizes))
+        self.build_resblocks()
+        self.build_decoders()
+        self.build_prediction_layer()
+
+    def forward(self, x, prev_states, encoder_only=False):
+        x = self.head(x)
+        head = x
+        if prev_states is None:
+            prev_states = [None] * self.num_encoders
+        blocks, states = [], []
+        for i, encoder in enumerate(self.encoders):
+            x, state = encoder(x, prev_states[i])
+            blocks.append(x)
+            states.append(state)
+        latent = {1: head}
+        for i, b in enumerate(blocks):
+            latent[2 ** (i + 1)] = b
+        if encoder_only:
+            return None, states, latent
+        return self._tail(x, blocks, head), states, latent
+
+
+class UNetDecoder(BaseUNet):
+    """resblocks + decoders + pred of an E2VID checkpoint as a standalone module (reference unet.py:183-219)."""
+
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
+                 activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
+                 use_upsample_conv=True):
+        super().__init__(num_input_channels, num_output_channels, skip_type, activation, num_encoders, base_num_channels,
+                         num_residual_blocks, norm, use_upsample_conv)
+        self.build_resblocks()
+        self.build_decoders()
+        self.build_prediction_layer()
+
+    def forward(self, x, blocks, head):
+        return self._tail(x, blocks, head)

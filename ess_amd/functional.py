@@ -26,6 +26,13 @@ def packed_weight(spec, w, w2=None, kind=hip.W_CONV):
     return pw
 
 
+def invalidate_packed(params):
+    """Drop cached re-layouts of tensors that a kernel modified through a raw pointer (the flat RAdam update does
+    not bump ``_version``)."""
+    for p in params:
+        _pack_cache.pop(id(p), None)
+
+
 def _virt(x, mode):
     m = 2 if mode != hip.SRC_DIRECT else 1
     return x.shape[2] * m, x.shape[3] * m

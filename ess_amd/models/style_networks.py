@@ -1,0 +1,263 @@
+"""
+Task decoder and image encoder of ESS on the HIP kernels (reference: models/style_networks.py).
+
+SemSegE2VID / StyleEncoderE2VID / ReLUINSConv2d / INSResBlock keep the reference's constructor signatures,
+forward contracts (dicts keyed by scale) and state_dict key layout.  The nn.Conv2d / nn.BatchNorm2d
+children only hold parameters; forward/backward run through ess_amd.functional (fused concat +
+nearest-upsample inside the conv tile loader, InstanceNorm/BatchNorm plane kernels, MFMA dgrad/wgrad).
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import hip
+from .submodules import InterpolationLayer
+
+
+def gaussian_weights_init(m):
+    """N(0, 0.02) on every module whose class name starts with 'Conv' (reference :152-155)."""
+    if m.__class__.__name__.find('Conv') == 0:
+        m.weight.data.normal_(0.0, 0.02)
+
+
+class ReLUINSConv2d(nn.Module):
+    """Conv(bias) -> InstanceNorm2d(affine=False) -> ReLU (reference :158-169)."""
+
+    def __init__(self, n_in, n_out, kernel_size, stride, padding=0):
+        super().__init__()
+        self.model = nn.Sequential(nn.Conv2d(n_in, n_out, kernel_size=kernel_size, stride=stride, padding=padding, bias=True),
+                                   nn.InstanceNorm2d(n_out, affine=False), nn.ReLU(inplace=True))
+        self.model.apply(gaussian_weights_init)
+
+    def forward_fused(self, x, skip=None, up=False):
+        """conv over cat(nearest_up2(x) if up else x, skip) without materialising either."""
+        c = self.model[0]
+        y = Fn.conv2d(x, c.weight, c.bias, c.stride[0], c.padding[0], x1=skip,
+                      mode0=hip.SRC_NEAREST_UP2 if up else hip.SRC_DIRECT)
+        return Fn.instance_norm(y, None, True, self.model[1].eps)
+
+    def forward(self, x):
+        return self.forward_fused(x)
+
+
+class INSResBlock(nn.Module):
+    """conv3x3 -> IN -> ReLU -> conv3x3 -> IN, plus the identity (reference :172-193)."""
+
+    def conv3x3(self, inplanes, out_planes, stride=1):
+        return [nn.Conv2d(inplanes, out_planes, kernel_size=3, stride=stride, padding=1)]
+
+    def __init__(self, inplanes, planes, stride=1, dropout=0.0):
+        super().__init__()
+        if dropout > 0:
+            raise NotImplementedError('INSResBlock dropout is never enabled by SemSegE2VID')
+        layers = self.conv3x3(inplanes, planes, stride) + [nn.InstanceNorm2d(planes), nn.ReLU(inplace=True)]
+        layers += self.conv3x3(planes, planes) + [nn.InstanceNorm2d(planes)]
+        self.model = nn.Sequential(*layers)
+        self.model.apply(gaussian_weights_init)
+
+    def forward(self, x):
+        c1, c2 = self.model[0], self.model[3]
+        y = Fn.conv2d(x, c1.weight, c1.bias, c1.stride[0], 1)
+        y = Fn.instance_norm(y, None, True, self.model[1].eps)
+        y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1)
+        return Fn.instance_norm(y, x, False, self.model[4].eps)  # IN(.) + residual in one pass
+
+
+class SemSegE2VID(nn.Module):
+    """Shared segmentation decoder (reference :9-107).  forward({1,2,4,8}) -> {8,4,2,1}."""
+
+    def __init__(self, input_c, output_c, skip_connect=False, skip_type='sum', input_index_map=False):
+        super().__init__()
+        if input_index_map:
+            raise NotImplementedError('input_index_map is never enabled by the ESS trainers')
+        if skip_connect and skip_type != 'concat':
+            raise ValueError("skip_connect=True only works with skip_type='concat' (decoder_scale_2 is built for "
+                             "2x channels, reference :25)")
+        self.skip_connect, self.skip_type, self.input_index_map = skip_connect, skip_type, input_index_map
+        self.index_coords = None
+        tch = input_c
+        if skip_connect:
+            blocks = [INSResBlock(tch, tch) for _ in range(5)]
+            blocks += [ReLUINSConv2d(tch, tch // 2, kernel_size=3, stride=1, padding=1)]
+            self.decoder_scale_1 = nn.Sequential(*blocks)
+            self.decoder_scale_2 = nn.Sequential(ReLUINSConv2d(tch, tch // 2, kernel_size=3, stride=1, padding=1),
+                                                 ReLUINSConv2d(tch // 2, tch // 4, kernel_size=3, stride=1, padding=1))
+            tch //= 2
+            self.decoder_scale_3 = nn.Sequential(ReLUINSConv2d(tch, tch // 2, kernel_size=3, stride=1, padding=1),
+                                                 ReLUINSConv2d(tch // 2, tch // 2, kernel_size=3, stride=1, padding=1))
+            tch //= 2
+            self.decoder_scale_4 = nn.Sequential(ReLUINSConv2d(tch, tch // 2, kernel_size=3, stride=1, padding=1))
+            tch //= 2
+        else:
+            self.decoder_scale_1 = nn.Sequential(*[INSResBlock(tch, tch) for _ in range(3)])
+            for name in ('decoder_scale_2', 'decoder_scale_3', 'decoder_scale_4'):
+                setattr(self, name, nn.Sequential(InterpolationLayer(scale_factor=2, mode='nearest'),
+                                                  ReLUINSConv2d(tch, tch // 2, kernel_size=3, stride=1, padding=1)))
+                tch //= 2
+        self.decoder_scale_5 = nn.Sequential(nn.Conv2d(tch, output_c, kernel_size=1, stride=1, padding=0))
+
+    def update_skip_dict(self, skips, x, sz_in):
+        rem, scale = sz_in % x.shape[3], sz_in // x.shape[3]
+        assert rem == 0
+        skips[scale] = x
+
+    def forward(self, input_dict):
+        sz_in = input_dict[1].shape[3]
+        x = input_dict[8]
+        out = {8: x}
+        x = x.contiguous()
+        if self.skip_connect:
+            x = self.decoder_scale_1(x)
+            x = self.decoder_scale_2[0].forward_fused(x, input_dict[4].contiguous(), up=True)
+            x = self.decoder_scale_2[1](x)
+            self.update_skip_dict(out, x, sz_in)
+            x = self.decoder_scale_3[0].forward_fused(x, input_dict[2].contiguous(), up=True)
+            x = self.decoder_scale_3[1](x)
+            self.update_skip_dict(out, x, sz_in)
+            x = self.decoder_scale_4[0].forward_fused(x, None, up=True)
+        else:
+            x = self.decoder_scale_1(x)
+            x = self.decoder_scale_2[1].forward_fused(x, None, up=True)
+            self.update_skip_dict(out, x, sz_in)
+            x = self.decoder_scale_3[1].forward_fused(x, None, up=True)
+            self.update_skip_dict(out, x, sz_in)
+            x = self.decoder_scale_4[1].forward_fused(x, None, up=True)
+        c5 = self.decoder_scale_5[0]
+        x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0)
+        self.update_skip_dict(out, x, sz_in)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class _ConvBN(nn.Module):
+    """Bias-free conv + BatchNorm2d (+residual) (+ReLU): train mode = conv kernel + BN plane kernel with batch
+    statistics; eval mode = one fused conv kernel with the running statistics folded into its epilogue."""
+
+    @staticmethod
+    def run(conv, bn, x, residual=None, relu=True):
+        if bn.training:
+            y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0])
+            out = Fn.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu,
+                                      bn.momentum, bn.eps)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            return out
+        if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+            raise NotImplementedError('eval-mode BatchNorm is forward-only here (validation runs under no_grad, '
+                                      'training/base_trainer.py:419)')
+        N, C, H, W = x.shape
+        spec = hip.conv_spec(N, H, W, C, 0, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0],
+                             act=hip.ACT_RELU if relu else hip.ACT_NONE)
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+        out = torch.empty(N, conv.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
+        return hip.conv_forward(spec, x.contiguous(), None, Fn.packed_weight(spec, conv.weight),
+                                hip.pack_rows(spec, scale.contiguous(), fill=1.0), hip.pack_rows(spec, shift.contiguous()),
+                                residual, out=out)
+
+
+class BasicBlock(nn.Module):
+    """torchvision (0.7.0) ResNet BasicBlock: conv3x3(s)-BN-ReLU-conv3x3-BN + identity / 1x1(s)-BN downsample, ReLU.
+    torchvision is not vendored by the reference (models/style_networks.py:3,117-121 import it); restated here."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        if self.downsample is not None:
+            identity = _ConvBN.run(self.downsample[0], self.downsample[1], x, None, relu=False)
+        out = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True)
+        return _ConvBN.run(self.conv2, self.bn2, out, identity, relu=True)
+
+
+def _resnet_init(module):
+    """torchvision's ResNet initialisation (kaiming_normal fan_out for convs, BN weight 1 / bias 0)."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class _Stem(nn.Sequential):
+    """conv7x7/s2 (1->64, no bias), bn1, relu, layer1 -- indices 0,1,2,3 as in the reference's Sequential."""
+
+    def forward(self, x):
+        x = _ConvBN.run(self[0], self[1], x, None, relu=True)
+        return self[3](x)
+
+
+class StyleEncoderE2VID(nn.Module):
+    """Image encoder = conv7x7/s2 + ResNet-18 {bn1, relu, layer1, layer2, layer3}, no maxpool (reference :110-145).
+    The reference takes those layers from torchvision.models.resnet18(pretrained=True); ImageNet weights are not
+    available offline, so the layers start from torchvision's default initialisation and `pretrained_state_dict`
+    (a torchvision resnet18 state_dict) can be passed to reproduce the reference's starting point."""
+
+    def __init__(self, input_dim, skip_connect=False, pretrained_state_dict=None):
+        super().__init__()
+        self.skip_connect = skip_connect
+        layer1 = nn.Sequential(BasicBlock(64, 64), BasicBlock(64, 64))
+        self.encoder_scale_1 = _Stem(nn.Conv2d(input_dim, 64, kernel_size=(7, 7), stride=(2, 2), padding=(3, 3), bias=False),
+                                     nn.BatchNorm2d(64), nn.ReLU(inplace=True), layer1)
+        self.encoder_scale_2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128))
+        self.encoder_scale_3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256))
+        _resnet_init(self)
+        if pretrained_state_dict is not None:
+            self.load_resnet18(pretrained_state_dict)
+
+    def load_resnet18(self, sd):
+        """Copy bn1/layer1/layer2/layer3 of a torchvision resnet18 state_dict (the conv7x7 stays freshly initialised,
+        exactly as in the reference where it is a new nn.Conv2d)."""
+        remap = {}
+        for k, v in sd.items():
+            if k.startswith('bn1.'):
+                remap['encoder_scale_1.1.' + k[4:]] = v
+            elif k.startswith('layer1.'):
+                remap['encoder_scale_1.3.' + k[7:]] = v
+            elif k.startswith('layer2.'):
+                remap['encoder_scale_2.' + k[7:]] = v
+            elif k.startswith('layer3.'):
+                remap['encoder_scale_3.' + k[7:]] = v
+        missing = [k for k in self.state_dict() if k not in remap and k != 'encoder_scale_1.0.weight']
+        if missing:
+            raise KeyError(f'resnet18 state_dict lacks {missing[:4]}...')
+        self.load_state_dict(remap, strict=False)
+
+    def update_skip_dict(self, skips, x, sz_in):
+        rem, scale = sz_in % x.shape[3], sz_in // x.shape[3]
+        assert rem == 0
+        skips[scale] = x
+
+    def forward(self, x):
+        out = {1: x}
+        sz_in = x.shape[3]
+        x = self.encoder_scale_1(x.contiguous())
+        if self.skip_connect:
+            self.update_skip_dict(out, x, sz_in)
+        x = self.encoder_scale_2(x)
+        if self.skip_connect:
+            self.update_skip_dict(out, x, sz_in)
+        x = self.encoder_scale_3(x)
+        self.update_skip_dict(out, x, sz_in)
+        return out
+
+
+def skip_concat(x1, x2):
+    return torch.cat([x1, x2], dim=1)
+
+
+def skip_sum(x1, x2):
+    return hip.add(x1, x2)

@@ -1,0 +1,139 @@
+"""
+Trainer base: construction order, epoch loop, validation cadence, checkpoint cadence, LR schedule
+(reference: training/base_trainer.py:21-66,361-453).  Dataset factories and visualisation helpers of the
+reference (:72-359,455-609) are out of scope; loaders come from `createDataLoaders`,
+which provides the seeded synthetic loaders when `settings.synthetic` is set and otherwise expects a subclass
+/ caller to assign `train_loader` / `val_loader_sensor_b`.
+"""
+import torch
+
+from ..utils.saver import CheckpointSaver
+from . import distributed as D
+from .synthetic import SyntheticPairedLoader
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass
+
+
+def _summary_writer(log_dir):
+    try:
+        from tensorboardX import SummaryWriter  # optional, as in the reference (base_trainer.py:34)
+        return SummaryWriter(log_dir)
+    except Exception:
+        return _NullWriter()
+
+
+class BaseTrainer(object):
+    def __init__(self, settings):
+        self.settings = settings
+        if not torch.cuda.is_available():
+            raise RuntimeError('ess_amd trainers need an MI355X (HIP device); there is no CPU path')
+        self.device = settings.gpu_device if isinstance(getattr(settings, 'gpu_device', None), torch.device) \
+            else torch.device('cuda')
+        torch.cuda.set_device(self.device)
+        self.do_val_training_epoch = True
+        self.grad_reducer = D.GradAllReducer()
+
+        self.init_fn()  # models are built ON the device, then the optimisers flatten their parameters
+        self.createDataLoaders()
+        self.summary_writer = _summary_writer(getattr(settings, 'ckpt_dir', None)) if D.rank() == 0 else _NullWriter()
+
+        load_optimizer = False  # the reference never restores optimiser state (base_trainer.py:37-40)
+        self.saver = CheckpointSaver(save_dir=getattr(settings, 'ckpt_dir', None))
+        if getattr(settings, 'resume_training', False):
+            self.checkpoint = self.saver.load_checkpoint(self.models_dict, self.optimizers_dict,
+                                                         checkpoint_file=settings.resume_ckpt_file,
+                                                         load_optimizer=load_optimizer)
+            self.epoch_count = self.checkpoint['epoch']
+            self.step_count = self.checkpoint['step_count']
+        else:
+            if getattr(settings, 'load_pretrained_weights', False):
+                self.saver.load_pretrained_weights(self.models_dict, self.models_dict.keys(), settings.pretrained_file)
+            self.epoch_count, self.step_count, self.checkpoint = 0, 0, None
+        for m in self.models_dict.values():
+            D.broadcast_module(m)
+        self.epoch = self.epoch_count
+        self.lr_schedulers = {k: torch.optim.lr_scheduler.ExponentialLR(v, gamma=settings.lr_decay)
+                              for k, v in self.optimizers_dict.items()}
+        self.train_statistics = {}
+
+    def init_fn(self):
+        """Model + optimisers are constructed in the child class."""
+
+    # ------------------------------------------------------------------ data
+    def createDataLoaders(self):
+        s = self.settings
+        if not getattr(s, 'synthetic', False):
+            raise NotImplementedError('real-dataset loaders (datasets/*, DSEC/*) are outside the hot path; set '
+                                      '`synthetic.enabled: true` in the yaml or assign train_loader yourself')
+        cfg = s.synthetic_cfg
+        H, W = self.input_height, self.input_width
+        rank = D.rank()
+        mk = lambda steps, seed, ev_only: SyntheticPairedLoader(
+            steps, s.batch_size_a, s.batch_size_b, s.nr_events_data_b, s.input_channels_b, H, W, s.semseg_num_classes,
+            self.device, seed=seed + 100003 * rank, events_only=ev_only)
+        ev_only = s.model_name == 'ess_supervised'
+        self.train_loader = mk(int(cfg.get('steps_per_epoch', 8)), 0, ev_only)
+        self.train_loader_sensor_b = self.train_loader
+        self.val_loader_sensor_b = mk(int(cfg.get('val_steps', 2)), 7919, True)
+
+    # ------------------------------------------------------------------ loops (reference :361-453)
+    def train(self):
+        s = self.settings
+        for _ in range(self.epoch_count, s.num_epochs):
+            if (self.epoch_count % s.val_epoch_step) == 0:
+                self.validationEpochs()
+            self.trainEpoch()
+            if s.save_checkpoint and self.epoch_count % s.val_epoch_step == 0 and D.rank() == 0:
+                self.saver.save_checkpoint(self.models_dict, self.optimizers_dict, self.epoch_count, self.step_count,
+                                           s.batch_size_a, s.batch_size_b)
+            for opt in self.optimizers_dict:
+                self.lr_schedulers[opt].step()
+            self.epoch_count += 1
+        self.validationEpochs()
+        if s.save_checkpoint and D.rank() == 0:
+            self.saver.save_checkpoint(self.models_dict, self.optimizers_dict, self.epoch_count, self.step_count,
+                                       s.batch_size_a, s.batch_size_b)
+
+    def trainEpoch(self):
+        self.train_loader.createIterators()
+        for model in self.models_dict:
+            self.models_dict[model].train()
+        last = None
+        for sample_batched in self.train_loader:
+            out = self.train_step(sample_batched)
+            self.train_summaries(out[0])
+            self.step_count += 1
+            last = out[-1]
+        if last is not None and D.rank() == 0:
+            print('epoch {} step {} TrainLoss {:.4f}'.format(self.epoch_count, self.step_count, float(last)))
+
+    def validationEpochs(self):
+        self.resetValidationStatistics()
+        with torch.no_grad():
+            for model in self.models_dict:
+                self.models_dict[model].eval()
+            self.validationEpoch(self.val_loader_sensor_b, 'sensor_b')
+        self.epoch_count_val = self.epoch_count
+
+    def resetValidationStatistics(self):
+        pass
+
+    def visualize_epoch(self):
+        return False  # tensorboard image dumps (reference :488-490 and the vis* helpers) are out of scope
+
+    def train_summaries(self, losses):
+        """Running means over 50 steps written as scalars (reference :525-541), without forcing a device sync
+        on the other 49 steps."""
+        for k, v in losses.items():
+            acc = self.train_statistics.setdefault(k, [])
+            acc.append(v.detach() if torch.is_tensor(v) else torch.tensor(float(v)))
+            if len(acc) >= 50:
+                self.summary_writer.add_scalar('train/' + k, torch.stack([a.float().cpu() for a in acc]).mean().item(),
+                                               self.step_count)
+                acc.clear()

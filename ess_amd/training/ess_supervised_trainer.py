@@ -1,0 +1,116 @@
+"""
+ESSSupervisedModel: events-only supervised training of the task decoder on top of the frozen E2VID encoder
+(reference: training/ess_supervised_trainer.py).  Same class surface: models_dict {'front_sensor_b',
+'back_end'}, optimizers_dict {'optimizer_back'}, train_step(batch) -> (losses, outputs, final_loss).
+"""
+import math
+
+import torch
+
+from ..e2vid.image_reconstructor import ImageReconstructor
+from ..e2vid.utils.loading_utils import load_model
+from ..evaluation.metrics import MetricsSemseg
+from ..models.style_networks import SemSegE2VID
+from ..utils import radam
+from ..utils.loss_functions import L1Loss, TaskLoss
+from . import base_trainer
+from .ess_trainer import build_event_encoder
+
+
+class ESSSupervisedModel(base_trainer.BaseTrainer):
+    def __init__(self, settings, train=True):
+        self.is_training = train
+        super().__init__(settings)
+        self.do_val_training_epoch = False
+
+    def init_fn(self):
+        self.buildModels()
+        self.createOptimizerDict()
+        self.cycle_content_loss = L1Loss()
+        self.cycle_attribute_loss = L1Loss()
+        s = self.settings
+        self.task_loss = TaskLoss(losses=s.task_loss, gamma=2.0, num_classes=s.semseg_num_classes,
+                                  ignore_index=s.semseg_ignore_label, reduction='mean')
+        self.metrics_semseg_b = MetricsSemseg(s.semseg_num_classes, s.semseg_ignore_label, s.semseg_class_names)
+
+    def buildModels(self):
+        s = self.settings
+        self.front_end_sensor_b = build_event_encoder(s).to(self.device)
+        for p in self.front_end_sensor_b.parameters():
+            p.requires_grad = False
+        self.front_end_sensor_b.eval()
+        self.input_height = math.ceil(s.img_size_b[0] / 8.0) * 8
+        self.input_width = math.ceil(s.img_size_b[1] / 8.0) * 8
+        self.reconstructor = ImageReconstructor(self.front_end_sensor_b, self.input_height, self.input_width,
+                                                s.nr_temporal_bins_b, s.gpu_device, s.e2vid_config)
+        self.models_dict = {'front_sensor_b': self.front_end_sensor_b}
+        self.task_backend = SemSegE2VID(input_c=256, output_c=s.semseg_num_classes, skip_connect=s.skip_connect_task,
+                                        skip_type=s.skip_connect_task_type).to(self.device)
+        self.models_dict['back_end'] = self.task_backend
+
+    def createOptimizerDict(self):
+        if not self.is_training:
+            self.optimizers_dict = {}
+            return
+        back_params = [p for p in self.task_backend.parameters() if p.requires_grad]
+        self.optimizers_dict = {'optimizer_back': radam.RAdam(back_params, lr=self.settings.lr_back, weight_decay=0.,
+                                                              betas=(0., 0.999))}
+
+    def train_step(self, input_batch):
+        opt = self.optimizers_dict['optimizer_back']
+        opt.zero_grad()
+        d_final_loss, d_losses, d_outputs = self.task_train_step(input_batch)
+        d_final_loss.backward()
+        self.grad_reducer.launch(opt.flat_grad)
+        self.grad_reducer.wait()
+        opt.step()
+        return d_losses, d_outputs, d_final_loss
+
+    def task_train_step(self, batch):
+        s = self.settings
+        data_b = batch[0].to(self.device)
+        labels_b = (batch[2] if s.require_paired_data_train_b else batch[1]).to(self.device)
+        for name, m in self.models_dict.items():
+            m.train()
+            if name == 'front_sensor_b':
+                m.eval()
+        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+        T, C = s.nr_events_data_b, s.input_channels_b
+        for i in range(T):
+            # only the encoder half feeds the recurrent state; the image half is needed at the last step only
+            img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
+                data_b[:, i * C:(i + 1) * C, :, :], need_image=False)
+        losses, outputs = {}, {}
+        loss, pred_b = self.trainTaskStep('sensor_b', latent_real, labels_b, losses)
+        return loss, losses, outputs
+
+    def trainTaskStep(self, sensor_name, content_features, labels, losses):
+        content_features = {k: v.detach() for k, v in content_features.items()}
+        pred = self.models_dict['back_end'](content_features)
+        loss_pred = self.task_loss(pred[1], labels) * self.settings.weight_task_loss
+        losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
+        return loss_pred, pred
+
+    # ------------------------------------------------------------------ validation (reference :235-292)
+    def validationEpoch(self, data_loader, sensor_name):
+        self.metrics_semseg_b.reset()
+        for batch in data_loader:
+            self.val_step(batch, sensor_name)
+        if self.metrics_semseg_b.metrics_acc is not None:
+            m = self.metrics_semseg_b.get_metrics_summary()
+            self.summary_writer.add_scalar('val_{}/mean_iou'.format(sensor_name), float(m['mean_iou']), self.epoch_count)
+            self.summary_writer.add_scalar('val_{}/acc'.format(sensor_name), float(m['acc']), self.epoch_count)
+            self.last_val_metrics = m
+
+    def val_step(self, batch, sensor):
+        s = self.settings
+        data = batch[0].to(self.device)
+        labels = (batch[2] if s.require_paired_data_val_b and len(batch) > 2 else batch[1]).to(self.device)
+        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+        T, C = s.nr_events_data_b, s.input_channels_b
+        for i in range(T):
+            _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False)
+        pred = self.models_dict['back_end'](latent)[1]
+        if tuple(pred.shape[2:]) != tuple(labels.shape[1:]):
+            pred = torch.nn.functional.interpolate(pred, size=tuple(labels.shape[1:]), mode='nearest')
+        return self.metrics_semseg_b.update_batch_logits(pred, labels)

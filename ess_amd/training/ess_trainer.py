@@ -1,0 +1,285 @@
+"""
+ESSModel: the unsupervised-domain-adaptation train step of ESS (reference: training/ess_trainer.py).
+
+Class surface kept: models_dict {'front_sensor_a','front_sensor_b','back_end'}, optimizers_dict
+{'optimizer_front_sensor_a','optimizer_back'}, train_step(batch) -> (losses, outputs, final_loss) with the
+reference's loss-dict keys, img_train_step / trainTaskStep / trainCycleStep / event_train_step /
+TasktrainCycleStep, val_step.
+
+What differs from the reference and why the results do not (SURVEY.md 3.1 "redundant work"):
+  * the decoder is evaluated on each latent set ONCE per step: `back_end(latent_real)` (with grad, for the task
+    cycle loss) doubles as the no-grad target of the image-encoder cycle loss and vice versa -- the decoder
+    has no train/eval-dependent state (InstanceNorm without running stats), probe-verified bit-identical;
+  * for non-final time steps only head+encoders of the UNet run (their outputs are all that reaches the state);
+  * `back_end` is frozen BEFORE the forward whose backward must not produce its weight gradients, instead of
+    toggling requires_grad between forward and backward (reference :133-136): same gradients, no wasted wgrad;
+  * loss scalars stay on the device (no `.cpu()` per entry, reference :220-253) -- no host syncs inside the step;
+  * data parallel: per-optimiser flat-gradient all-reduce overlapped with the following backward.
+"""
+import math
+
+import torch
+
+from ..e2vid.image_reconstructor import ImageReconstructor
+from ..e2vid.model.model import E2VIDRecurrent
+from ..e2vid.utils.loading_utils import load_model
+from ..evaluation.metrics import MetricsSemseg
+from ..models.style_networks import SemSegE2VID, StyleEncoderE2VID
+from ..utils import radam
+from ..utils.loss_functions import L1Loss, TaskLoss, symJSDivLoss
+from . import base_trainer
+
+
+def build_event_encoder(settings):
+    """E2VID checkpoint if present (reference ess_trainer.py:51), else -- synthetic mode only -- a seeded
+    E2VIDRecurrent from `synthetic.e2vid` (the pretrained file cannot be downloaded offline)."""
+    import os
+    if os.path.isfile(settings.path_to_model):
+        model, _ = load_model(settings.path_to_model)
+        return model
+    if not getattr(settings, 'synthetic', False):
+        raise FileNotFoundError(settings.path_to_model)
+    cfg = dict(num_bins=settings.nr_temporal_bins_b, skip_type='sum', num_encoders=3, base_num_channels=32,
+               num_residual_blocks=2, norm='BN', use_upsample_conv=True, recurrent_block_type='convlstm')
+    cfg.update(settings.synthetic_cfg.get('e2vid') or {})
+    g = torch.random.get_rng_state()
+    torch.manual_seed(int(settings.synthetic_cfg.get('weight_seed', 6)))
+    model = E2VIDRecurrent(cfg)
+    with torch.no_grad():  # non-trivial BN statistics so the folded epilogue is exercised
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.05)
+    torch.random.set_rng_state(g)
+    return model
+
+
+class ESSModel(base_trainer.BaseTrainer):
+    def __init__(self, settings, train=True):
+        self.is_training = train
+        super().__init__(settings)
+        self.do_val_training_epoch = False
+
+    def init_fn(self):
+        self.buildModels()
+        self.createOptimizerDict()
+        s = self.settings
+        self.cycle_content_loss = L1Loss()
+        self.cycle_pred_loss = symJSDivLoss()
+        self.task_loss = TaskLoss(losses=s.task_loss, gamma=2.0, num_classes=s.semseg_num_classes,
+                                  ignore_index=s.semseg_ignore_label, reduction='mean')
+        self.metrics_semseg_a = MetricsSemseg(s.semseg_num_classes, s.semseg_ignore_label, s.semseg_class_names)
+        if s.semseg_label_val_b:
+            self.metrics_semseg_b = MetricsSemseg(s.semseg_num_classes, s.semseg_ignore_label, s.semseg_class_names)
+            self.metrics_semseg_cycle = MetricsSemseg(s.semseg_num_classes, s.semseg_ignore_label, s.semseg_class_names)
+
+    def buildModels(self):
+        s = self.settings
+        self.front_end_sensor_a = StyleEncoderE2VID(s.input_channels_a, skip_connect=s.skip_connect_encoder).to(self.device)
+        self.front_end_sensor_b = build_event_encoder(s).to(self.device)
+        self.e2vid_decoder = None
+        for p in self.front_end_sensor_b.parameters():
+            p.requires_grad = False
+        self.front_end_sensor_b.eval()
+        self.input_height = math.ceil(s.img_size_b[0] / 8.0) * 8
+        self.input_width = math.ceil(s.img_size_b[1] / 8.0) * 8
+        if s.dataset_name_b == 'DDD17_events' and not getattr(s, 'synthetic', False):
+            self.input_height, self.input_width = 120, 216  # random-crop size of the DDD17 training loader (:58-60)
+        self.input_height_valid, self.input_width_valid = self.input_height, self.input_width
+        self.reconstructor = ImageReconstructor(self.front_end_sensor_b, self.input_height, self.input_width,
+                                                s.nr_temporal_bins_b, s.gpu_device, s.e2vid_config)
+        self.reconstructor_valid = self.reconstructor
+        if s.dataset_name_b == 'DDD17_events' and not getattr(s, 'synthetic', False):
+            self.input_height_valid, self.input_width_valid = 200, 352
+            self.reconstructor_valid = ImageReconstructor(self.front_end_sensor_b, 200, 352, s.nr_temporal_bins_b,
+                                                          s.gpu_device, s.e2vid_config)
+        self.models_dict = {'front_sensor_a': self.front_end_sensor_a, 'front_sensor_b': self.front_end_sensor_b}
+        self.task_backend = SemSegE2VID(input_c=256, output_c=s.semseg_num_classes, skip_connect=s.skip_connect_task,
+                                        skip_type=s.skip_connect_task_type).to(self.device)
+        self.models_dict['back_end'] = self.task_backend
+
+    def createOptimizerDict(self):
+        if not self.is_training:
+            self.optimizers_dict = {}
+            return
+        s = self.settings
+        front = [p for p in self.front_end_sensor_a.parameters() if p.requires_grad]
+        back = [p for p in self.task_backend.parameters() if p.requires_grad]
+        self.optimizers_dict = {
+            'optimizer_front_sensor_a': radam.RAdam(front, lr=s.lr_front, weight_decay=0., betas=(0., 0.999)),
+            'optimizer_back': radam.RAdam(back, lr=s.lr_back, weight_decay=0., betas=(0., 0.999))}
+
+    # ------------------------------------------------------------------ the UDA step (reference :103-148)
+    def train_step(self, input_batch):
+        losses, outputs = {}, {}
+        opt_front, opt_back = self.optimizers_dict['optimizer_front_sensor_a'], self.optimizers_dict['optimizer_back']
+        opt_back.zero_grad()
+        opt_front.zero_grad()
+
+        t_final_loss, t_losses, t_outputs = self.img_train_step(input_batch)
+        # DSEC: the image latents were detached, so this reaches the decoder only; DDD17: decoder + image encoder
+        t_final_loss.backward()
+        final_loss = t_final_loss.detach()
+        losses.update(t_losses)
+        outputs.update(t_outputs)
+
+        e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch)
+        e_loss.backward()  # image encoder only: the decoder was frozen while this graph was recorded
+        self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
+        t_loss.backward()  # decoder only
+        self.grad_reducer.launch(opt_back.flat_grad)
+        final_loss = final_loss + e_loss.detach() + t_loss.detach()
+        losses.update(event_losses)
+        outputs.update(event_outputs)
+
+        self.grad_reducer.wait()
+        opt_back.step()
+        opt_front.step()
+        return losses, outputs, final_loss
+
+    def img_train_step(self, batch):
+        s = self.settings
+        data_a = batch[0][0]
+        labels_a = batch[0][2] if s.require_paired_data_train_a else batch[0][1]
+        for name, m in self.models_dict.items():
+            m.train()
+            if name in ('front_sensor_b', 'e2vid_decoder'):
+                m.eval()
+        for p in self.models_dict['back_end'].parameters():
+            p.requires_grad = True
+        losses, out = {}, {}
+        if s.dataset_name_b == 'DSEC_events':
+            with torch.no_grad():  # outputs are detached below: no tape needed, BN running stats still update
+                latent_fake = self.models_dict['front_sensor_a'](data_a)
+        else:
+            latent_fake = self.models_dict['front_sensor_a'](data_a)
+        t_loss, pred_a = self.trainTaskStep('sensor_a', latent_fake, labels_a, losses)
+        return t_loss, losses, out
+
+    def trainTaskStep(self, sensor_name, latent_fake, labels, losses, pred=None):
+        if pred is None:
+            if self.settings.dataset_name_b == 'DSEC_events':
+                latent_fake = {k: v.detach() for k, v in latent_fake.items()}
+            pred = self.models_dict['back_end'](latent_fake)
+        loss_pred = self.task_loss(pred[1], labels) * self.settings.weight_task_loss
+        losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
+        return loss_pred, pred
+
+    def trainCycleStep(self, first_sensor_name, second_sensor_name, content_first_sensor, content_second_sensor, losses,
+                       pred_first_sensor_no_grad=None):
+        """Cycle losses that train the image encoder (reference :211-255).  The decoder must be frozen by the caller
+        while this runs (event_train_step does it); `pred_first_sensor_no_grad` lets the caller share the decoder
+        output on the event latents instead of recomputing it."""
+        s = self.settings
+        g_loss = 0.
+        cycle_name = first_sensor_name + '_to_' + second_sensor_name
+        scales = (2, 4, 8) if s.skip_connect_encoder else (8,)
+        for k in scales:
+            li = self.cycle_content_loss(content_second_sensor[k], content_first_sensor[k]) * s.weight_cycle_loss
+            g_loss = g_loss + li
+            losses['cycle_latent_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
+        task_backend = self.models_dict['back_end']
+        pred_second_sensor = task_backend(content_second_sensor)
+        if pred_first_sensor_no_grad is None:
+            with torch.no_grad():
+                pred_first_sensor_no_grad = task_backend(content_first_sensor)
+        js = self.cycle_pred_loss(pred_second_sensor[1], pred_first_sensor_no_grad[1])
+        losses['cycle_pred_1x_' + cycle_name + '_loss'] = js.detach()
+        if s.dataset_name_b == 'DSEC_events':
+            g_loss = g_loss + js
+        for k in (2, 4):
+            li = self.cycle_content_loss(pred_second_sensor[k], pred_first_sensor_no_grad[k]) * s.weight_cycle_task_loss
+            g_loss = g_loss + li
+            losses['cycle_pred_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
+        return g_loss, pred_first_sensor_no_grad, pred_second_sensor
+
+    def event_train_step(self, batch):
+        s = self.settings
+        data_b = batch[1][0]
+        labels_b = batch[1][2] if s.require_paired_data_train_b else batch[1][1]
+        for name, m in self.models_dict.items():
+            m.train()
+            if name in ('front_sensor_b', 'e2vid_decoder', 'back_end'):
+                m.eval()
+        gen_model_sensor_a = self.models_dict['front_sensor_a']
+        back_end = self.models_dict['back_end']
+        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+        losses, out = {}, {}
+        T, C = s.nr_events_data_b, s.input_channels_b
+        with torch.no_grad():
+            for i in range(T):
+                img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
+                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1))
+        latent_fake = gen_model_sensor_a(img_fake.detach())
+        latent_real = {k: v.detach() for k, v in latent_real.items()}
+
+        # decoder on the event latents: ONE forward, with grad (task cycle loss), shared as no-grad target
+        back_end.train()
+        pred_real = back_end(latent_real)
+        pred_real_ng = {k: v.detach() for k, v in pred_real.items()}
+
+        # image-encoder cycle losses: decoder frozen while the graph is recorded -> data-gradients only
+        back_end.eval()
+        for p in back_end.parameters():
+            p.requires_grad = False
+        e_loss, pred_b, pred_a = self.trainCycleStep('sensor_b', 'sensor_a', latent_real, latent_fake, losses,
+                                                     pred_first_sensor_no_grad=pred_real_ng)
+        for p in back_end.parameters():
+            p.requires_grad = True
+
+        back_end.train()
+        pred_fake_ng = {k: v.detach() for k, v in pred_a.items()}
+        t_loss = self.TasktrainCycleStep('sensor_b', 'sensor_a', latent_real, latent_fake, losses,
+                                         pred_first_sensor=pred_real, pred_second_sensor_no_grad=pred_fake_ng)
+        if s.train_on_event_labels:
+            t_loss_b, _ = self.trainTaskStep('sensor_b', latent_real, labels_b, losses, pred=pred_real)
+            t_loss = t_loss + t_loss_b
+        return e_loss, t_loss, losses, out
+
+    def TasktrainCycleStep(self, first_sensor_name, second_sensor_name, content_first_sensor, content_second_sensor, losses,
+                           pred_first_sensor=None, pred_second_sensor_no_grad=None):
+        """Cycle losses that train the decoder (reference :303-330)."""
+        s = self.settings
+        task_backend = self.models_dict['back_end']
+        if pred_first_sensor is None:
+            pred_first_sensor = task_backend(content_first_sensor)
+        if pred_second_sensor_no_grad is None:
+            with torch.no_grad():
+                pred_second_sensor_no_grad = task_backend(content_second_sensor)
+        t_loss = self.cycle_pred_loss(pred_first_sensor[1], pred_second_sensor_no_grad[1]) * s.weight_KL_loss
+        for k in (2, 4):
+            t_loss = t_loss + self.cycle_content_loss(pred_first_sensor[k], pred_second_sensor_no_grad[k]) * \
+                s.weight_cycle_task_loss
+        return t_loss
+
+    # ------------------------------------------------------------------ validation (reference :364-493)
+    def validationEpoch(self, data_loader, sensor_name):
+        if not self.settings.semseg_label_val_b:
+            return
+        self.metrics_semseg_b.reset()
+        for batch in data_loader:
+            self.val_step(batch, sensor_name)
+        if self.metrics_semseg_b.metrics_acc is not None:
+            m = self.metrics_semseg_b.get_metrics_summary()
+            self.summary_writer.add_scalar('val_{}/mean_iou'.format(sensor_name), float(m['mean_iou']), self.epoch_count)
+            self.summary_writer.add_scalar('val_{}/acc'.format(sensor_name), float(m['acc']), self.epoch_count)
+            self.last_val_metrics = m
+
+    def val_step(self, batch, sensor):
+        s = self.settings
+        data = batch[0].to(self.device)
+        labels = (batch[2] if s.require_paired_data_val_b and len(batch) > 2 else batch[1]).to(self.device)
+        rec = self.reconstructor_valid
+        rec.last_states_for_each_channel = {'grayscale': None}
+        T, C = s.nr_events_data_b, s.input_channels_b
+        for i in range(T):
+            _, _, latent = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False)
+        return self.valTaskStep(latent, labels, self.metrics_semseg_b)
+
+    def valTaskStep(self, content, labels, metrics):
+        pred = self.models_dict['back_end'](content)[1]
+        if tuple(pred.shape[2:]) != tuple(labels.shape[1:]):
+            pred = torch.nn.functional.interpolate(pred, size=tuple(labels.shape[1:]), mode='nearest')
+        return metrics.update_batch_logits(pred, labels)

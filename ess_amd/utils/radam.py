@@ -1,0 +1,104 @@
+"""RAdam with ONE flat-buffer HIP kernel per step (reference: utils/radam.py).
+
+Same constructor and update rule as the reference (incl. the N_sma >= 5 switch and weight_decay handling).
+Differences that do not change results: all parameters of the optimiser are re-homed into one contiguous fp32
+buffer (each nn.Parameter becomes a view of it) with matching flat gradient / exp_avg / exp_avg_sq buffers,
+so `step()` is a single kernel launch instead of a Python loop over ~150 tensors, and the flat gradient
+buffer is what data-parallel training all-reduces.  `zero_grad()` zeroes the flat gradient in place and keeps
+the `.grad` views alive."""
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from .. import hip
+from ..functional import invalidate_packed
+
+
+class RAdam(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError('one parameter group per RAdam instance (as the ESS trainers build them)')
+        if weight_decay != 0:
+            raise NotImplementedError('weight_decay is always 0. in the ESS trainers (training/ess_trainer.py:91,99)')
+        self._step = 0
+        self._flatten()
+
+    def _flatten(self):
+        ps = [p for p in self.param_groups[0]['params']]
+        if not ps:
+            raise ValueError('RAdam got no parameters')
+        dev = ps[0].device
+        if not all(p.dtype == torch.float32 and p.device == dev for p in ps):
+            raise hip.EssHipError('RAdam: parameters must be fp32 on one device')
+        self._sizes = [p.numel() for p in ps]
+        n = sum(self._sizes)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p, k in zip(ps, self._sizes):
+                self.flat_param[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_param[off:off + k].view_as(p)
+                off += k
+        self._bind_grads()
+
+    def _bind_grads(self):
+        off = 0
+        for p, k in zip(self.param_groups[0]['params'], self._sizes):
+            p.grad = self.flat_grad[off:off + k].view_as(p)
+            off += k
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        self._bind_grads()
+
+    @staticmethod
+    def rectification(step, beta1, beta2):
+        """(N_sma, step_size) exactly as reference radam.py:49-64 (python float arithmetic)."""
+        beta2_t = beta2 ** step
+        n_sma_max = 2 / (1 - beta2) - 1
+        n_sma = n_sma_max - 2 * step * beta2_t / (1 - beta2_t)
+        if n_sma >= 5:
+            step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_sma_max - 4) * (n_sma - 2) / n_sma * n_sma_max /
+                                  (n_sma_max - 2)) / (1 - beta1 ** step)
+        else:
+            step_size = 1.0 / (1 - beta1 ** step)
+        return n_sma, step_size
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        group = self.param_groups[0]
+        # a parameter whose .grad was replaced (not accumulated into the view) is copied back into the flat buffer
+        off = 0
+        for p, k in zip(group['params'], self._sizes):
+            view = self.flat_grad[off:off + k]
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad.reshape(-1))
+            off += k
+        self._step += 1
+        beta1, beta2 = group['betas']
+        n_sma, step_size = self.rectification(self._step, beta1, beta2)
+        hip.radam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, group['lr'], beta1, beta2,
+                       group['eps'], step_size, n_sma >= 5)
+        invalidate_packed(group['params'])  # the kernel wrote the weights behind autograd's back
+        self._bind_grads()
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['flat'] = {'step': self._step, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        flat = state_dict.get('flat')
+        if flat is not None:
+            self._step = flat['step']
+            self.exp_avg.copy_(flat['exp_avg'])
+            self.exp_avg_sq.copy_(flat['exp_avg_sq'])

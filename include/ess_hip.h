@@ -111,7 +111,9 @@ int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1,
                      ess_stream_t stream);
 
 /* InstanceNorm2d(affine=False, eps) (+residual)(+ReLU): models/style_networks.py:163-164,180-182,192.
- * y = act(IN(x)) + residual.  stats: [N*C][2] = (mean, rstd) saved for backward.                    */
+ * relu = 0: y = IN(x) + residual; 1: y = relu(IN(x)) + residual; 2 (forward only): y = relu(IN(x) +
+ * residual) (ResidualBlock with norm='IN', e2vid/model/submodules.py:157-172).
+ * stats: [N*C][2] = (mean, rstd) saved for backward.                                                */
 int ess_instnorm_forward(const float* x, const float* residual, float* y, float* stats, int32_t planes,
                          int32_t hw, float eps, int32_t relu, ess_stream_t stream);
 /* dx from dy (gradient w.r.t. y; the residual branch gradient is dy itself, handled by the caller). */
