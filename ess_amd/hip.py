@@ -249,6 +249,7 @@ def add(a, b, out=None):
 
 
 def event_normalize(x):
+    ptr(x)  # device / dtype / layout check before anything is allocated
     y = torch.empty_like(x)
     ws = workspace(64, x.device, 'evnorm')
     _check(lib().ess_event_normalize(ptr(x), ptr(y), x.numel(), c_void_p(ws.data_ptr()), stream()), 'ess_event_normalize')

@@ -1,0 +1,165 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/ess_hip.h declares (no compute without a GPU),
+host-side planning/validation logic, RAdam rectification schedule, settings parsing, and the data-parallel gradient
+reducer over gloo with world_size 2."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    return ge.build_library(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'ess_hip.h')).read()
+    declared = set(re.findall(r'\b(ess_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(built_lib)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from ess_amd import hip
+    assert set(hip.EXPORTS) == declared
+
+
+def test_conv_plan_and_validation_on_host(built_lib):
+    from ess_amd import hip
+    sp = hip.conv_spec(8, 240, 320, 64, 64, 256, 3, 1, 1, epi=hip.EPI_LSTM, hidden=64)
+    assert (sp.H_out, sp.W_out) == (240, 320)
+    assert sp.plan.cout_tile == 64 and sp.plan.ck == 8 and sp.plan.n_chunks == 16 and sp.plan.n_cout_tiles == 4
+    assert sp.plan.packed_elems == 256 * 128 * 9 and sp.plan.lds_bytes <= 64 * 1024
+    head = hip.conv_spec(2, 200, 352, 2, 0, 32, 5, 1, 2, act=hip.ACT_RELU)
+    assert head.plan.ck == 2 and head.plan.cout_tile == 32
+    small = hip.conv_spec(1, 24, 40, 32, 0, 11, 1, 1, 0)  # 11 classes padded to a 32-row tile
+    assert small.plan.rows_padded == 32
+    with pytest.raises(hip.EssHipError, match='ksize'):
+        hip.conv_spec(1, 8, 8, 4, 0, 4, 4, 1, 1)
+    with pytest.raises(hip.EssHipError, match='LSTM'):
+        hip.conv_spec(1, 8, 8, 4, 4, 12, 3, 1, 1, epi=hip.EPI_LSTM, hidden=4)
+
+
+def test_product_refuses_cpu_tensors(built_lib):
+    from ess_amd import hip
+    with pytest.raises(hip.EssHipError, match='no CPU path'):
+        hip.event_normalize(torch.zeros(1, 2, 4, 4))
+
+
+def test_missing_library_is_loud(monkeypatch, built_lib):
+    from ess_amd import hip
+    monkeypatch.setattr(hip, '_lib', None)
+    monkeypatch.setattr(hip, 'LIB_PATH', '/nonexistent/libess_hip.so')
+    with pytest.raises(hip.EssHipError, match='no CPU or eager fallback'):
+        hip.lib()
+
+
+def test_radam_rectification_matches_oracle():
+    from oracle import ess_oracle as O
+    from ess_amd.utils.radam import RAdam
+    for step in range(1, 40):
+        assert RAdam.rectification(step, 0.0, 0.999) == O.radam_step_size(step, 0.0, 0.999)
+    assert RAdam.rectification(5, 0.0, 0.999)[0] < 5 <= RAdam.rectification(6, 0.0, 0.999)[0]
+
+
+def test_state_dict_layout_matches_reference_tables():
+    """The product modules expose exactly the reference's state_dict keys/shapes (pinned through the oracle tables,
+    which tests/golden/make_golden.py asserts against the imported reference)."""
+    from oracle import ess_oracle as O
+    from ess_amd.e2vid.model.model import E2VIDRecurrent
+    from ess_amd.models.style_networks import SemSegE2VID, StyleEncoderE2VID
+    for rec in ('convlstm', 'convgru'):
+        for norm in ('BN', 'none', 'IN'):
+            for up in (True, False):
+                cfg = O.e2vid_config(num_bins=5, recurrent_block_type=rec, norm=norm, use_upsample_conv=up, base_num_channels=8)
+                got = {k: tuple(v.shape) for k, v in E2VIDRecurrent(dict(cfg)).state_dict().items()}
+                assert got == {k: tuple(v) for k, v in O.e2vid_param_shapes(cfg).items()}, (rec, norm, up)
+    for skip in (True, False):
+        got = {k: tuple(v.shape) for k, v in SemSegE2VID(256, 11, skip, 'concat' if skip else 'sum').state_dict().items()}
+        assert got == {k: tuple(v) for k, v in O.semseg_param_shapes(256, 11, skip).items()}
+    got = {k: tuple(v.shape) for k, v in StyleEncoderE2VID(1, True).state_dict().items()}
+    assert got == {k: tuple(v) for k, v in O.style_encoder_param_shapes(1).items()}
+
+
+def test_settings_parses_reference_yaml_schema(tmp_path):
+    import yaml
+    from ess_amd.config.settings import Settings
+    ref_yaml = {
+        'dataset': {'name_a': 'Cityscapes_gray', 'name_b': 'DSEC_events',
+                    'DSEC_events': {'dataset_path': '/none', 'shape': [440, 640], 'nr_events_data': 20,
+                                    'nr_events_files_per_data': None, 'fixed_duration': False, 'delta_t_per_data': 50,
+                                    'require_paired_data_train': False, 'require_paired_data_val': True,
+                                    'nr_events_window': 100000, 'event_representation': 'voxel_grid', 'nr_temporal_bins': 5,
+                                    'separate_pol': False, 'normalize_event': False},
+                    'cityscapes_img': {'dataset_path': '/none', 'shape': [440, 640], 'random_crop': False,
+                                       'read_two_imgs': False, 'require_paired_data_train': False,
+                                       'require_paired_data_val': False}},
+        'task': {'semseg_num_classes': 11}, 'dir': {'log': str(tmp_path)},
+        'model': {'model_name': 'ess', 'skip_connect_encoder': True, 'skip_connect_task': True,
+                  'skip_connect_task_type': 'concat', 'data_augmentation_train': True, 'train_on_event_labels': False},
+        'optim': {'batch_size_a': 8, 'batch_size_b': 8, 'lr_front': '5e-4', 'lr_back': '5e-4', 'lr_decay': 1, 'num_epochs': 50,
+                  'val_epoch_step': 5, 'weight_task_loss': 1, 'weight_cycle_pred_loss': 1, 'weight_cycle_emb_loss': 1,
+                  'weight_cycle_task_loss': 1, 'task_loss': ['dice', 'cross_entropy']},
+        'checkpoint': {'save_checkpoint': True, 'resume_training': False, 'load_pretrained_weights': False,
+                       'resume_file': None, 'pretrained_file': None},
+        'hardware': {'num_cpu_workers': 8, 'gpu_device': 0},
+        'synthetic': {'enabled': True, 'img_size': [480, 640], 'nr_events_data': 5, 'nr_temporal_bins': 2},
+    }
+    p = tmp_path / 's.yaml'
+    p.write_text(yaml.safe_dump(ref_yaml))
+    s = Settings(str(p), generate_log=False)
+    assert s.model_name == 'ess' and s.dataset_name_b == 'DSEC_events' and s.semseg_num_classes == 11
+    assert s.nr_events_data_b == 5 and s.input_channels_b == 2 and s.img_size_b == [480, 640]
+    assert s.weight_KL_loss == 1.0 and s.weight_cycle_loss == 1.0 and s.lr_front == 5e-4
+    assert len(s.semseg_class_names) == 11 and s.semseg_ignore_label == 255
+    ref_yaml['synthetic']['enabled'] = False
+    p.write_text(yaml.safe_dump(ref_yaml))
+    with pytest.raises(AssertionError):  # dataset dirs must exist, as in the reference
+        Settings(str(p), generate_log=False)
+
+
+def _dp_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ess_amd.training import distributed as D
+    red = D.GradAllReducer()
+    g1 = torch.full((1000,), float(rank + 1))
+    g2 = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    red.launch(g1)
+    red.launch(g2)
+    red.wait()
+    lin = torch.nn.Linear(4, 3)
+    torch.manual_seed(rank)
+    with torch.no_grad():
+        lin.weight.normal_()
+    D.broadcast_module(lin, 0)
+    out = torch.cat([g1[:2], g2[:3], lin.weight.flatten()[:2]])
+    gathered = [torch.zeros_like(out) for _ in range(world)]
+    dist.all_gather(gathered, out)
+    if rank == 0:
+        ret.put([t.tolist() for t in gathered])
+    dist.destroy_process_group()
+
+
+def test_data_parallel_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a == b  # both ranks hold the same averaged gradients and the same broadcast weights
+    assert a[0] == pytest.approx(1.5) and a[3] == pytest.approx(1.5 * 1) and a[4] == pytest.approx(1.5 * 2)
