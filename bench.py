@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 
 
 def parse():
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--classes', type=int, default=11)
     ap.add_argument('--trainer', default='ess', choices=['ess', 'ess_supervised'])
+    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32'],
+                    help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3) or exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -104,10 +107,13 @@ def roofline_gate_kernels(args, device):
         tot_flops += flops
         tot_ms += ms
     achieved = tot_flops / tot_ms / 1e9
-    return {'bound': 'mfma', 'kernel': 'conv_f32_kernel<3,1,2,EPI_LSTM>', 'achieved': round(achieved, 2),
-            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+    bf16 = args.compute == 'bf16'
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    return {'bound': 'mfma', 'kernel': ('conv_bf16_kernel' if bf16 else 'conv_f32_kernel') + '<3,1,2,EPI_LSTM>',
+            'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
             'traffic': None, 'per_level': per_level,
-            'note': 'fp32-input MFMA (exact fp32); avg over the 3 encoder-level launches of one time step'}
+            'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
+                    '; sum over the 3 encoder-level launches of one time step; HIP events on the launch stream'}
 
 
 def cpu_baseline(args):
@@ -159,6 +165,7 @@ def main():
     from ess_amd.training import distributed as D
     from ess_amd.training.synthetic import make_batch
     hip.lib()
+    hip.set_compute(args.compute)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=device)
@@ -203,12 +210,13 @@ def main():
             'metric': 'UDA train-step throughput (voxel grids/s = N*B*T/step_time)' if args.trainer == 'ess'
             else 'supervised train-step throughput (voxel grids/s)',
             'value': round(grids, 2), 'unit': 'voxel_grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.compute == 'bf16' else 'f32',
             'data': 'synthetic', 'sequences_per_s': round(world * args.batch * args.steps / elapsed, 3),
             'final_loss': final_loss,
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
                                    f'DSEC-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
-                                   f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam',
+                                   f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
+                                   f'conv contractions {args.compute} (fp32 accumulate, fp32 tensors), weight gradients fp32',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         }
         if not args.no_roofline:

@@ -29,6 +29,12 @@ static inline int ess_launch_status(const char* what) {
   return ESS_OK;
 }
 
+// dynamic LDS above 64 KiB must be opted into per kernel (up to the 160 KiB of a CDNA4 CU)
+template <typename K>
+static inline void ess_allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -183,6 +183,159 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 variant for 3x3 / stride 1 (95 % of the weight-gradient FLOPs): v_mfma_f32_32x32x16_bf16, reduction over 16
+// pixels per instruction.  A fragment = 8 consecutive pixels of dY[co] (lane half picks the second 8), B fragment =
+// the same 8 pixels of X[ci] shifted by the tap.  Tiles are converted to bf16 while staged; rows of X are stored
+// ONCE, aligned so that the kx = 1 fragment is a plain 16-byte vector; the kx = 0 / 2 fragments (one pixel to the
+// left / right) are produced from two neighbouring vectors with v_alignbyte (4 VALU per fragment) instead of keeping
+// three shifted copies in LDS.  Per-channel pitches are odd multiples of 16 B: lanes run over channels, so the
+// ds_read_b128 groups hit 16 distinct slots.
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4w cvt8(const float (&v)[8]) {
+  bf16x8w b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+  return __builtin_bit_cast(u32x4w, b);
+}
+// bytes [off, off+16) of the 32-byte concatenation lo|hi
+__device__ __forceinline__ u32x4w shift_left1(u32x4w lo, u32x4w hi) {  // window starting 14 bytes into lo (one pixel earlier than hi)
+  u32x4w r;
+  r[0] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
+  r[1] = __builtin_amdgcn_alignbyte(hi[1], hi[0], 2);
+  r[2] = __builtin_amdgcn_alignbyte(hi[2], hi[1], 2);
+  r[3] = __builtin_amdgcn_alignbyte(hi[3], hi[2], 2);
+  return r;
+}
+__device__ __forceinline__ u32x4w shift_right1(u32x4w lo, u32x4w hi) {  // window starting 2 bytes into lo (one pixel later)
+  u32x4w r;
+  r[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], 2);
+  r[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], 2);
+  r[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], 2);
+  r[3] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
+  return r;
+}
+
+struct WgradBArgs {
+  WgradArgs w;
+  int thl;     // pixel tile = (128 >> twl) rows x (1 << twl) cols, twl in {4,5}
+  int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
+};
+
+__global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b) {
+  extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
+  const WgradArgs& a = b.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x - cot * a.ci_tiles;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int cb = wave >> 1, ib = wave & 1;
+  const int TWp = 1 << a.twl, THp = 128 >> a.twl;
+  const int TV = TWp >> 3;  // vectors per dY row
+  const int IH = THp + 2;
+  const int Cin = a.C0 + a.C1;
+  u32x4w* dy_t = smemv;                 // [64][pyv]
+  u32x4w* x_t = smemv + 64 * b.pyv;     // [64][pxv]
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const size_t HWo = (size_t)a.Hout * a.Wout;
+
+  for (int tile = split; tile < a.ntiles; tile += nsplit) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * THp, x0 = tx * TWp;
+    __syncthreads();
+    // ---- dY tile: 64 channels x THp rows x TV vectors
+    for (int v = tid; v < 64 * THp * TV; v += 256) {
+      const int xv = v % TV, r = v / TV;
+      const int qy = r % THp, co = r / THp;
+      const int cg = cot * 64 + co, y = y0 + qy, x = x0 + xv * 8;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      if (cg < a.Cout && y < a.Hout) {
+        const float* src = a.dy + ((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x;
+        if (x + 8 <= a.Wout && (a.Wout & 3) == 0) {
+          const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (x + j < a.Wout) f[j] = src[j];
+        }
+      }
+      dy_t[co * b.pyv + qy * TV + xv] = cvt8(f);
+    }
+    // ---- X tile: 64 channels x IH rows x RV vectors; LDS pixel l of a row <-> image x = x0 - 8 + l
+    for (int v = tid; v < 64 * IH * b.rv; v += 256) {
+      const int xv = v % b.rv, r = v / b.rv;
+      const int iy = r % IH, ci = r / IH;
+      const int cg = cit * 64 + ci, gy = y0 - a.pad + iy, gx = x0 - 8 + xv * 8;
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      if (cg < Cin && gy >= 0 && gy < a.Hin) {
+        const bool first = cg < a.C0;
+        const int mode = first ? a.mode0 : a.mode1;
+        if (mode == ESS_SRC_DIRECT && gx >= 0 && gx + 8 <= a.Win && (a.Win & 3) == 0) {
+          const float* sp = first ? a.src0 : a.src1;
+          const int cc = first ? cg : cg - a.C0, Cs = first ? a.C0 : a.C1;
+          const float* src = sp + (((size_t)n * Cs + cc) * a.Hin + gy) * a.Win + gx;
+          const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = load_virtual(a, n, cg, gy, gx + j);
+        }
+      }
+      x_t[ci * b.pxv + iy * b.rv + xv] = cvt8(f);
+    }
+    __syncthreads();
+    const u32x4w* ap = dy_t + (cb * 32 + p) * b.pyv + half;
+    const u32x4w* xp = x_t + (ib * 32 + p) * b.pxv + half;
+    for (int qy = 0; qy < THp; ++qy) {
+      for (int xs = 0; xs < TV; xs += 2) {  // one 16-pixel k-step
+        const u32x4w av = ap[qy * TV + xs];
+        const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const u32x4w* row = xp + (qy + ky) * b.rv + xs;
+          const u32x4w v0 = row[0], v1 = row[1], v2 = row[2];
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(v0, v1)),
+                                                                    acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, v1), acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(v1, v2)),
+                                                                    acc[ky * 3 + 2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int ci = cit * 64 + ib * 32 + p;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+    }
+  if (a.ws_b && cit == 0 && ib == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int co = cot * 64 + cb * 32 + p;
+    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
                                     int Cin, int accumulate) {
   const size_t total = (size_t)T * Cout * Cin;
@@ -204,7 +357,8 @@ __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* d
 
 struct WPlan {
   int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
-  bool taps_variant;
+  bool taps_variant, bf16;
+  int pyv, pxv, rv;
   size_t slab_floats;
 };
 
@@ -222,14 +376,16 @@ WPlan wplan(const EssConvDesc* d) {
   WPlan w{};
   const int cin = d->C0 + d->C1, KS = d->ksize, S = d->stride;
   w.taps_variant = (cin == 1 && KS == 7);
-  // pixel tile of 64: pick the width that wastes the least
+  w.bf16 = d->compute == ESS_COMPUTE_BF16 && KS == 3 && S == 1 && d->pad == 1;
+  const int npx = w.bf16 ? 128 : 64;
+  // pixel tile of 64 (fp32) / 128 (bf16): pick the width that wastes the least
   double best = 1e300;
-  for (int twl = 5; twl >= 3; --twl) {
-    const int tw = 1 << twl, th = 64 >> twl;
+  for (int twl = 5; twl >= (w.bf16 ? 4 : 3); --twl) {
+    const int tw = 1 << twl, th = npx >> twl;
     const double c = (double)ceil_div(d->W_out, tw) * tw * ceil_div(d->H_out, th) * th + 1e-3 * (5 - twl);
     if (c < best) { best = c; w.twl = twl; }
   }
-  const int tw = 1 << w.twl, th = 64 >> w.twl;
+  const int tw = 1 << w.twl, th = npx >> w.twl;
   w.tiles_x = ceil_div(d->W_out, tw); w.tiles_y = ceil_div(d->H_out, th);
   w.ntiles = d->N * w.tiles_x * w.tiles_y;
   w.IH = (th - 1) * S + KS; w.IW = (tw - 1) * S + KS;
@@ -245,6 +401,12 @@ WPlan wplan(const EssConvDesc* d) {
   if (ns < 1) ns = 1;
   w.nsplit = ns;
   w.lds_bytes = (64 * 65 + (w.taps_variant ? w.IH * w.IW : 64 * w.plx)) * 4;
+  if (w.bf16) {
+    w.rv = tw / 8 + 2;
+    w.pyv = (th * tw / 8) | 1;
+    w.pxv = ((th + 2) * w.rv) | 1;
+    w.lds_bytes = 64 * (w.pyv + w.pxv) * 16;
+  }
   return w;
 }
 
@@ -293,7 +455,12 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
     hipLaunchKernelGGL((wgrad_f32_kernel<KS_, S_>), grid, dim3(256), w.lds_bytes, st, a);             \
   } while (0)
-  if (w.taps_variant) {
+  if (w.bf16) {
+    WgradBArgs bb{};
+    bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
+    if ((rc = raise_lds(wgrad_bf16_k3s1_kernel, w.lds_bytes))) return rc;
+    hipLaunchKernelGGL(wgrad_bf16_k3s1_kernel, grid, dim3(256), w.lds_bytes, st, bb);
+  } else if (w.taps_variant) {
     ESS_CHECK_ARG(d->stride == 2, "wgrad: 7x7 stem variant is stride 2 only");
     if ((rc = raise_lds(wgrad_taps_kernel<7, 2>, w.lds_bytes))) return rc;
     hipLaunchKernelGGL((wgrad_taps_kernel<7, 2>), grid, dim3(256), w.lds_bytes, st, a);

@@ -164,39 +164,217 @@ __global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split variants for few-but-large reduction groups (full-resolution InstanceNorm planes, BatchNorm channels):
+// pass 1 accumulates per-group partial sums from many workgroups into fp64 atomics, pass 2 is a flat elementwise map.
+// group g covers `nseg` segments of `hw` contiguous floats, segment j at ((j * seg_stride) + g) * hw
+// (InstanceNorm: nseg = 1; BatchNorm: nseg = N, seg_stride = C).
+
+// sums[g][0] += sum f0, sums[g][1] += sum f1 with (f0, f1) = (x, x^2) [MODE 0] or (g, g*xhat) [MODE 1, backward]
+template <int MODE>
+__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ stats,
+                                                           double* sums, int hw, int nseg, int seg_stride, int relu,
+                                                           int relu_from_y) {
+  __shared__ double red[16];
+  const int g = blockIdx.x, nsl = gridDim.y, sl = blockIdx.y;
+  const int len = ((hw + nsl - 1) / nsl + 3) & ~3;
+  const int i0 = sl * len, i1 = min(hw, i0 + len);
+  float mean = 0.f, rstd = 0.f;
+  if (MODE == 1) { mean = stats[2 * g]; rstd = stats[2 * g + 1]; }
+  double s0 = 0, s1 = 0;
+  for (int j = 0; j < nseg; ++j) {
+    const size_t base = ((size_t)j * seg_stride + g) * hw;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      if (MODE == 0) {
+        const double v = x[base + i];
+        s0 += v; s1 += v * v;
+      } else {
+        const float xh = (x[base + i] - mean) * rstd;
+        float gr = dy[base + i];
+        if (relu && (relu_from_y ? y[base + i] <= 0.f : xh <= 0.f)) gr = 0.f;
+        s0 += gr; s1 += (double)gr * xh;
+      }
+    }
+  }
+  s0 = block_sum_d(s0, red);
+  s1 = block_sum_d(s1, red);
+  if (threadIdx.x == 0) { atomicAdd(sums + 2 * g, s0); atomicAdd(sums + 2 * g + 1, s1); }
+}
+
+// InstanceNorm forward map: y = act(IN(x)) (+ residual) from the group sums; (chunk 0, thread 0) writes (mean, rstd)
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             float* __restrict__ y, float* __restrict__ stats,
+                                                             const double* sums, int hw, float eps, int relu) {
+  const int g = blockIdx.x;
+  const double mean_d = sums[2 * g] / hw;
+  double var = sums[2 * g + 1] / hw - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (blockIdx.y == 0 && threadIdx.x == 0) { stats[2 * g] = mean; stats[2 * g + 1] = rstd; }
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float t = (x[base + i] - mean) * rstd;
+    if (relu == 1) t = fmaxf(t, 0.f);
+    if (res) t += res[base + i];
+    if (relu == 2) t = fmaxf(t, 0.f);
+    y[base + i] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ stats, const double* sums,
+                                                                 float* __restrict__ dx, int hw, int relu) {
+  const int g = blockIdx.x;
+  const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+  const float m1 = (float)(sums[2 * g] / hw), m2 = (float)(sums[2 * g + 1] / hw);
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    const float xh = (x[base + i] - mean) * rstd;
+    float gr = dy[base + i];
+    if (relu && xh <= 0.f) gr = 0.f;
+    dx[base + i] = rstd * (gr - m1 - xh * m2);
+  }
+}
+
+// BatchNorm(train) forward map over plane (n, c) = blockIdx.x; the n == 0 / chunk 0 block also updates running stats
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* running_mean, float* running_var, float momentum, float eps,
+                                                       float* __restrict__ y, float* __restrict__ stats, const double* sums,
+                                                       int N, int C, int hw, int relu) {
+  const int plane = blockIdx.x, c = plane % C;
+  const double cnt = (double)N * hw;
+  const double mean_d = sums[2 * c] / cnt;
+  double var = sums[2 * c + 1] / cnt - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+    stats[2 * c] = mean; stats[2 * c + 1] = rstd;
+    if (running_mean) {
+      const double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  const float gm = gamma[c], bt = beta[c];
+  const size_t base = (size_t)plane * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float t = (x[base + i] - mean) * rstd * gm + bt;
+    if (res) t += res[base + i];
+    if (relu) t = fmaxf(t, 0.f);
+    y[base + i] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                           const float* __restrict__ stats, const double* sums,
+                                                           float* __restrict__ dx, float* __restrict__ dres, float* dgamma,
+                                                           float* dbeta, int accumulate, int N, int C, int hw, int relu) {
+  const int plane = blockIdx.x, c = plane % C;
+  const float mean = stats[2 * c], rstd = stats[2 * c + 1];
+  const double cnt = (double)N * hw;
+  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+  }
+  const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt), gr = gamma[c] * rstd;
+  const size_t base = (size_t)plane * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float g = dy[base + i];
+    if (relu && y[base + i] <= 0.f) g = 0.f;
+    if (dres) dres[base + i] = g;
+    if (dx) dx[base + i] = gr * (g - m1 - (x[base + i] - mean) * rstd * m2);
+  }
+}
+
+inline int split_for(int groups, int hw) {
+  int s = (2048 + groups - 1) / groups;
+  const int maxs = (hw + 2047) / 2048;  // at least 2048 elements per slice
+  if (s > maxs) s = maxs;
+  return s < 1 ? 1 : s;
+}
+inline int chunks_for(int planes, int hw) {
+  int c = (4096 + planes - 1) / planes;
+  const int maxc = (hw + 1023) / 1024;
+  if (c > maxc) c = maxc;
+  return c < 1 ? 1 : c;
+}
+inline int zero_ws(void* ws, size_t need, size_t have, hipStream_t st, const char* what) {
+  if (!ws || have < need) { ess_set_error("%s: workspace too small (%zu < %zu)", what, have, need); return ESS_EINVAL; }
+  hipError_t e = hipMemsetAsync(ws, 0, need, st);
+  if (e != hipSuccess) { ess_set_error("%s: memset failed: %s", what, hipGetErrorString(e)); return ESS_ELAUNCH; }
+  return ESS_OK;
+}
+
 }  // namespace
 
+extern "C" size_t ess_norm_workspace(int32_t groups) { return (size_t)(groups > 0 ? groups : 0) * 16; }
+
 extern "C" int ess_instnorm_forward(const float* x, const float* residual, float* y, float* stats, int32_t planes, int32_t hw,
-                                    float eps, int32_t relu, ess_stream_t stream) {
+                                    float eps, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && stats && planes > 0 && hw > 0, "instnorm_forward: bad arguments");
-  hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, residual, y, stats, hw, eps, relu);
-  return ess_launch_status("instnorm_forward");
+  hipStream_t st = (hipStream_t)stream;
+  if (planes >= 1024 || hw < 16384) {  // enough planes to fill the chip: one fused workgroup per plane
+    hipLaunchKernelGGL(instnorm_fwd_kernel, dim3(planes), dim3(NT), 0, st, x, residual, y, stats, hw, eps, relu);
+    return ess_launch_status("instnorm_forward");
+  }
+  int rc = zero_ws(workspace, ess_norm_workspace(planes), workspace_bytes, st, "instnorm_forward");
+  if (rc) return rc;
+  hipLaunchKernelGGL((group_reduce_kernel<0>), dim3(planes, split_for(planes, hw)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     (double*)workspace, hw, 1, 0, 0, 0);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(planes, chunks_for(planes, hw)), dim3(256), 0, st, x, residual, y, stats,
+                     (const double*)workspace, hw, eps, relu);
+  return ess_launch_status("instnorm_forward(split)");
 }
 
 extern "C" int ess_instnorm_backward(const float* x, const float* dy, const float* stats, float* dx, int32_t planes, int32_t hw,
-                                     int32_t relu, ess_stream_t stream) {
+                                     int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && dy && stats && dx && planes > 0 && hw > 0, "instnorm_backward: bad arguments");
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_backward: relu-after-residual (2) is forward only");
-  hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(NT), 0, (hipStream_t)stream, x, dy, stats, dx, hw, relu);
-  return ess_launch_status("instnorm_backward");
+  hipStream_t st = (hipStream_t)stream;
+  if (planes >= 1024 || hw < 16384) {
+    hipLaunchKernelGGL(instnorm_bwd_kernel, dim3(planes), dim3(NT), 0, st, x, dy, stats, dx, hw, relu);
+    return ess_launch_status("instnorm_backward");
+  }
+  int rc = zero_ws(workspace, ess_norm_workspace(planes), workspace_bytes, st, "instnorm_backward");
+  if (rc) return rc;
+  hipLaunchKernelGGL((group_reduce_kernel<1>), dim3(planes, split_for(planes, hw)), dim3(256), 0, st, x, nullptr, dy, stats,
+                     (double*)workspace, hw, 1, 0, relu, 0);
+  hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(planes, chunks_for(planes, hw)), dim3(256), 0, st, x, dy, stats,
+                     (const double*)workspace, dx, hw, relu);
+  return ess_launch_status("instnorm_backward(split)");
 }
 
 extern "C" int ess_batchnorm_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, float momentum, float eps, float* y,
-                                           float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, ess_stream_t stream) {
+                                           float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace,
+                                           size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && gamma && beta && y && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_forward: bad arguments");
   ESS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_forward: running stats come in pairs");
-  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(C), dim3(NT), 0, (hipStream_t)stream, x, residual, gamma, beta, running_mean,
-                     running_var, momentum, eps, y, stats, N, C, hw, relu);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = zero_ws(workspace, ess_norm_workspace(C), workspace_bytes, st, "batchnorm_train_forward");
+  if (rc) return rc;
+  hipLaunchKernelGGL((group_reduce_kernel<0>), dim3(C, split_for(C, hw)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                     (double*)workspace, hw, N, C, 0, 0);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(N * C, chunks_for(N * C, hw)), dim3(256), 0, st, x, residual, gamma, beta, running_mean,
+                     running_var, momentum, eps, y, stats, (const double*)workspace, N, C, hw, relu);
   return ess_launch_status("batchnorm_train_forward");
 }
 
 extern "C" int ess_batchnorm_train_backward(const float* x, const float* y, const float* dy, const float* gamma,
                                             const float* stats, float* dx, float* d_residual, float* dgamma, float* dbeta,
-                                            int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu,
-                                            ess_stream_t stream) {
+                                            int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace,
+                                            size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && dy && gamma && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_backward: bad arguments");
-  hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(C), dim3(NT), 0, (hipStream_t)stream, x, y, dy, gamma, stats, dx, d_residual,
-                     dgamma, dbeta, accumulate, N, C, hw, relu);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = zero_ws(workspace, ess_norm_workspace(C), workspace_bytes, st, "batchnorm_train_backward");
+  if (rc) return rc;
+  hipLaunchKernelGGL((group_reduce_kernel<1>), dim3(C, split_for(C, hw)), dim3(256), 0, st, x, y, dy, stats, (double*)workspace, hw,
+                     N, C, relu, 1);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(N * C, chunks_for(N * C, hw)), dim3(256), 0, st, x, y, dy, gamma, stats,
+                     (const double*)workspace, dx, d_residual, dgamma, dbeta, accumulate, N, C, hw, relu);
   return ess_launch_status("batchnorm_train_backward");
 }

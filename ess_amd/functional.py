@@ -67,7 +67,7 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x0, x1, weight = ctx.saved_tensors
         spec = ctx.spec
-        (N, Hv, Wv, C0, C1, mode0, mode1, Cout, k, s, p, _, _, _, _) = spec.key
+        (N, Hv, Wv, C0, C1, mode0, mode1, Cout, k, s, p, _, _, _, _, _) = spec.key
         dy = dy.contiguous()
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_x1, \
             ctx.needs_input_grad[2], ctx.needs_input_grad[3] and ctx.has_bias

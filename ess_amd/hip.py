@@ -18,10 +18,25 @@ SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 W_CONV, W_TRANSPOSED = 0, 1
+COMPUTE_FP32, COMPUTE_BF16 = 0, 1
+
+_default_compute = COMPUTE_FP32
+
+
+def set_compute(kind):
+    """Arithmetic of the convolution contractions for specs created without an explicit `compute`:
+    'fp32' (exact fp32 MFMA; BASELINE config 2) or 'bf16' (bf16 MFMA operands, fp32 accumulate, fp32 tensors in HBM;
+    BASELINE config 3).  Weight gradients always run on the fp32 MFMA path."""
+    global _default_compute
+    _default_compute = {'fp32': COMPUTE_FP32, 'bf16': COMPUTE_BF16, COMPUTE_FP32: COMPUTE_FP32, COMPUTE_BF16: COMPUTE_BF16}[kind]
+
+
+def get_compute():
+    return 'bf16' if _default_compute == COMPUTE_BF16 else 'fp32'
 
 EXPORTS = [
     'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',
-    'ess_conv2d_forward', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_instnorm_forward',
+    'ess_conv2d_forward', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
@@ -31,12 +46,12 @@ EXPORTS = [
 class EssConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         'N', 'H_in', 'W_in', 'C0', 'C1', 'mode0', 'mode1', 'C_out', 'H_out', 'W_out', 'ksize', 'stride', 'pad',
-        'epilogue', 'act', 'hidden', 'out_split')]
+        'epilogue', 'act', 'hidden', 'out_split', 'compute')]
 
 
 class EssConvPlan(Structure):
     _fields_ = [('cout_tile', c_int32), ('ck', c_int32), ('n_chunks', c_int32), ('n_cout_tiles', c_int32),
-                ('packed_elems', c_int64), ('rows_padded', c_int32), ('lds_bytes', c_int32)]
+                ('packed_elems', c_int64), ('packed_bytes', c_int64), ('rows_padded', c_int32), ('lds_bytes', c_int32)]
 
 
 class EssHipError(RuntimeError):
@@ -59,6 +74,8 @@ def lib():
         L.ess_conv2d_wgrad_workspace.argtypes = [POINTER(EssConvDesc)]
         L.ess_task_loss_workspace.restype = c_size_t
         L.ess_task_loss_workspace.argtypes = [c_int32]
+        L.ess_norm_workspace.restype = c_size_t
+        L.ess_norm_workspace.argtypes = [c_int32]
         P, F, I, I64 = c_void_p, c_float, c_int32, c_int64
         D = POINTER(EssConvDesc)
         sig = {
@@ -67,10 +84,10 @@ def lib():
             'ess_conv2d_pack_rows': [D, P, P, F, P, P],
             'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P],
             'ess_conv2d_wgrad': [D, P, P, P, P, P, c_int, P, c_size_t, P],
-            'ess_instnorm_forward': [P, P, P, P, I, I, F, I, P],
-            'ess_instnorm_backward': [P, P, P, P, I, I, I, P],
-            'ess_batchnorm_train_forward': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P],
-            'ess_batchnorm_train_backward': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+            'ess_instnorm_forward': [P, P, P, P, I, I, F, I, P, c_size_t, P],
+            'ess_instnorm_backward': [P, P, P, P, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_forward': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_backward': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_upsample_bilinear2x_add': [P, P, P, I, I, I, P],
             'ess_sumpool2x2': [P, P, I, I, I, I, P],
             'ess_add': [P, P, P, I64, P],
@@ -121,11 +138,11 @@ class ConvSpec:
     """Descriptor + plan of one convolution shape (cached)."""
 
     def __init__(self, key):
-        (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split) = key
+        (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split, compute) = key
         H_out = (H_in + 2 * p - k) // s + 1
         W_out = (W_in + 2 * p - k) // s + 1
         self.desc = EssConvDesc(N, H_in, W_in, C0, C1, mode0, mode1, C_out, H_out, W_out, k, s, p, epi, act, hidden,
-                                out_split)
+                                out_split, compute)
         self.plan = EssConvPlan()
         _check(lib().ess_conv2d_plan(byref(self.desc), byref(self.plan)), 'ess_conv2d_plan')
         self.key = key
@@ -134,8 +151,10 @@ class ConvSpec:
 
 
 def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC_DIRECT, epi=EPI_LINEAR, act=ACT_NONE,
-              hidden=0, out_split=0):
-    key = (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split)
+              hidden=0, out_split=0, compute=None):
+    if compute is None:
+        compute = _default_compute
+    key = (N, H_in, W_in, C0, C1, mode0, mode1, C_out, k, s, p, epi, act, hidden, out_split, compute)
     sp = _desc_cache.get(key)
     if sp is None:
         sp = _desc_cache[key] = ConvSpec(key)
@@ -143,8 +162,8 @@ def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC
 
 
 def pack_weights(spec, w, w2=None, kind=W_CONV):
-    out = torch.empty(spec.plan.packed_elems, dtype=torch.float32, device=w.device)
-    _check(lib().ess_conv2d_pack_weights(byref(spec.desc), kind, ptr(w), ptr(w2), ptr(out), stream()),
+    out = torch.empty(spec.plan.packed_bytes, dtype=torch.uint8, device=w.device)
+    _check(lib().ess_conv2d_pack_weights(byref(spec.desc), kind, ptr(w), ptr(w2), c_void_p(out.data_ptr()), stream()),
            'ess_conv2d_pack_weights')
     return out
 
@@ -158,7 +177,7 @@ def pack_rows(spec, v, v2=None, fill=0.0):
 
 def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None,
                  out2=None):
-    _check(lib().ess_conv2d_forward(byref(spec.desc), ptr(src0), ptr(src1), ptr(packed_w), ptr(scale), ptr(shift),
+    _check(lib().ess_conv2d_forward(byref(spec.desc), ptr(src0), ptr(src1), ptr(packed_w, torch.uint8), ptr(scale), ptr(shift),
                                     ptr(residual), ptr(aux0), ptr(aux1), ptr(out), ptr(out2), stream()),
            'ess_conv2d_forward')
     return out
@@ -191,16 +210,18 @@ def instnorm_forward(x, residual, relu, eps=1e-5):
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
+    ws = workspace(N * C * 16, x.device, 'norm')
     _check(lib().ess_instnorm_forward(ptr(x), ptr(residual), ptr(y), ptr(stats), N * C, H * W, c_float(eps), int(relu),
-                                      stream()), 'ess_instnorm_forward')
+                                      c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_forward')
     return y, stats
 
 
 def instnorm_backward(x, dy, stats, relu):
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
-    _check(lib().ess_instnorm_backward(ptr(x), ptr(dy), ptr(stats), ptr(dx), N * C, H * W, int(relu), stream()),
-           'ess_instnorm_backward')
+    ws = workspace(N * C * 16, x.device, 'norm')
+    _check(lib().ess_instnorm_backward(ptr(x), ptr(dy), ptr(stats), ptr(dx), N * C, H * W, int(relu),
+                                       c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward')
     return dx
 
 
@@ -208,9 +229,11 @@ def batchnorm_train_forward(x, residual, gamma, beta, running_mean, running_var,
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    ws = workspace(C * 16, x.device, 'norm')
     _check(lib().ess_batchnorm_train_forward(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean),
                                              ptr(running_var), c_float(momentum), c_float(eps), ptr(y), ptr(stats), N, C,
-                                             H * W, int(relu), stream()), 'ess_batchnorm_train_forward')
+                                             H * W, int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
+           'ess_batchnorm_train_forward')
     return y, stats
 
 
@@ -219,8 +242,10 @@ def batchnorm_train_backward(x, y, dy, gamma, stats, relu, need_dx=True, need_dr
     N, C, H, W = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dres = torch.empty_like(x) if need_dres else None
+    ws = workspace(C * 16, x.device, 'norm')
     _check(lib().ess_batchnorm_train_backward(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dres),
-                                              ptr(dgamma), ptr(dbeta), int(accumulate), N, C, H * W, int(relu), stream()),
+                                              ptr(dgamma), ptr(dbeta), int(accumulate), N, C, H * W, int(relu),
+                                              c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
            'ess_batchnorm_train_backward')
     return dx, dres
 

@@ -39,6 +39,9 @@ enum {
   ESS_EPI_GRU_OUT = 3  /* ConvGRU candidate -> h'               e2vid/model/submodules.py:270-271     */
 };
 enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3 };
+/* arithmetic of the convolution contraction.  Tensors in HBM are fp32 either way; BF16 rounds the MFMA operands
+ * (activations while staging the LDS tile, weights at pack time) to bfloat16 and accumulates in fp32.         */
+enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -67,13 +70,15 @@ typedef struct EssConvDesc {
                            GRU_UR, hidden GRU_OUT)                                                   */
   int32_t out_split;    /* LINEAR: >0 writes channels [0,out_split) to `out` and the rest to `out2`
                            (data-gradient of a two-source conv)                                      */
+  int32_t compute;      /* ESS_COMPUTE_*                                                             */
 } EssConvDesc;
 
 typedef struct EssConvPlan {
   int32_t cout_tile;    /* output channels per workgroup (32 or 64)                                  */
   int32_t ck;           /* input channels per LDS chunk                                              */
   int32_t n_chunks, n_cout_tiles;
-  int64_t packed_elems; /* floats in the packed weight buffer                                        */
+  int64_t packed_elems; /* elements in the packed weight buffer (fp32 or bf16 by `compute`)          */
+  int64_t packed_bytes; /* size of that buffer                                                       */
   int32_t rows_padded;  /* n_cout_tiles * cout_tile = length of packed scale/shift vectors           */
   int32_t lds_bytes;
 } EssConvPlan;
@@ -87,7 +92,7 @@ int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
  * w_kind ESS_W_CONV: w is [C_out][C0+C1][k][k]; ESS_W_TRANSPOSED: w is [C0+C1][C_out][k][k].
  * For ESS_EPI_GRU_UR pass w = update_gate.weight and w2 = reset_gate.weight.                        */
 int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const float* w, const float* w2,
-                            float* packed, ess_stream_t stream);
+                            void* packed, ess_stream_t stream);
 /* Same permutation/padding for a per-output-channel vector (bias, folded BN scale/shift).
  * v2: second vector for GRU_UR (reset gate); fill: value for padded rows.                           */
 int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, float fill,
@@ -97,7 +102,7 @@ int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, 
  * residual: [N][C_out][H_out][W_out] or NULL (LINEAR).
  * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev ; aux1: GRU_OUT u.
  * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h | LINEAR split.  */
-int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const float* src1, const float* packed_w,
+int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const float* src1, const void* packed_w,
                        const float* scale, const float* shift, const float* residual, const float* aux0,
                        const float* aux1, float* out, float* out2, ess_stream_t stream);
 
@@ -114,24 +119,27 @@ int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1,
  * relu = 0: y = IN(x) + residual; 1: y = relu(IN(x)) + residual; 2 (forward only): y = relu(IN(x) +
  * residual) (ResidualBlock with norm='IN', e2vid/model/submodules.py:157-172).
  * stats: [N*C][2] = (mean, rstd) saved for backward.                                                */
+size_t ess_norm_workspace(int32_t groups); /* groups = planes (InstanceNorm) or channels (BatchNorm) */
 int ess_instnorm_forward(const float* x, const float* residual, float* y, float* stats, int32_t planes,
-                         int32_t hw, float eps, int32_t relu, ess_stream_t stream);
+                         int32_t hw, float eps, int32_t relu, void* workspace, size_t workspace_bytes,
+                         ess_stream_t stream);
 /* dx from dy (gradient w.r.t. y; the residual branch gradient is dy itself, handled by the caller). */
 int ess_instnorm_backward(const float* x, const float* dy, const float* stats, float* dx, int32_t planes,
-                          int32_t hw, int32_t relu, ess_stream_t stream);
+                          int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 
 /* BatchNorm2d, training mode (ResNet prefix of StyleEncoderE2VID, models/style_networks.py:116-121):
  * batch statistics, running-stat update with momentum (unbiased var), y = act(bn(x) + residual).
  * stats: [C][2] = (mean, rstd).                                                                     */
 int ess_batchnorm_train_forward(const float* x, const float* residual, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* y,
-                                float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, ess_stream_t stream);
+                                float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace,
+                                size_t workspace_bytes, ess_stream_t stream);
 /* dy is the gradient w.r.t. y; `y` is needed for the ReLU mask; d_residual (nullable) receives the
  * masked gradient.  dgamma/dbeta: [C] overwritten or accumulated.                                   */
 int ess_batchnorm_train_backward(const float* x, const float* y, const float* dy, const float* gamma,
                                  const float* stats, float* dx, float* d_residual, float* dgamma, float* dbeta,
                                  int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu,
-                                 ess_stream_t stream);
+                                 void* workspace, size_t workspace_bytes, ess_stream_t stream);
 
 /* y = bilinear_x2(a + b), align_corners=False (UpsampleConvLayer input: e2vid/model/submodules.py:84,
  * skip_sum e2vid/model/unet.py:12-13,176).  b may be NULL.  a: [planes][H][W] -> y: [planes][2H][2W] */

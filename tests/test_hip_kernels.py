@@ -85,6 +85,80 @@ def test_conv_forward(H, case):
     assert relerr(out, ref) < 2e-5
 
 
+def _bf(t):
+    return None if t is None else t.bfloat16().float()
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_bf16(H, case):
+    """bf16 MFMA operands, fp32 accumulate: exact (to accumulation order) against an fp32 conv of bf16-rounded inputs and
+    weights; within bf16 rounding (1e-2 of the output scale) of the fp32 result."""
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, act, affine, res = case
+    if C1 and C0 % 8:
+        pytest.skip('bf16 path needs C0 % 8 == 0 for a concat')
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    d0 = 2 if m0 else 1
+    d1 = 2 if m1 else 1
+    x0 = torch.randn(N, C0, Hv // d0, Wv // d0, generator=g)
+    x1 = torch.randn(N, C1, Hv // d1, Wv // d1, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, k, k, generator=g) / math.sqrt((C0 + C1) * k * k)
+    scale = torch.rand(Cout, generator=g) + 0.5 if affine else None
+    shift = torch.randn(Cout, generator=g) if affine else None
+    r = None
+
+    def ref_of(a0, a1, ww):
+        xin = _up(a0, m0) if a1 is None else torch.cat([_up(a0, m0), _up(a1, m1)], 1)
+        y = F.conv2d(xin, ww, None, s, p)
+        if affine:
+            y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if r is not None:
+            y = y + r
+        return [y, torch.relu(y), torch.sigmoid(y), torch.tanh(y)][act]
+    if res:
+        r = torch.randn(ref_of(x0, x1, w).shape, generator=g)
+    ref_b, ref_f = ref_of(_bf(x0), _bf(x1), _bf(w)), ref_of(x0, x1, w)
+    spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, k, s, p, m0, m1, act=act, compute=H.COMPUTE_BF16)
+    out = torch.full(ref_f.shape, float('nan')).cuda()
+    H.conv_forward(spec, dev(x0), dev(x1), H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(scale), fill=1.0) if affine else None,
+                   H.pack_rows(spec, dev(shift)) if affine else None, dev(r), out=out)
+    assert relerr(out, ref_b) < 2e-5
+    assert relerr(out, ref_f) < 2e-2
+
+
+@pytest.mark.parametrize('hid,Hh,Ww', [(64, 12, 20), (16, 9, 13), (256, 3, 5)])
+def test_conv_lstm_gru_bf16(H, hid, Hh, Ww):
+    g = torch.Generator().manual_seed(hid)
+    sd = {'r.Gates.weight': torch.randn(4 * hid, 2 * hid, 3, 3, generator=g) / math.sqrt(18 * hid),
+          'r.Gates.bias': torch.randn(4 * hid, generator=g) * 0.1}
+    for n in ('update_gate', 'reset_gate', 'out_gate'):
+        sd[f'r.{n}.weight'] = torch.randn(hid, 2 * hid, 3, 3, generator=g) / math.sqrt(18 * hid)
+        sd[f'r.{n}.bias'] = torch.randn(hid, generator=g) * 0.1
+    x, hp, cp = [torch.randn(2, hid, Hh, Ww, generator=g) for _ in range(3)]
+    sdb = {k: (_bf(v) if k.endswith('weight') else v) for k, v in sd.items()}
+    h_ref, c_ref = O.conv_lstm(sdb, 'r', _bf(x), (_bf(hp), cp))
+    spec = H.conv_spec(2, Hh, Ww, hid, hid, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=H.COMPUTE_BF16)
+    h, c = torch.empty(2, hid, Hh, Ww).cuda(), torch.empty(2, hid, Hh, Ww).cuda()
+    H.conv_forward(spec, dev(x), dev(hp), H.pack_weights(spec, dev(sd['r.Gates.weight'])), None,
+                   H.pack_rows(spec, dev(sd['r.Gates.bias'])), aux0=dev(cp), out=h, out2=c)
+    assert relerr(h, h_ref) < 2e-5 and relerr(c, c_ref) < 2e-5
+    # GRU: the candidate conv consumes r*h rounded to bf16 inside the kernel, so emulate that rounding in the reference
+    xs = torch.cat((_bf(x), _bf(hp)), 1)
+    u = torch.sigmoid(F.conv2d(xs, sdb['r.update_gate.weight'], sd['r.update_gate.bias'], padding=1))
+    rr = torch.sigmoid(F.conv2d(xs, sdb['r.reset_gate.weight'], sd['r.reset_gate.bias'], padding=1))
+    o = torch.tanh(F.conv2d(torch.cat((_bf(x), _bf(hp * rr)), 1), sdb['r.out_gate.weight'], sd['r.out_gate.bias'], padding=1))
+    ref = hp * (1 - u) + o * u
+    s1 = H.conv_spec(2, Hh, Ww, hid, hid, 2 * hid, 3, 1, 1, epi=H.EPI_GRU_UR, hidden=hid, compute=H.COMPUTE_BF16)
+    s2 = H.conv_spec(2, Hh, Ww, hid, hid, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, hidden=hid, compute=H.COMPUTE_BF16)
+    xd, hd = dev(x), dev(hp)
+    ud, rh = torch.empty_like(hd), torch.empty_like(hd)
+    H.conv_forward(s1, xd, hd, H.pack_weights(s1, dev(sd['r.update_gate.weight']), dev(sd['r.reset_gate.weight'])), None,
+                   H.pack_rows(s1, dev(sd['r.update_gate.bias']), dev(sd['r.reset_gate.bias'])), aux0=hd, out=ud, out2=rh)
+    hn = torch.empty_like(hd)
+    H.conv_forward(s2, xd, rh, H.pack_weights(s2, dev(sd['r.out_gate.weight'])), None,
+                   H.pack_rows(s2, dev(sd['r.out_gate.bias'])), aux0=hd, aux1=ud, out=hn)
+    assert relerr(hn, ref) < 1e-3
+
+
 def test_conv_transposed_forward(H):
     # TransposedConvLayer: ConvTranspose2d k5 s2 p2 output_padding 1 (e2vid/model/submodules.py:34-62)
     g = torch.Generator().manual_seed(3)
@@ -175,8 +249,51 @@ def test_conv_backward(H, case):
         assert relerr(o, r) < 5e-5, name
 
 
+@pytest.mark.parametrize('case', GRAD_CASES + [(2, 64, 0, 64, 48, 80, 3, 1, 1, 0, True), (1, 128, 128, 128, 25, 44, 3, 1, 1, 0, True)])
+def test_conv_backward_bf16(H, case):
+    """bf16 contraction arithmetic in dgrad and (3x3/s1) wgrad: tight against fp32 math on bf16-rounded operands,
+    within bf16 rounding of the fp32 gradients."""
+    from ess_amd import functional as Fn
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, has_b = case
+    if C1 and C0 % 8:
+        pytest.skip('bf16 path needs C0 % 8 == 0 for a concat')
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    d0 = 2 if m0 else 1
+    x0 = torch.randn(N, C0, Hv // d0, Wv // d0, generator=g)
+    x1 = torch.randn(N, C1, Hv, Wv, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, k, k, generator=g) / math.sqrt((C0 + C1) * k * k)
+    b = torch.randn(Cout, generator=g) if has_b else None
+
+    def grads(rx0, rx1, rw, rgy_w, rgy_x):
+        a0, a1, aw = rx0.clone().requires_grad_(True), None if rx1 is None else rx1.clone().requires_grad_(True), rw.clone().requires_grad_(True)
+        xin = _up(a0, m0) if a1 is None else torch.cat([_up(a0, m0), a1], 1)
+        y = F.conv2d(xin, aw, None, s, p)
+        gw, = torch.autograd.grad(y, aw, rgy_w, retain_graph=True)
+        gx = torch.autograd.grad(y, [t for t in (a0, a1) if t is not None], rgy_x)
+        return gw, gx
+    y_shape = F.conv2d(_up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), x1], 1), w, None, s, p).shape
+    gy = torch.randn(y_shape, generator=g)
+    wgrad_bf16 = (k == 3 and s == 1)
+    gw_b, gx_b = grads(_bf(x0) if wgrad_bf16 else x0, (_bf(x1) if wgrad_bf16 else x1), _bf(w), _bf(gy) if wgrad_bf16 else gy, _bf(gy))
+    gw_f, gx_f = grads(x0, x1, w, gy, gy)
+    H.set_compute('bf16')
+    try:
+        a0, a1, aw, ab = [None if t is None else t.detach().cuda().requires_grad_(True) for t in (x0, x1, w, b)]
+        yd = Fn.conv2d(a0, aw, ab, s, p, x1=a1, mode0=m0)
+        outs = torch.autograd.grad(yd, [t for t in (a0, a1, aw) if t is not None], gy.cuda())
+    finally:
+        H.set_compute('fp32')
+    gx_d, gw_d = outs[:-1], outs[-1]
+    # the emulation of wgrad rounds x at the *virtual* resolution; nearest-upsampled sources round identically
+    assert relerr(gw_d, gw_b) < 1e-4, relerr(gw_d, gw_b)
+    assert relerr(gw_d, gw_f) < 2e-2
+    for o, rb, rf in zip(gx_d, gx_b, gx_f):
+        assert relerr(o, rb) < 1e-4 and relerr(o, rf) < 2e-2
+
+
 @pytest.mark.parametrize('shape,relu,res', [((2, 64, 12, 20), True, False), ((2, 256, 3, 5), False, True),
-                                            ((1, 7, 9, 13), True, True), ((2, 32, 48, 80), True, False)])
+                                            ((1, 7, 9, 13), True, True), ((2, 32, 48, 80), True, False),
+                                            ((1, 6, 160, 130), True, True), ((2, 3, 144, 128), False, False)])
 def test_instance_norm(H, shape, relu, res):
     from ess_amd import functional as Fn
     g = torch.Generator().manual_seed(5)
@@ -199,7 +316,7 @@ def test_instance_norm(H, shape, relu, res):
 
 
 @pytest.mark.parametrize('shape,relu,res', [((2, 64, 12, 20), True, False), ((3, 128, 6, 10), True, True),
-                                            ((2, 5, 7, 9), False, False)])
+                                            ((2, 5, 7, 9), False, False), ((2, 16, 120, 160), True, True)])
 def test_batch_norm_train(H, shape, relu, res):
     from ess_amd import functional as Fn
     g = torch.Generator().manual_seed(6)

@@ -35,7 +35,9 @@ def test_conv_plan_and_validation_on_host(built_lib):
     sp = hip.conv_spec(8, 240, 320, 64, 64, 256, 3, 1, 1, epi=hip.EPI_LSTM, hidden=64)
     assert (sp.H_out, sp.W_out) == (240, 320)
     assert sp.plan.cout_tile == 64 and sp.plan.ck == 8 and sp.plan.n_chunks == 16 and sp.plan.n_cout_tiles == 4
-    assert sp.plan.packed_elems == 256 * 128 * 9 and sp.plan.lds_bytes <= 64 * 1024
+    assert sp.plan.packed_elems == 256 * 128 * 9 and sp.plan.packed_bytes == 4 * sp.plan.packed_elems and sp.plan.lds_bytes <= 64 * 1024
+    sb = hip.conv_spec(8, 240, 320, 64, 64, 256, 3, 1, 1, epi=hip.EPI_LSTM, hidden=64, compute=hip.COMPUTE_BF16)
+    assert sb.plan.ck == 16 and sb.plan.packed_bytes == 2 * sb.plan.packed_elems and sb.plan.lds_bytes <= 64 * 1024
     head = hip.conv_spec(2, 200, 352, 2, 0, 32, 5, 1, 2, act=hip.ACT_RELU)
     assert head.plan.ck == 2 and head.plan.cout_tile == 32
     small = hip.conv_spec(1, 24, 40, 32, 0, 11, 1, 1, 0)  # 11 classes padded to a 32-row tile
