@@ -38,6 +38,17 @@ static inline void ess_allow_lds(K kernel, size_t bytes) {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with a
+// private 4 MiB L2).  Remap so that every XCD walks one CONTIGUOUS range of logical ids: workgroups that share an
+// operand (all channel tiles of one input tile, all channel-tile pairs of one pixel split) then run on the same XCD at
+// about the same time and the operand is fetched into that L2 once.  Bijective for any total; a pure speed choice.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  constexpr int NX = 8;
+  const int q = total / NX, r = total % NX;
+  const int xcd = b % NX, i = b / NX;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 __device__ __forceinline__ float ess_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // wave64 all-lanes sum (butterfly through DPP/shuffles)

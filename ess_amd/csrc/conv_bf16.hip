@@ -24,25 +24,33 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
   return __builtin_bit_cast(u32x4, b);
 }
 
-// pixel vectors a thread stages per chunk (compile-time bound of the register prefetch), by filter geometry
-constexpr int maxv(int ks, int s) {
-  return s == 1 ? (ks == 1 ? 4 : ks == 3 ? 3 : ks == 5 ? 4 : 5) : (ks == 1 ? 8 : ks == 3 ? 9 : ks == 5 ? 10 : 12);
+// pixel positions a thread stages per 8-channel block (compile-time bound of the register prefetch), by filter geometry
+constexpr int kpc(int ks, int s) {
+  return s == 1 ? (ks == 1 ? 1 : ks == 3 ? 2 : ks == 5 ? 2 : 3) : (ks == 1 ? 4 : ks == 3 ? 5 : ks == 5 ? 5 : 6);
 }
+constexpr unsigned OOB = 0x80000000u;  // beyond any buffer: the bounds-checked load returns 0
 
-template <int KS, int S, int MB, int EPI>
+template <int KS, int S, int MB, int EPI, int CB8>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int COT = MB * 32;
+  constexpr int CK = CB8 * 8;
+  constexpr int KPC = kpc(KS, S);
+  constexpr int WSZ = KS * KS * CB8 * COT;  // weight slab of one chunk, 16-byte units
+  constexpr int WV = (WSZ + 255) / 256;
+  constexpr bool WPRE = WV <= 5;           // small slabs ride in registers across the MFMA phase as well
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
-  const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+  // logical order: channel tile fastest, then spatial tile, then sample (see xcd_remap)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = logical % a.n_cout_tiles;
+  const int sp = logical / a.n_cout_tiles;
+  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int ct = blockIdx.y, n = blockIdx.z;
-  const int CB8 = a.ck >> 3;
   u32x4* in_t = smem16;
   u32x4* w_t = smem16 + CB8 * a.plane;
-  const int wsz = KS * KS * CB8 * COT;  // 16-byte units
 
   const int ox = p & (BW - 1), oy = p >> a.bwl;
   const int wx = wave & (WX - 1), wy = wave >> a.wxl;
@@ -62,69 +70,94 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-  constexpr int MAXV = maxv(KS, S);
+  // ---- staging plan.  The input tile of a chunk is CB8 blocks of IH*IW "pixel vectors" (8 channels of one position,
+  // 16 B of bf16).  Thread t owns positions t, t+256, ... of EVERY block (lanes run along x: each of the 8 per-channel
+  // loads of a vector is a coalesced row segment).  Loads go through bounds-checked buffer descriptors, one per
+  // source and sample: everything that must read as zero (conv padding, zero-insert holes, channels past the end of a
+  // source, positions past the tile) is given an out-of-range offset, so the loads carry NO branch and NO select --
+  // a load under a per-lane condition makes hipcc wait vmcnt(0) inside every branch (one serialized memory round
+  // trip per element), which was the whole cost of the first version of this kernel.
   const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
-  // The input tile is a list of CB8*IH*IW pixel vectors; thread t stages vectors t, t+256, ... (lanes run along x, so
-  // each of the 8 per-channel loads of a vector is a coalesced row segment).  Everything that does not depend on the
-  // chunk index is resolved once: LDS slot, channel block, and the element offset inside a channel plane of either
-  // source (-1: outside the image / a zero of the zero-insert mode).
-  const int nvec = CB8 * a.IH * a.IW;
   const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
   const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
-  const size_t pl0 = (size_t)(a.Hin >> sh0) * Wp0, pl1 = (size_t)(a.Hin >> sh1) * Wp1;
-  const float* s0 = a.src0 + (size_t)n * a.C0 * pl0;
-  const float* s1 = a.C1 ? a.src1 + (size_t)n * a.C1 * pl1 : nullptr;
-  int v_lds[MAXV], v_cb[MAXV], v_o0[MAXV], v_o1[MAXV];
+  const unsigned pl0 = (unsigned)((a.Hin >> sh0) * Wp0) * 4u, pl1 = (unsigned)((a.Hin >> sh1) * Wp1) * 4u;  // plane bytes
+  const __amdgpu_buffer_rsrc_t r0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * a.C0 * (pl0 / 4)), 0, a.C0 * pl0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.C1 ? a.src1 + (size_t)n * a.C1 * (pl1 / 4) : a.src0), 0, a.C1 * pl1, 0x00020000);
+  unsigned v_o0[KPC], v_o1[KPC];
+  int v_lds[KPC];
+  const int npos = a.IH * a.IW;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int vi = tid + i * 256;
-    const int cb = vi / (a.IH * a.IW);
-    const int r = vi - cb * a.IH * a.IW;
-    const int iy = r / a.IW, ix = r - iy * a.IW;
+  for (int k = 0; k < KPC; ++k) {
+    const int vi = tid + k * 256;
+    const int iy = vi / a.IW, ix = vi - iy * a.IW;
     const int gy = iy0 + iy, gx = ix0 + ix;
-    const bool in = vi < nvec && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    const bool in = vi < npos && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
     const bool odd = ((gy | gx) & 1) != 0;
-    v_cb[i] = cb;
-    v_lds[i] = vi < nvec ? cb * a.plane + iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix) : -1;
-    v_o0[i] = (in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd)) ? (gy >> sh0) * Wp0 + (gx >> sh0) : -1;
-    v_o1[i] = (in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd)) ? (gy >> sh1) * Wp1 + (gx >> sh1) : -1;
+    v_lds[k] = vi < npos ? iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix) : -1;
+    v_o0[k] = (in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0)) * 4u : OOB;
+    v_o1[k] = (in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh1) * Wp1 + (gx >> sh1)) * 4u : OOB;
   }
-  // 8 consecutive channels of one position -> bf16x8 (a vector never straddles the two sources: C0 % 8 == 0)
-  auto load_vec = [&](int ch, int i) -> u32x4 {
-    const int c0 = ch * a.ck + v_cb[i] * 8;
-    const bool first = c0 < a.C0;
-    const int off = first ? v_o0[i] : v_o1[i];
-    const size_t pls = first ? pl0 : pl1;
-    const int cc = first ? c0 : c0 - a.C0;
-    const int lim = (first ? a.C0 : a.C1) - cc;  // channels left in this source
-    const float* sp = (first ? s0 : s1) + (size_t)cc * pls + off;
-    float v[8];
+  // 8 consecutive channels (block cb of chunk ch) at staged position k -> bf16x8
+  struct Raw8 { float v[8]; };
+  auto load_vec = [&](int ch, int cb, int k) -> Raw8 {
+    const int c0 = ch * CK + cb * 8;                  // wave-uniform
+    const bool first = c0 < a.C0 || a.C1 == 0;        // a block never straddles the sources (C0 % 8 == 0)
+    const unsigned pls = first ? pl0 : pl1;
+    const unsigned cbase = (unsigned)(first ? c0 : c0 - a.C0) * pls;
+    const unsigned off = (first ? v_o0[k] : v_o1[k]) + cbase;
+    Raw8 r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (off >= 0 && j < lim) ? sp[(size_t)j * pls] : 0.f;
-    return pack8(v);
+    for (int j = 0; j < 8; ++j)
+      r.v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
+    return r;
   };
 
-  u32x4 pre[MAXV];
-  const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * wsz;
+  // raw fp32 values stay in registers across the MFMA phase; the bf16 conversion happens at the LDS write so that
+  // nothing waits on these loads before the matrix work has been issued
+  Raw8 pre[CB8][KPC];
+  u32x4 wpre[WPRE ? WV : 1];
+  const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i)
-    if (v_lds[i] >= 0) pre[i] = load_vec(0, i);
+  for (int cb = 0; cb < CB8; ++cb)
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) pre[cb][k] = load_vec(0, cb, k);
+  if constexpr (WPRE) {
+#pragma unroll
+    for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wbase[i < WSZ ? i : 0]; }
+  }
 
   for (int ch = 0; ch < a.n_chunks; ++ch) {
     __syncthreads();  // previous chunk's fragments have been read
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if (v_lds[i] >= 0) in_t[v_lds[i]] = pre[i];
-    {
-      const u32x4* wsrc = wbase + (size_t)ch * wsz;
-      for (int i = tid; i < wsz; i += 256) w_t[i] = wsrc[i];
+    for (int cb = 0; cb < CB8; ++cb)
+#pragma unroll
+      for (int k = 0; k < KPC; ++k)
+        if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = pack8(pre[cb][k].v);
+    if constexpr (WPRE) {
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+    } else {
+      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+      u32x4 wv[WV];
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wv[it] = wsrc[i < WSZ ? i : 0]; }
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wv[it]; }
     }
     __syncthreads();
-    // prefetch the next chunk's activations; they land while the matrix cores work on this one
+    // prefetch the next chunk; the loads land while the matrix cores work on this one
     if (ch + 1 < a.n_chunks) {
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i)
-        if (v_lds[i] >= 0) pre[i] = load_vec(ch + 1, i);
+      for (int cb = 0; cb < CB8; ++cb)
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) pre[cb][k] = load_vec(ch + 1, cb, k);
+      if constexpr (WPRE) {
+        const u32x4* wsrc = wbase + (size_t)(ch + 1) * WSZ;
+#pragma unroll
+        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+      }
     }
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
@@ -134,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
         const int toff = ky * a.row_pitch + (S == 2 ? (kx & 1) * a.par_off + (kx >> 1) : kx);
         const u32x4* wp = w_t + (tap * CB8 + half) * COT + p;
         const u32x4* ip = in_t + toff;
+#pragma unroll
         for (int kk = 0; kk < CB8; kk += 2) {
           bf16x8 af[MB], bfr[NBW];
 #pragma unroll
@@ -177,23 +211,30 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
   out[i] = (__bf16)v;
 }
 
-template <int KS, int S, int MB>
+template <int KS, int S, int MB, int CB8>
 void launch_epi(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
   if constexpr (KS == 3 && S == 1) {
     switch (epi) {
-      case ESS_EPI_LSTM: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LSTM>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LSTM>), grid, dim3(256), lds, st, a); } return;
-      case ESS_EPI_GRU_UR: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_UR>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_UR>), grid, dim3(256), lds, st, a); } return;
-      case ESS_EPI_GRU_OUT: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_OUT>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_OUT>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_LSTM: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LSTM, CB8>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LSTM, CB8>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_GRU_UR: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_UR, CB8>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_UR, CB8>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_GRU_OUT: { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_OUT, CB8>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_GRU_OUT, CB8>), grid, dim3(256), lds, st, a); } return;
       default: break;
     }
   }
-  { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR>), grid, dim3(256), lds, st, a); }
+  { ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8>, lds); hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8>), grid, dim3(256), lds, st, a); }
 }
 
 template <int KS, int S>
-void launch_mb(int mb, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
-  if (mb == 2) launch_epi<KS, S, 2>(epi, grid, lds, st, a);
-  else launch_epi<KS, S, 1>(epi, grid, lds, st, a);
+void launch_mb(int mb, int cb8, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if constexpr (KS == 1 && S == 1) {
+    if (cb8 == 4) {
+      if (mb == 2) launch_epi<KS, S, 2, 4>(epi, grid, lds, st, a);
+      else launch_epi<KS, S, 1, 4>(epi, grid, lds, st, a);
+      return;
+    }
+  }
+  if (mb == 2) launch_epi<KS, S, 2, 2>(epi, grid, lds, st, a);
+  else launch_epi<KS, S, 1, 2>(epi, grid, lds, st, a);
 }
 
 }  // namespace
@@ -209,22 +250,23 @@ int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_ki
 }
 
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st) {
-  const int nvec = (pl.ck / 8) * g.IH * g.IW;
-  ESS_CHECK_ARG(nvec <= maxv(d->ksize, d->stride) * 256, "conv(bf16): input tile of %d pixel vectors exceeds the staging capacity",
-                nvec);
+  ESS_CHECK_ARG(g.IH * g.IW <= kpc(d->ksize, d->stride) * 256, "conv(bf16): input tile of %d positions exceeds the staging capacity",
+                g.IH * g.IW);
+  ESS_CHECK_ARG((int64_t)(d->C0 > d->C1 ? d->C0 : d->C1) * d->H_in * d->W_in * 4 < (int64_t)1 << 31,
+                "conv(bf16): one sample of a source must stay below 2 GiB (32-bit buffer offsets)");
   ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "conv(bf16): the first source of a concat must have a multiple of 8 channels");
-  const dim3 grid(g.tiles_x * g.tiles_y, pl.n_cout_tiles, d->N);
+  const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const int key = d->ksize * 10 + d->stride;
   switch (key) {
-    case 11: launch_mb<1, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 12: launch_mb<1, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 31: launch_mb<3, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 32: launch_mb<3, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 51: launch_mb<5, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 52: launch_mb<5, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 71: launch_mb<7, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 72: launch_mb<7, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 11: launch_mb<1, 1>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 12: launch_mb<1, 2>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 31: launch_mb<3, 1>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 32: launch_mb<3, 2>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 51: launch_mb<5, 1>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 52: launch_mb<5, 2>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 71: launch_mb<7, 1>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 72: launch_mb<7, 2>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;
     default: ess_set_error("conv: no kernel for k%d s%d", d->ksize, d->stride); return ESS_ENOTSUP;
   }
   return ess_launch_status("conv2d_forward(bf16)");

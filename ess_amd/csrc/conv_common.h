@@ -20,7 +20,7 @@ struct ConvKArgs {
   float* out2;
   int N, Hin, Win, C0, C1, mode0, mode1;
   int Cout, Hout, Wout, pad;
-  int bwl, wxl, tiles_x;
+  int bwl, wxl, tiles_x, n_tiles, n_cout_tiles;
   int IH, IW, row_pitch, par_off, plane;
   int ck, n_chunks;
   int act, hid, out_split;

@@ -25,9 +25,13 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
-  const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+  // logical order: channel tile fastest, then spatial tile, then sample (see xcd_remap)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = logical % a.n_cout_tiles;
+  const int sp = logical / a.n_cout_tiles;
+  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int ct = blockIdx.y, n = blockIdx.z;
   const int CB = a.ck;
   float* in_t = smem;
   float* w_t = smem + CB * a.plane;
@@ -69,17 +73,24 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
       const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
       const float* pl = sp + ((size_t)n * Cs + cc) * Hp * Wp;
       float* dst = in_t + cb * a.plane;
+      if (!cvalid) {  // zero padding channels of the last chunk (block-uniform branch)
+        for (int iy = wave; iy < a.IH; iy += 4)
+          for (int ix = lane; ix < a.IW; ix += 64)
+            dst[iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix)] = 0.f;
+        continue;
+      }
       for (int iy = wave; iy < a.IH; iy += 4) {
         const int gy = iy0 + iy;
         bool yok = cvalid && gy >= 0 && gy < a.Hin;
         if (mode == ESS_SRC_ZERO_UP2) yok = yok && !(gy & 1);
-        const float* row = pl + (size_t)(gy >> sh) * Wp;
+        const float* row = pl + (size_t)(min(max(gy, 0), a.Hin - 1) >> sh) * Wp;
         for (int ix = lane; ix < a.IW; ix += 64) {
           const int gx = ix0 + ix;
           bool ok = yok && gx >= 0 && gx < a.Win;
           if (mode == ESS_SRC_ZERO_UP2) ok = ok && !(gx & 1);
-          float v = 0.f;
-          if (ok) v = row[gx >> sh];
+          // unconditional load from a clamped address + select: no per-element branch, loads stay batched
+          const float t = row[min(max(gx, 0), a.Win - 1) >> sh];
+          const float v = ok ? t : 0.f;
           const int li = iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix);
           dst[li] = v;
         }
@@ -200,12 +211,12 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const
   a.aux0 = aux0; a.aux1 = aux1; a.out = out; a.out2 = out2;
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
-  a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x;
+  a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;
   a.IH = g.IH; a.IW = g.IW; a.row_pitch = g.row_pitch; a.par_off = g.par_off; a.plane = g.plane;
   a.ck = pl.ck; a.n_chunks = pl.n_chunks; a.act = d->act; a.hid = d->hidden; a.out_split = d->out_split;
   hipStream_t st = (hipStream_t)stream;
   if (is_bf16(d)) return conv_bf16_launch(d, pl, g, a, st);
-  const dim3 grid(g.tiles_x * g.tiles_y, pl.n_cout_tiles, d->N);
+  const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const int key = d->ksize * 10 + d->stride;
   switch (key) {

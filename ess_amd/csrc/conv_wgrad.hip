@@ -21,20 +21,51 @@ struct WgradArgs {
   int twl;        // pixel tile = (64>>twl) rows x (1<<twl) cols
   int tiles_x, tiles_y, ntiles;
   int IH, IW, plx;  // X tile rows/cols, per-channel pitch (odd)
-  int ci_tiles;
+  int ci_tiles, npairs, nsplit;
 };
 
+// Value of the (virtually upsampled, concatenated) conv input at channel c (< C0+C1), position (gy, gx).  Branch-free in
+// the per-lane quantities: the load is unconditional from a clamped address and the result selected afterwards (a load
+// under a per-lane branch costs one serialized memory round trip per element, see conv_bf16.hip).
 __device__ __forceinline__ float load_virtual(const WgradArgs& a, int n, int c, int gy, int gx) {
-  // value of the (virtually upsampled, concatenated) conv input at channel c, position (gy, gx)
-  if (gy < 0 || gy >= a.Hin || gx < 0 || gx >= a.Win) return 0.f;
   const bool first = c < a.C0;
   const int mode = first ? a.mode0 : a.mode1;
-  if (mode == ESS_SRC_ZERO_UP2 && ((gy | gx) & 1)) return 0.f;
   const int sh = mode != ESS_SRC_DIRECT ? 1 : 0;
   const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
   const float* sp = first ? a.src0 : a.src1;
   const int cc = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
-  return sp[(((size_t)n * Cs + cc) * Hp + (gy >> sh)) * Wp + (gx >> sh)];
+  const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win && !(mode == ESS_SRC_ZERO_UP2 && ((gy | gx) & 1));
+  const int cy = min(max(gy, 0), a.Hin - 1) >> sh, cx = min(max(gx, 0), a.Win - 1) >> sh;
+  const float t = sp[(((size_t)n * Cs + cc) * Hp + cy) * Wp + cx];
+  return ok ? t : 0.f;
+}
+
+// 8 consecutive virtual pixels gx..gx+7 (gx % 8 == 0) of one row, as floats; vector loads when the row is 16-byte
+// friendly, clamped scalar loads otherwise.  `valid` masks the whole vector (channel / row out of range).
+__device__ __forceinline__ void load8_virtual(const WgradArgs& a, int n, int c, int gy, int gx, bool valid, float (&f)[8]) {
+  const bool first = c < a.C0;
+  const int mode = first ? a.mode0 : a.mode1;
+  const float* sp = first ? a.src0 : a.src1;
+  const int cc = first ? c : c - a.C0, Cs = first ? a.C0 : a.C1;
+  const bool rowok = valid && gy >= 0 && gy < a.Hin;
+  const int cy = min(max(gy, 0), a.Hin - 1);
+  if (mode == ESS_SRC_DIRECT && (a.Win & 7) == 0) {  // uniform per (tile, channel): a vector is fully in or fully out
+    const bool ok = rowok && gx >= 0 && gx < a.Win;
+    const float* src = sp + (((size_t)n * Cs + cc) * a.Hin + cy) * a.Win + min(max(gx, 0), a.Win - 8);
+    const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = ok ? lo[j] : 0.f; f[4 + j] = ok ? hi[j] : 0.f; }
+  } else if (mode == ESS_SRC_NEAREST_UP2 && (a.Win & 7) == 0) {  // 8 virtual pixels = 4 stored pixels, each used twice
+    const int Wp = a.Win >> 1;
+    const bool ok = rowok && gx >= 0 && gx < a.Win;
+    const float* src = sp + (((size_t)n * Cs + cc) * (a.Hin >> 1) + (cy >> 1)) * Wp + (min(max(gx, 0), a.Win - 8) >> 1);
+    const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = ok ? v[j] : 0.f; f[2 * j + 1] = f[2 * j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = load_virtual(a, n, c, gy, gx + j); f[j] = valid ? t : 0.f; }
+  }
 }
 
 template <int KS, int S>
@@ -43,8 +74,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   constexpr int T = KS * KS;
   constexpr int PY = 65;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
-  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x - cot * a.ci_tiles;
-  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);  // channel-tile pair fastest, pixel split slowest
+  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
+  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
   const int cb = wave >> 1, ib = wave & 1;
   const int TWp = 1 << a.twl, THp = 64 >> a.twl;
   const int Cin = a.C0 + a.C1;
@@ -72,9 +104,9 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
       for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
         const int co = r / THp, qy = r - co * THp;  // THp is a power of two
         const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
-        float v = 0.f;
-        if (cg < a.Cout && y < a.Hout && x < a.Wout) v = a.dy[((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x];
-        dy_t[co * PY + qy * TWp + qx] = v;
+        const bool ok = cg < a.Cout && y < a.Hout && x < a.Wout;
+        const float t = a.dy[((size_t)n * a.Cout + min(cg, a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout + min(x, a.Wout - 1)];
+        dy_t[co * PY + qy * TWp + qx] = ok ? t : 0.f;
       }
     }
     // ---- X tile: 64 channels x IH x IW (halo included), lanes along x
@@ -84,8 +116,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
         const int ci = r / a.IH, iy = r - ci * a.IH;
         const int cg = cit * 64 + ci;
         float* dst = x_t + ci * a.plx + iy * a.IW;
-        for (int ix = lane; ix < a.IW; ix += 64)
-          dst[ix] = cg < Cin ? load_virtual(a, n, cg, iy0 + iy, ix0 + ix) : 0.f;
+        const bool cok = cg < Cin;
+        const int cgc = min(cg, Cin - 1);
+        for (int ix = lane; ix < a.IW; ix += 64) {
+          const float t = load_virtual(a, n, cgc, iy0 + iy, ix0 + ix);
+          dst[ix] = cok ? t : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -129,8 +165,8 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
   constexpr int PY = 65;
   static_assert(T <= 64, "taps must fit two MFMA column blocks");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
-  const int cot = blockIdx.x;
-  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int cot = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
   const int cb = wave >> 1, tb = wave & 1;
   const int TWp = 1 << a.twl, THp = 64 >> a.twl;
   float* dy_t = smem;
@@ -155,9 +191,9 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
       for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
         const int co = r / THp, qy = r - co * THp;
         const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
-        float v = 0.f;
-        if (cg < a.Cout && y < a.Hout && x < a.Wout) v = a.dy[((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x];
-        dy_t[co * PY + qy * TWp + qx] = v;
+        const bool ok = cg < a.Cout && y < a.Hout && x < a.Wout;
+        const float t = a.dy[((size_t)n * a.Cout + min(cg, a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout + min(x, a.Wout - 1)];
+        dy_t[co * PY + qy * TWp + qx] = ok ? t : 0.f;
       }
       const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
       for (int iy = wave; iy < a.IH; iy += 4)
@@ -229,8 +265,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
   extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
   const WgradArgs& a = b.w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
-  const int cot = blockIdx.x / a.ci_tiles, cit = blockIdx.x - cot * a.ci_tiles;
-  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
+  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
   const int cb = wave >> 1, ib = wave & 1;
   const int TWp = 1 << a.twl, THp = 128 >> a.twl;
   const int TV = TWp >> 3;  // vectors per dY row
@@ -253,24 +290,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
     const int y0 = ty * THp, x0 = tx * TWp;
     __syncthreads();
-    // ---- dY tile: 64 channels x THp rows x TV vectors
+    // ---- dY tile: 64 channels x THp rows x TV vectors (branch-free: clamped address + select)
     for (int v = tid; v < 64 * THp * TV; v += 256) {
       const int xv = v % TV, r = v / TV;
       const int qy = r % THp, co = r / THp;
       const int cg = cot * 64 + co, y = y0 + qy, x = x0 + xv * 8;
+      const bool rok = cg < a.Cout && y < a.Hout;
+      const float* rowp = a.dy + ((size_t)n * a.Cout + min(cg, a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout;
       float f[8];
+      if ((a.Wout & 7) == 0) {  // uniform: a vector is fully inside or fully outside the row
+        const bool ok = rok && x < a.Wout;
+        const float* src = rowp + min(x, a.Wout - 8);
+        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      if (cg < a.Cout && y < a.Hout) {
-        const float* src = a.dy + ((size_t)n * a.Cout + cg) * HWo + (size_t)y * a.Wout + x;
-        if (x + 8 <= a.Wout && (a.Wout & 3) == 0) {
-          const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+        for (int j = 0; j < 4; ++j) { f[j] = ok ? lo[j] : 0.f; f[4 + j] = ok ? hi[j] : 0.f; }
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) if (x + j < a.Wout) f[j] = src[j];
-        }
+        for (int j = 0; j < 8; ++j) { const float t = rowp[min(x + j, a.Wout - 1)]; f[j] = (rok && x + j < a.Wout) ? t : 0.f; }
       }
       dy_t[co * b.pyv + qy * TV + xv] = cvt8(f);
     }
@@ -278,25 +314,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
     for (int v = tid; v < 64 * IH * b.rv; v += 256) {
       const int xv = v % b.rv, r = v / b.rv;
       const int iy = r % IH, ci = r / IH;
-      const int cg = cit * 64 + ci, gy = y0 - a.pad + iy, gx = x0 - 8 + xv * 8;
+      const int cg = cit * 64 + ci;
       float f[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      if (cg < Cin && gy >= 0 && gy < a.Hin) {
-        const bool first = cg < a.C0;
-        const int mode = first ? a.mode0 : a.mode1;
-        if (mode == ESS_SRC_DIRECT && gx >= 0 && gx + 8 <= a.Win && (a.Win & 3) == 0) {
-          const float* sp = first ? a.src0 : a.src1;
-          const int cc = first ? cg : cg - a.C0, Cs = first ? a.C0 : a.C1;
-          const float* src = sp + (((size_t)n * Cs + cc) * a.Hin + gy) * a.Win + gx;
-          const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { f[j] = lo[j]; f[4 + j] = hi[j]; }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = load_virtual(a, n, cg, gy, gx + j);
-        }
-      }
+      load8_virtual(a, n, min(cg, Cin - 1), y0 - a.pad + iy, x0 - 8 + xv * 8, cg < Cin, f);
       x_t[ci * b.pxv + iy * b.rv + xv] = cvt8(f);
     }
     __syncthreads();
@@ -447,9 +467,9 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.twl = w.twl; a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
-  a.IH = w.IH; a.IW = w.IW; a.plx = w.plx; a.ci_tiles = w.ci_tiles;
+  a.IH = w.IH; a.IW = w.IW; a.plx = w.plx; a.ci_tiles = w.ci_tiles; a.npairs = w.co_tiles * w.ci_tiles; a.nsplit = w.nsplit;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(w.co_tiles * w.ci_tiles, w.nsplit);
+  const dim3 grid((unsigned)(w.co_tiles * w.ci_tiles * w.nsplit));
 #define ESS_WG(KS_, S_)                                                                               \
   do {                                                                                                \
     if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
