@@ -228,9 +228,45 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
 // left / right) are produced from two neighbouring vectors with v_alignbyte (4 VALU per fragment) instead of keeping
 // three shifted copies in LDS.  Per-channel pitches are odd multiples of 16 B: lanes run over channels, so the
 // ds_read_b128 groups hit 16 distinct slots.
+constexpr unsigned OOBW = 0x80000000u;  // beyond any buffer: bounds-checked loads return 0
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 
+// 16-byte bounds-checked buffer loads.  hipcc (ROCm 7.2) mis-lowers __builtin_amdgcn_raw_buffer_load_b64/_b128 to a
+// single buffer_load_dword, so the wide form is inline asm.  A whole batch is ONE statement -- loads and their
+// s_waitcnt together, early-clobber outputs (cdna_hip_programming.md 5.7 form i) -- so the compiler never sees a
+// destination register that is "written" but still in flight (it may otherwise copy it before the data lands).
+// `s_nop 4` covers the SGPR-write -> VMEM-read hazard on the freshly built descriptors.
+__device__ __forceinline__ void ldb128x8(u32x4w (&d)[8], __amdgpu_buffer_rsrc_t r, const unsigned (&o)[8]) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %8, %16, 0 offen\n\tbuffer_load_dwordx4 %1, %9, %16, 0 offen\n\t"
+      "buffer_load_dwordx4 %2, %10, %16, 0 offen\n\tbuffer_load_dwordx4 %3, %11, %16, 0 offen\n\t"
+      "buffer_load_dwordx4 %4, %12, %16, 0 offen\n\tbuffer_load_dwordx4 %5, %13, %16, 0 offen\n\t"
+      "buffer_load_dwordx4 %6, %14, %16, 0 offen\n\tbuffer_load_dwordx4 %7, %15, %16, 0 offen\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+      : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "s"(r)
+      : "memory");
+}
+// 6 loads against descriptor ra followed by 6 against rb
+__device__ __forceinline__ void ldb128x12(u32x4w (&d)[12], __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                          const unsigned (&o)[12]) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "buffer_load_dwordx4 %0, %12, %24, 0 offen\n\tbuffer_load_dwordx4 %1, %13, %24, 0 offen\n\t"
+      "buffer_load_dwordx4 %2, %14, %24, 0 offen\n\tbuffer_load_dwordx4 %3, %15, %24, 0 offen\n\t"
+      "buffer_load_dwordx4 %4, %16, %24, 0 offen\n\tbuffer_load_dwordx4 %5, %17, %24, 0 offen\n\t"
+      "buffer_load_dwordx4 %6, %18, %25, 0 offen\n\tbuffer_load_dwordx4 %7, %19, %25, 0 offen\n\t"
+      "buffer_load_dwordx4 %8, %20, %25, 0 offen\n\tbuffer_load_dwordx4 %9, %21, %25, 0 offen\n\t"
+      "buffer_load_dwordx4 %10, %22, %25, 0 offen\n\tbuffer_load_dwordx4 %11, %23, %25, 0 offen\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),
+        "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+      : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "v"(o[8]), "v"(o[9]),
+        "v"(o[10]), "v"(o[11]), "s"(ra), "s"(rb)
+      : "memory");
+}
 __device__ __forceinline__ u32x4w cvt8(const float (&v)[8]) {
   bf16x8w b;
 #pragma unroll
@@ -290,34 +326,105 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
     const int y0 = ty * THp, x0 = tx * TWp;
     __syncthreads();
-    // ---- dY tile: 64 channels x THp rows x TV vectors (branch-free: clamped address + select)
-    for (int v = tid; v < 64 * THp * TV; v += 256) {
-      const int xv = v % TV, r = v / TV;
-      const int qy = r % THp, co = r / THp;
-      const int cg = cot * 64 + co, y = y0 + qy, x = x0 + xv * 8;
-      const bool rok = cg < a.Cout && y < a.Hout;
-      const float* rowp = a.dy + ((size_t)n * a.Cout + min(cg, a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout;
-      float f[8];
-      if ((a.Wout & 7) == 0) {  // uniform: a vector is fully inside or fully outside the row
-        const bool ok = rok && x < a.Wout;
-        const float* src = rowp + min(x, a.Wout - 8);
-        const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+    // ---- staging through bounds-checked buffer loads: out-of-range offsets (OOBW) read as zero, so there is no
+    // per-lane branch or select and all loads of a batch are in flight together
+    {
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.dy + (size_t)n * a.Cout * HWo), 0, (unsigned)(a.Cout * HWo * 4), 0x00020000);
+      constexpr int DV = 4;  // 64 * 128 / 8 / 256 vectors per thread
+      float f[DV][8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = ok ? lo[j] : 0.f; f[4 + j] = ok ? hi[j] : 0.f; }
-      } else {
+      for (int i = 0; i < DV; ++i) {
+        const int v = tid + i * 256;
+        const int xv = v % TV, r = v / TV;
+        const int qy = r % THp, co = r / THp;
+        const int cg = cot * 64 + co, y = y0 + qy, x = x0 + xv * 8;
+        const bool rok = cg < a.Cout && y < a.Hout;
+        const unsigned base = rok ? (unsigned)((cg * a.Hout + y) * a.Wout + x) * 4u : OOBW;
+        {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = rowp[min(x + j, a.Wout - 1)]; f[j] = (rok && x + j < a.Wout) ? t : 0.f; }
+          for (int j = 0; j < 8; ++j)
+            f[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, (int)((x + j < a.Wout) ? base + 4 * j : OOBW), 0, 0));
+        }
       }
-      dy_t[co * b.pyv + qy * TV + xv] = cvt8(f);
+#pragma unroll
+      for (int i = 0; i < DV; ++i) {
+        const int v = tid + i * 256;
+        const int xv = v % TV, r = v / TV;
+        const int qy = r % THp, co = r / THp;
+        dy_t[co * b.pyv + qy * TV + xv] = cvt8(f[i]);
+      }
     }
-    // ---- X tile: 64 channels x IH rows x RV vectors; LDS pixel l of a row <-> image x = x0 - 8 + l
-    for (int v = tid; v < 64 * IH * b.rv; v += 256) {
-      const int xv = v % b.rv, r = v / b.rv;
-      const int iy = r % IH, ci = r / IH;
-      const int cg = cit * 64 + ci;
-      float f[8];
-      load8_virtual(a, n, min(cg, Cin - 1), y0 - a.pad + iy, x0 - 8 + xv * 8, cg < Cin, f);
-      x_t[ci * b.pxv + iy * b.rv + xv] = cvt8(f);
+    {
+      const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+      const unsigned pl0 = (unsigned)((a.Hin >> sh0) * (a.Win >> sh0)) * 4u, pl1 = (unsigned)((a.Hin >> sh1) * (a.Win >> sh1)) * 4u;
+      const __amdgpu_buffer_rsrc_t r0 =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * a.C0 * (pl0 / 4)), 0, a.C0 * pl0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.C1 ? a.src1 + (size_t)n * a.C1 * (pl1 / 4) : a.src0), 0, a.C1 * pl1, 0x00020000);
+      const bool fast = (a.Win & 7) == 0 && a.mode0 != ESS_SRC_ZERO_UP2 && a.mode1 != ESS_SRC_ZERO_UP2;
+      const int nxv = 64 * IH * b.rv;
+      for (int v0 = 0; v0 < nxv; v0 += 256 * 3) {  // batches of 3 vectors per thread keep the register footprint small
+        float f[3][8];
+        u32x4w xq[12];
+        unsigned xofs[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int v = v0 + tid + i * 256;
+          const int xv = v % b.rv, r = v / b.rv;
+          const int iy = r % IH, ci = r / IH;
+          const int cg = cit * 64 + ci, gy = y0 - a.pad + iy, gx = x0 - 8 + xv * 8;
+          const bool first = cg < a.C0;
+          const int sh = first ? sh0 : sh1;
+          const int Wp = a.Win >> sh;
+          const unsigned pls = first ? pl0 : pl1;
+          const int cc = first ? cg : cg - a.C0;
+          const bool rok = v < nxv && cg < Cin && gy >= 0 && gy < a.Hin;
+          if (fast) {
+            const bool ok = rok && gx >= 0 && gx < a.Win;
+            const unsigned o = ok ? (unsigned)cc * pls + (unsigned)((gy >> sh) * Wp + (gx >> sh)) * 4u : OOBW;
+            // per-lane descriptor choice is avoided by issuing against both sources: the wrong one is out of range
+            const unsigned oa = first ? o : OOBW, ob = first ? OOBW : o;
+            xofs[2 * i] = oa;
+            xofs[2 * i + 1] = sh0 ? OOBW : oa + 16;
+            xofs[6 + 2 * i] = ob;
+            xofs[6 + 2 * i + 1] = sh1 ? OOBW : ob + 16;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int x = gx + j;
+              const int mode = first ? a.mode0 : a.mode1;
+              const bool ok = rok && x >= 0 && x < a.Win && !(mode == ESS_SRC_ZERO_UP2 && ((gy | x) & 1));
+              const unsigned o = ok ? (unsigned)cc * pls + (unsigned)((gy >> sh) * Wp + (x >> sh)) * 4u : OOBW;
+              const unsigned ua = __builtin_amdgcn_raw_buffer_load_b32(r0, (int)(first ? o : OOBW), 0, 0);
+              const unsigned ub = __builtin_amdgcn_raw_buffer_load_b32(r1, (int)(first ? OOBW : o), 0, 0);
+              f[i][j] = __builtin_bit_cast(float, ua | ub);
+            }
+          }
+        }
+        if (fast) {
+          ldb128x12(xq, r0, r1, xofs);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              // a nearest-upsampled source holds 4 stored pixels per vector, each used twice; the source that does not
+              // own this channel was read out of range and contributes zero bits
+              const unsigned ua = sh0 ? xq[2 * i][j >> 1] : xq[2 * i + (j >> 2)][j & 3];
+              const unsigned ub = sh1 ? xq[6 + 2 * i][j >> 1] : xq[6 + 2 * i + (j >> 2)][j & 3];
+              f[i][j] = __builtin_bit_cast(float, ua | ub);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int v = v0 + tid + i * 256;
+          if (v < nxv) {
+            const int xv = v % b.rv, r = v / b.rv;
+            const int iy = r % IH, ci = r / IH;
+            x_t[ci * b.pxv + iy * b.rv + xv] = cvt8(f[i]);
+          }
+        }
+      }
     }
     __syncthreads();
     const u32x4w* ap = dy_t + (cb * 32 + p) * b.pyv + half;
@@ -361,8 +468,14 @@ __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* d
   const size_t total = (size_t)T * Cout * Cin;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      s0 += ws[(size_t)k * total + i]; s1 += ws[(size_t)(k + 1) * total + i];
+      s2 += ws[(size_t)(k + 2) * total + i]; s3 += ws[(size_t)(k + 3) * total + i];
+    }
+    for (; k < nsplit; ++k) s0 += ws[(size_t)k * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
     const int t = i / ((size_t)Cout * Cin);
     const size_t rem = i - (size_t)t * Cout * Cin;  // co*Cin + ci
     float* dst = dw + rem * T + t;
