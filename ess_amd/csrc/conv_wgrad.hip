@@ -463,6 +463,164 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
   }
 }
 
+
+// ---- fast variant: rows that are multiples of 8 pixels, direct / nearest-upsampled sources.
+// All global loads of the NEXT pixel tile (13 vectors = 26 x 16 B per thread) are issued before the MFMA phase of the
+// current one and stay in flight across it; conversion to bf16 + LDS write happen afterwards.  Loads are plain,
+// unconditional dwordx4 loads from clamped (always valid) per-lane addresses, zeroed by a 0/1 mask multiply -- no
+// branch, no select on the load, nothing for the compiler to serialize.
+__global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBArgs b) {
+  extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
+  const WgradArgs& a = b.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
+  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
+  const int cb = wave >> 1, ib = wave & 1;
+  const int TWp = 1 << a.twl, THp = 128 >> a.twl;
+  const int TV = TWp >> 3;
+  const int IH = THp + 2;
+  const int Cin = a.C0 + a.C1;
+  u32x4w* dy_t = smemv;
+  u32x4w* x_t = smemv + 64 * b.pyv;
+  constexpr int DV = 4, XV = 10;  // vectors per thread: 64*128/8/256 of dY, ceil(64*IH*RV/256) of X (IH*RV = 36 or 40)
+  const int nxv = 64 * IH * b.rv;
+  const size_t HWo = (size_t)a.Hout * a.Wout;
+  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+
+  // tile-independent part of the staging plan
+  int d_lds[DV], d_co[DV], d_qy[DV], d_xv[DV];
+#pragma unroll
+  for (int i = 0; i < DV; ++i) {
+    const int v = tid + i * 256;
+    const int xv = v % TV, r = v / TV;
+    d_qy[i] = r % THp; d_co[i] = cot * 64 + r / THp; d_xv[i] = xv;
+    d_lds[i] = (r / THp) * b.pyv + (r % THp) * TV + xv;
+  }
+  int x_lds[XV], x_iy[XV], x_xv[XV], x_sh[XV];
+  const float* x_base[XV];  // channel plane of this vector's channel in its source (sample 0)
+  size_t x_ns[XV];          // sample stride of that source
+  int x_w[XV];
+  float x_ok[XV];
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int v = tid + i * 256;
+    const int xv = v % b.rv, r = v / b.rv;
+    const int iy = r % IH, ci = r / IH;
+    const int cg = cit * 64 + ci;
+    const bool cok = v < nxv && cg < Cin;
+    const int cgc = min(cg, Cin - 1);
+    const bool first = cgc < a.C0;
+    const int sh = first ? sh0 : sh1;
+    const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
+    const int cc = first ? cgc : cgc - a.C0, Cs = first ? a.C0 : a.C1;
+    x_base[i] = (first ? a.src0 : a.src1) + (size_t)cc * Hp * Wp;
+    x_ns[i] = (size_t)Cs * Hp * Wp;
+    x_w[i] = Wp; x_sh[i] = sh; x_iy[i] = iy; x_xv[i] = xv;
+    x_ok[i] = cok ? 1.f : 0.f;
+    x_lds[i] = v < nxv ? ci * b.pxv + iy * b.rv + xv : -1;
+  }
+
+  f32x4 dreg[DV][2], xreg[XV][2];
+  float dmask[DV], xmask[XV];
+  auto issue = [&](int tile) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * THp, x0 = tx * TWp;
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int y = y0 + d_qy[i], x = x0 + d_xv[i] * 8;
+      dmask[i] = (d_co[i] < a.Cout && y < a.Hout && x < a.Wout) ? 1.f : 0.f;
+      const float* src = a.dy + ((size_t)n * a.Cout + min(d_co[i], a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout +
+                         min(x, a.Wout - 8);
+      dreg[i][0] = *(const f32x4*)src;
+      dreg[i][1] = *(const f32x4*)(src + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int gy = y0 - a.pad + x_iy[i], gx = x0 - 8 + x_xv[i] * 8;
+      xmask[i] = (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? x_ok[i] : 0.f;
+      const int cy = min(max(gy, 0), a.Hin - 1) >> x_sh[i];
+      const int cx = min(max(gx, 0), a.Win - 8) >> x_sh[i];
+      const float* src = x_base[i] + (size_t)n * x_ns[i] + (size_t)cy * x_w[i] + cx;
+      xreg[i][0] = *(const f32x4*)src;
+      // a nearest-upsampled source covers the 8 virtual pixels with 4 stored ones: the second load is not needed,
+      // re-read the first address (keeps the access in range at the right image border)
+      xreg[i][1] = *(const f32x4*)(src + (x_sh[i] ? 0 : 4));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[j] = dreg[i][0][j] * dmask[i]; f[4 + j] = dreg[i][1][j] * dmask[i]; }
+      dy_t[d_lds[i]] = cvt8(f);
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      float f[8];
+      if (x_sh[i]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[2 * j] = xreg[i][0][j] * xmask[i]; f[2 * j + 1] = f[2 * j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = xreg[i][0][j] * xmask[i]; f[4 + j] = xreg[i][1][j] * xmask[i]; }
+      }
+      if (x_lds[i] >= 0) x_t[x_lds[i]] = cvt8(f);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  if (split < a.ntiles) issue(split);
+  for (int tile = split; tile < a.ntiles; tile += nsplit) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (tile + nsplit < a.ntiles) issue(tile + nsplit);
+    const u32x4w* ap = dy_t + (cb * 32 + p) * b.pyv + half;
+    const u32x4w* xp = x_t + (ib * 32 + p) * b.pxv + half;
+    for (int qy = 0; qy < THp; ++qy) {
+      for (int xs = 0; xs < TV; xs += 2) {
+        const u32x4w av = ap[qy * TV + xs];
+        const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const u32x4w* row = xp + (qy + ky) * b.rv + xs;
+          const u32x4w v0 = row[0], v1 = row[1], v2 = row[2];
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(v0, v1)),
+                                                                    acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, v1), acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(v1, v2)),
+                                                                    acc[ky * 3 + 2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int ci = cit * 64 + ib * 32 + p;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+    }
+  if (a.ws_b && cit == 0 && ib == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int co = cot * 64 + cb * 32 + p;
+    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
                                     int Cin, int accumulate) {
   const size_t total = (size_t)T * Cout * Cin;
@@ -591,8 +749,14 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
   if (w.bf16) {
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
-    if ((rc = raise_lds(wgrad_bf16_k3s1_kernel, w.lds_bytes))) return rc;
-    hipLaunchKernelGGL(wgrad_bf16_k3s1_kernel, grid, dim3(256), w.lds_bytes, st, bb);
+    const bool fast = (d->W_in % 8) == 0 && (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
+    if (fast) {
+      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel, w.lds_bytes))) return rc;
+      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel, grid, dim3(256), w.lds_bytes, st, bb);
+    } else {
+      if ((rc = raise_lds(wgrad_bf16_k3s1_kernel, w.lds_bytes))) return rc;
+      hipLaunchKernelGGL(wgrad_bf16_k3s1_kernel, grid, dim3(256), w.lds_bytes, st, bb);
+    }
   } else if (w.taps_variant) {
     ESS_CHECK_ARG(d->stride == 2, "wgrad: 7x7 stem variant is stride 2 only");
     if ((rc = raise_lds(wgrad_taps_kernel<7, 2>, w.lds_bytes))) return rc;

@@ -220,3 +220,54 @@ def test_config2_ddd17_shape_parity_vs_oracle():
     miou_ref = O.miou_acc(ref_conf)[0].item()
     miou = O.miou_acc(conf.cpu())[0].item()
     assert abs(miou - miou_ref) < 1e-4 or int(mism.sum()) > 0
+
+
+def test_config3_bf16_vs_oracle_and_bf16_reference():
+    """BASELINE config 3 arithmetic (bf16 MFMA operands, fp32 accumulate, fp32 tensors/state) on a reduced DSEC-like shape
+    (B=2, T=5, 2x96x128, K=11): the T-step recurrent encoder + decoder on the HIP path against (a) the fp32 oracle --
+    stated tolerance 3e-2 of the logit range, argmax equal wherever the oracle's top-2 margin exceeds twice the logit error -- and (b) the fp32 HIP path."""
+    from ess_amd import hip
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.options.inference_options import default_options
+    from ess_amd.evaluation.metrics import logits_to_confusion
+    from ess_amd.models.style_networks import SemSegE2VID
+    B, T, C, H, W, K = 2, 5, 2, 96, 128, 11
+    cfg = O.e2vid_config(num_bins=C)
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 21)
+    sd_d = O.synth_state_dict(O.semseg_param_shapes(256, K), 22, decoder_style=True)
+    ev, _, _, lab = O.synth_batch(B, T, C, H, W, K, seed=5)
+    ref_logits, ref_lbl, ref_conf = O.validate_batch(sd_e, cfg, sd_d, ev, lab, T, K)
+    out = {}
+    for mode in ('fp32', 'bf16'):
+        hip.set_compute(mode)
+        try:
+            model = _e2vid(cfg, sd_e)
+            dec = SemSegE2VID(256, K, skip_connect=True, skip_type='concat')
+            dec.load_state_dict(sd_d)
+            dec = dec.cuda().eval()
+            rec = ImageReconstructor(model, H, W, C, torch.device('cuda:0'), default_options())
+            rec.last_states_for_each_channel = {'grayscale': None}
+            with torch.no_grad():
+                for t in range(T):
+                    _, states, latent = rec.update_reconstruction(ev.cuda()[:, t * C:(t + 1) * C], need_image=False)
+                logits = dec(latent)[1]
+                pred, conf = logits_to_confusion(logits, lab.cuda(), K, 255)
+            out[mode] = (logits.cpu(), pred.cpu(), conf.cpu(), latent[8].cpu())
+        finally:
+            hip.set_compute('fp32')
+    rng = (ref_logits.max() - ref_logits.min()).item()
+    e32 = (out['fp32'][0] - ref_logits).abs().max().item()
+    e16 = (out['bf16'][0] - ref_logits).abs().max().item()
+    agree = (out['bf16'][1] == ref_lbl).float().mean().item()
+    miou_ref, miou16 = O.miou_acc(ref_conf)[0].item(), O.miou_acc(out['bf16'][2])[0].item()
+    print(f'config3: logit range {rng:.3f}; max|dlogit| fp32 {e32:.2e}, bf16 {e16:.2e}; argmax agreement {agree:.4f}; '
+          f'mIoU oracle {miou_ref:.4f} bf16 {miou16:.4f}; latent8 rel err {relerr(out["bf16"][3], out["fp32"][3]):.2e}')
+    assert e32 < 1e-3
+    assert e16 < 3e-2 * rng
+    top2 = ref_logits.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    mism = out['bf16'][1] != ref_lbl
+    # random-init decoder: logits are nearly tied; every disagreement must sit inside the bf16 logit error band
+    assert int((mism & (margin > 2 * e16)).sum()) == 0
+    assert agree > 0.9
+    assert relerr(out['bf16'][3], out['fp32'][3]) < 3e-2  # recurrent state drift over T steps stays at bf16 rounding level
