@@ -25,9 +25,7 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 }
 
 // pixel positions a thread stages per 8-channel block (compile-time bound of the register prefetch), by filter geometry
-constexpr int kpc(int ks, int s) {
-  return s == 1 ? (ks == 1 ? 1 : ks == 3 ? 2 : ks == 5 ? 2 : 3) : (ks == 1 ? 4 : ks == 3 ? 5 : ks == 5 ? 5 : 6);
-}
+constexpr int kpc(int ks, int s) { return stage_kpc(ks, s); }
 constexpr unsigned OOB = 0x80000000u;  // beyond any buffer: the bounds-checked load returns 0
 
 template <int KS, int S, int MB, int EPI, int CB8>

@@ -119,12 +119,17 @@ inline bool is_bf16(const EssConvDesc* d) { return d->compute == ESS_COMPUTE_BF1
 inline int pick_ck(const EssConvDesc* d) {
   const int cin = d->C0 + d->C1;
   if (is_bf16(d)) return (d->ksize == 1 && d->stride == 1 && cin >= 32) ? 32 : 16;  // one v_mfma_f32_32x32x16_bf16 K-step = 16 channels
-  int ck = d->ksize >= 7 ? 2 : (d->ksize == 5 ? 4 : 8);
-  while (ck > 2 && ck / 2 >= cin) ck /= 2;
-  return ck;
+  // fp32: K-step = 2 channels; chunk sized for LDS.  Only the 2-channel 5x5 head gets a narrower chunk.
+  if (d->ksize == 5 && d->stride == 1 && cin <= 2) return 2;
+  return d->ksize >= 7 ? 2 : (d->ksize == 5 ? 4 : 8);
 }
 
 inline int pick_mb(const EssConvDesc* d) { return d->C_out > 32 ? 2 : 1; }
+
+// tile positions (per channel / per 8-channel block) a thread can stage: bound of the kernels' register prefetch
+constexpr int stage_kpc(int ks, int s) {
+  return s == 1 ? (ks == 1 ? 1 : ks == 3 ? 2 : ks == 5 ? 2 : 3) : (ks == 1 ? 4 : ks == 3 ? 5 : ks == 5 ? 5 : 6);
+}
 
 inline Geom choose_geom(const EssConvDesc* d) {
   Geom best{};
@@ -136,6 +141,7 @@ inline Geom choose_geom(const EssConvDesc* d) {
       const int TW = BW << wxl, TH = (4 >> wxl) * NBW * RB;
       const int tx = ceil_div(d->W_out, TW), ty = ceil_div(d->H_out, TH);
       const int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
+      if (IH * IW > stage_kpc(KS, S) * 256) continue;  // would not fit the staging registers
       // padded MACs (dominant) + a small halo/staging term; prefer wide blocks on ties
       const double cost = (double)tx * ty * TW * TH * (1.0 + 0.02 * (double)(IH * IW) / (TH * TW * S * S)) +
                           1e-3 * (5 - bwl);

@@ -18,10 +18,17 @@ namespace {
 
 using namespace essconv;
 
-template <int KS, int S, int MB, int EPI>
+// positions a thread stages per channel (compile-time bound of the register prefetch), by filter geometry
+constexpr int kpc32(int ks, int s) { return stage_kpc(ks, s); }
+constexpr unsigned OOB32 = 0x80000000u;  // beyond any buffer: the bounds-checked load returns 0
+
+template <int KS, int S, int MB, int EPI, int CB>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int COT = MB * 32;
+  constexpr int KPC = kpc32(KS, S);
+  constexpr int WSZ = KS * KS * CB * COT;  // floats of one chunk's weight slab
+  constexpr int WV = (WSZ / 4 + 255) / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
@@ -32,10 +39,8 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
   const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int CB = a.ck;
   float* in_t = smem;
   float* w_t = smem + CB * a.plane;
-  const int wsz = KS * KS * CB * COT;
 
   const int ox = p & (BW - 1), oy = p >> a.bwl;
   const int wx = wave & (WX - 1), wy = wave >> a.wxl;
@@ -55,53 +60,68 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
+  // ---- staging plan (same scheme as conv_bf16.hip): thread t owns tile positions t, t+256, ... of every channel of
+  // the chunk; loads are bounds-checked buffer loads whose offset is out of range wherever a zero is wanted (padding,
+  // zero-insert holes, channels past the source), so they carry no branch; the values of chunk i+1 are fetched before
+  // the MFMA phase of chunk i and written to LDS after it.
   const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
-  const int Ctot = a.C0 + a.C1;
+  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+  const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
+  const unsigned pl0 = (unsigned)((a.Hin >> sh0) * Wp0) * 4u, pl1 = (unsigned)((a.Hin >> sh1) * Wp1) * 4u;
+  const __amdgpu_buffer_rsrc_t r0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * a.C0 * (pl0 / 4)), 0, a.C0 * pl0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.C1 ? a.src1 + (size_t)n * a.C1 * (pl1 / 4) : a.src0), 0, a.C1 * pl1, 0x00020000);
+  unsigned v_o0[KPC], v_o1[KPC];
+  int v_lds[KPC];
+  const int npos = a.IH * a.IW;
+#pragma unroll
+  for (int k = 0; k < KPC; ++k) {
+    const int vi = tid + k * 256;
+    const int iy = vi / a.IW, ix = vi - iy * a.IW;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    const bool in = vi < npos && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+    const bool odd = ((gy | gx) & 1) != 0;
+    v_lds[k] = vi < npos ? iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix) : -1;
+    v_o0[k] = (in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0)) * 4u : OOB32;
+    v_o1[k] = (in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh1) * Wp1 + (gx >> sh1)) * 4u : OOB32;
+  }
+  auto load_one = [&](int ch, int cb, int k) -> float {
+    const int c = ch * CB + cb;            // wave-uniform
+    const bool first = c < a.C0 || a.C1 == 0;
+    const unsigned off = first ? v_o0[k] + (unsigned)c * pl0 : v_o1[k] + (unsigned)(c - a.C0) * pl1;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)off, 0, 0));
+  };
+
+  float pre[CB][KPC];
+  const f32x4* wbase = (const f32x4*)a.wpk + (size_t)ct * a.n_chunks * (WSZ / 4);
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) pre[cb][k] = load_one(0, cb, k);
 
   for (int ch = 0; ch < a.n_chunks; ++ch) {
     __syncthreads();  // everyone finished reading the previous chunk
-    // ---- stage the input tile of this channel chunk
-    for (int cb = 0; cb < CB; ++cb) {
-      const int c = ch * CB + cb;
-      const bool first = c < a.C0;
-      const float* sp = first ? a.src0 : a.src1;
-      const int cc = first ? c : c - a.C0;
-      const int Cs = first ? a.C0 : a.C1;
-      const int mode = first ? a.mode0 : a.mode1;
-      const bool cvalid = c < Ctot;
-      const int sh = mode != ESS_SRC_DIRECT ? 1 : 0;
-      const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
-      const float* pl = sp + ((size_t)n * Cs + cc) * Hp * Wp;
-      float* dst = in_t + cb * a.plane;
-      if (!cvalid) {  // zero padding channels of the last chunk (block-uniform branch)
-        for (int iy = wave; iy < a.IH; iy += 4)
-          for (int ix = lane; ix < a.IW; ix += 64)
-            dst[iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix)] = 0.f;
-        continue;
-      }
-      for (int iy = wave; iy < a.IH; iy += 4) {
-        const int gy = iy0 + iy;
-        bool yok = cvalid && gy >= 0 && gy < a.Hin;
-        if (mode == ESS_SRC_ZERO_UP2) yok = yok && !(gy & 1);
-        const float* row = pl + (size_t)(min(max(gy, 0), a.Hin - 1) >> sh) * Wp;
-        for (int ix = lane; ix < a.IW; ix += 64) {
-          const int gx = ix0 + ix;
-          bool ok = yok && gx >= 0 && gx < a.Win;
-          if (mode == ESS_SRC_ZERO_UP2) ok = ok && !(gx & 1);
-          // unconditional load from a clamped address + select: no per-element branch, loads stay batched
-          const float t = row[min(max(gx, 0), a.Win - 1) >> sh];
-          const float v = ok ? t : 0.f;
-          const int li = iy * a.row_pitch + (S == 2 ? (ix & 1) * a.par_off + (ix >> 1) : ix);
-          dst[li] = v;
-        }
-      }
-    }
-    // ---- stage the weight slab (one contiguous block in the packed layout)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int k = 0; k < KPC; ++k)
+        if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = pre[cb][k];
     {
-      const float* wsrc = (const float*)a.wpk + ((size_t)ct * a.n_chunks + ch) * wsz;
-      for (int i = tid * 4; i < wsz; i += 1024) *(f32x4*)(w_t + i) = *(const f32x4*)(wsrc + i);
+      const f32x4* wsrc = wbase + (size_t)ch * (WSZ / 4);
+      f32x4 wv[WV];
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wv[it] = wsrc[i < WSZ / 4 ? i : 0]; }
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ / 4) ((f32x4*)w_t)[i] = wv[it]; }
     }
     __syncthreads();
+    if (ch + 1 < a.n_chunks) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) pre[cb][k] = load_one(ch + 1, cb, k);
+    }
     // ---- MFMA over (tap, channel pair)
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
@@ -111,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
         const int toff = ky * a.row_pitch + (S == 2 ? (kx & 1) * a.par_off + (kx >> 1) : kx);
         const float* wp = w_t + (tap * CB + half) * COT + p;
         const float* ip = in_t + toff;
-#pragma unroll 2
+#pragma unroll
         for (int kk = 0; kk < CB; kk += 2) {
           float af[MB], bf[NBW];
 #pragma unroll
@@ -127,28 +147,34 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvKArgs a) {
       }
     }
   }
-
   conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
-
 }
 
-template <int KS, int S, int MB>
+template <int KS, int S, int MB, int CB>
 void launch_epi(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
   if constexpr (KS == 3 && S == 1) {
     switch (epi) {
-      case ESS_EPI_LSTM: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_LSTM>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_LSTM>), grid, dim3(256), lds, st, a); } return;
-      case ESS_EPI_GRU_UR: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_UR>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_UR>), grid, dim3(256), lds, st, a); } return;
-      case ESS_EPI_GRU_OUT: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_OUT>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_OUT>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_LSTM: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_LSTM, CB>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_LSTM, CB>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_GRU_UR: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_UR, CB>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_UR, CB>), grid, dim3(256), lds, st, a); } return;
+      case ESS_EPI_GRU_OUT: { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_OUT, CB>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_GRU_OUT, CB>), grid, dim3(256), lds, st, a); } return;
       default: break;
     }
   }
-  { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_LINEAR>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_LINEAR>), grid, dim3(256), lds, st, a); }
+  { ess_allow_lds(conv_f32_kernel<KS, S, MB, ESS_EPI_LINEAR, CB>, lds); hipLaunchKernelGGL((conv_f32_kernel<KS, S, MB, ESS_EPI_LINEAR, CB>), grid, dim3(256), lds, st, a); }
 }
 
 template <int KS, int S>
-void launch_mb(int mb, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
-  if (mb == 2) launch_epi<KS, S, 2>(epi, grid, lds, st, a);
-  else launch_epi<KS, S, 1>(epi, grid, lds, st, a);
+void launch_mb(int mb, int ck, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  constexpr int CBD = KS >= 7 ? 2 : (KS == 5 ? 4 : 8);  // default channels per chunk for this filter size
+  if constexpr (KS == 5 && S == 1) {
+    if (ck == 2) {  // 2-channel head
+      if (mb == 2) launch_epi<KS, S, 2, 2>(epi, grid, lds, st, a);
+      else launch_epi<KS, S, 1, 2>(epi, grid, lds, st, a);
+      return;
+    }
+  }
+  if (mb == 2) launch_epi<KS, S, 2, CBD>(epi, grid, lds, st, a);
+  else launch_epi<KS, S, 1, CBD>(epi, grid, lds, st, a);
 }
 
 }  // namespace
@@ -216,18 +242,22 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const
   a.ck = pl.ck; a.n_chunks = pl.n_chunks; a.act = d->act; a.hid = d->hidden; a.out_split = d->out_split;
   hipStream_t st = (hipStream_t)stream;
   if (is_bf16(d)) return conv_bf16_launch(d, pl, g, a, st);
+  ESS_CHECK_ARG(g.IH * g.IW <= kpc32(d->ksize, d->stride) * 256, "conv: input tile of %d positions exceeds the staging capacity",
+                g.IH * g.IW);
+  ESS_CHECK_ARG((int64_t)(d->C0 > d->C1 ? d->C0 : d->C1) * d->H_in * d->W_in * 4 < (int64_t)1 << 31,
+                "conv: one sample of a source must stay below 2 GiB (32-bit buffer offsets)");
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const int key = d->ksize * 10 + d->stride;
   switch (key) {
-    case 11: launch_mb<1, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 12: launch_mb<1, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 31: launch_mb<3, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 32: launch_mb<3, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 51: launch_mb<5, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 52: launch_mb<5, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 71: launch_mb<7, 1>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
-    case 72: launch_mb<7, 2>(mb, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 11: launch_mb<1, 1>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 12: launch_mb<1, 2>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 31: launch_mb<3, 1>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 32: launch_mb<3, 2>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 51: launch_mb<5, 1>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 52: launch_mb<5, 2>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 71: launch_mb<7, 1>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
+    case 72: launch_mb<7, 2>(mb, pl.ck, d->epilogue, grid, pl.lds_bytes, st, a); break;
     default: ess_set_error("conv: no kernel for k%d s%d", d->ksize, d->stride); return ESS_ENOTSUP;
   }
   return ess_launch_status("conv2d_forward");

@@ -40,6 +40,7 @@ def test_conv_plan_and_validation_on_host(built_lib):
     assert sb.plan.ck == 16 and sb.plan.packed_bytes == 2 * sb.plan.packed_elems and sb.plan.lds_bytes <= 64 * 1024
     head = hip.conv_spec(2, 200, 352, 2, 0, 32, 5, 1, 2, act=hip.ACT_RELU)
     assert head.plan.ck == 2 and head.plan.cout_tile == 32
+    assert hip.conv_spec(1, 8, 8, 3, 0, 8, 3, 1, 1).plan.ck == 8  # narrow inputs are zero-padded to the chunk
     small = hip.conv_spec(1, 24, 40, 32, 0, 11, 1, 1, 0)  # 11 classes padded to a 32-row tile
     assert small.plan.rows_padded == 32
     with pytest.raises(hip.EssHipError, match='ksize'):
