@@ -68,6 +68,8 @@ __device__ __forceinline__ void load8_virtual(const WgradArgs& a, int n, int c, 
   }
 }
 
+constexpr unsigned OOBF = 0x80000000u;  // beyond any buffer: bounds-checked loads return 0
+
 template <int KS, int S>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -97,30 +99,47 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradArgs a) {
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
     const int y0 = ty * THp, x0 = tx * TWp;
     __syncthreads();
-    // ---- dY tile: 64 channels x 64 pixels, lanes along x
+    // ---- staging via bounds-checked buffer loads (out-of-range offset = 0): branch-free, so the unrolled rows'
+    // loads are all in flight together
     {
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.dy + (size_t)n * a.Cout * HWo), 0, (unsigned)(a.Cout * HWo * 4), 0x00020000);
       const int qx = tid & (TWp - 1);
       const int rows_per_it = 256 >> a.twl;
+      const int x = x0 + qx;
+#pragma unroll 4
       for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
         const int co = r / THp, qy = r - co * THp;  // THp is a power of two
-        const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
+        const int cg = cot * 64 + co, y = y0 + qy;
         const bool ok = cg < a.Cout && y < a.Hout && x < a.Wout;
-        const float t = a.dy[((size_t)n * a.Cout + min(cg, a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout + min(x, a.Wout - 1)];
-        dy_t[co * PY + qy * TWp + qx] = ok ? t : 0.f;
+        const unsigned off = ok ? (unsigned)((cg * a.Hout + y) * a.Wout + x) * 4u : OOBF;
+        dy_t[co * PY + qy * TWp + qx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, (int)off, 0, 0));
       }
     }
-    // ---- X tile: 64 channels x IH x IW (halo included), lanes along x
     {
+      const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+      const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
+      const unsigned pl0 = (unsigned)((a.Hin >> sh0) * Wp0) * 4u, pl1 = (unsigned)((a.Hin >> sh1) * Wp1) * 4u;
+      const __amdgpu_buffer_rsrc_t r0 =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * a.C0 * (pl0 / 4)), 0, a.C0 * pl0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.C1 ? a.src1 + (size_t)n * a.C1 * (pl1 / 4) : a.src0), 0, a.C1 * pl1, 0x00020000);
       const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
+#pragma unroll 2
       for (int r = wave; r < 64 * a.IH; r += 4) {
         const int ci = r / a.IH, iy = r - ci * a.IH;
-        const int cg = cit * 64 + ci;
+        const int cg = cit * 64 + ci;              // wave-uniform
+        const bool first = cg < a.C0;
+        const int mode = first ? a.mode0 : a.mode1, sh = first ? sh0 : sh1, Wp = first ? Wp0 : Wp1;
+        const unsigned cbase = first ? (unsigned)cg * pl0 : (unsigned)(cg - a.C0) * pl1;
+        const int gy = iy0 + iy;
+        const bool rok = cg < Cin && gy >= 0 && gy < a.Hin && !(mode == ESS_SRC_ZERO_UP2 && (gy & 1));
         float* dst = x_t + ci * a.plx + iy * a.IW;
-        const bool cok = cg < Cin;
-        const int cgc = min(cg, Cin - 1);
         for (int ix = lane; ix < a.IW; ix += 64) {
-          const float t = load_virtual(a, n, cgc, iy0 + iy, ix0 + ix);
-          dst[ix] = cok ? t : 0.f;
+          const int gx = ix0 + ix;
+          const bool ok = rok && gx >= 0 && gx < a.Win && !(mode == ESS_SRC_ZERO_UP2 && (gx & 1));
+          const unsigned off = ok ? cbase + (unsigned)((gy >> sh) * Wp + (gx >> sh)) * 4u : OOBF;
+          dst[ix] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)off, 0, 0));
         }
       }
     }
@@ -621,6 +640,61 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   }
 }
 
+
+// ---- 1x1 convolution with few channels (the K-class head, 32 -> K at full resolution): HBM-bound, the MFMA tile
+// kernel would stage 64x64 channels to use 11x32.  Plain VALU: each workgroup walks chunks of 128 pixels, stages
+// dY[Cout][128] and X[Cin][128] in LDS (coalesced rows) and each thread accumulates up to 4 (co, ci) products.
+__global__ __launch_bounds__(256) void wgrad_small1x1_kernel(const WgradArgs a, int nchunks_per_img, int total_chunks) {
+  constexpr int P = 128, PP = P + 1;
+  __shared__ float dy_s[16 * PP];
+  __shared__ float x_s[64 * PP];
+  const int tid = threadIdx.x;
+  const int Cin = a.C0, Cout = a.Cout;
+  const int npair = Cout * Cin;
+  const size_t HW = (size_t)a.Hout * a.Wout;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float bacc = 0.f;
+  int pco[4], pci[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int q = tid + k * 256; pco[k] = q / Cin; pci[k] = q - pco[k] * Cin; }
+  for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    const int n = chunk / nchunks_per_img;
+    const size_t px0 = (size_t)(chunk - n * nchunks_per_img) * P;
+    __syncthreads();
+    for (int i = tid; i < (Cout + Cin) * P; i += 256) {
+      const int r = i / P, j = i - r * P;
+      const bool isdy = r < Cout;
+      const float* src = isdy ? a.dy + ((size_t)n * Cout + r) * HW : a.src0 + ((size_t)n * Cin + (r - Cout)) * HW;
+      const size_t px = px0 + j;
+      const float t = src[px < HW ? px : HW - 1];
+      const float v = px < HW ? t : 0.f;
+      if (isdy) dy_s[r * PP + j] = v; else x_s[(r - Cout) * PP + j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (tid + k * 256 < npair) {
+        const float* dp = dy_s + pco[k] * PP;
+        const float* xp = x_s + pci[k] * PP;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < P; ++j) s += dp[j] * xp[j];
+        acc[k] += s;
+      }
+    }
+    if (tid < Cout) {
+      float s = 0.f;
+      for (int j = 0; j < P; ++j) s += dy_s[tid * PP + j];
+      bacc += s;
+    }
+  }
+  // slab [split = blockIdx.x][tap = 0][co][ci]
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (tid + k * 256 < npair) a.ws[(size_t)blockIdx.x * npair + tid + k * 256] = acc[k];
+  if (a.ws_b && tid < Cout) a.ws_b[(size_t)blockIdx.x * Cout + tid] = bacc;
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
                                     int Cin, int accumulate) {
   const size_t total = (size_t)T * Cout * Cin;
@@ -648,7 +722,7 @@ __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* d
 
 struct WPlan {
   int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
-  bool taps_variant, bf16;
+  bool taps_variant, bf16, small1x1;
   int pyv, pxv, rv;
   size_t slab_floats;
 };
@@ -667,6 +741,7 @@ WPlan wplan(const EssConvDesc* d) {
   WPlan w{};
   const int cin = d->C0 + d->C1, KS = d->ksize, S = d->stride;
   w.taps_variant = (cin == 1 && KS == 7);
+  w.small1x1 = KS == 1 && S == 1 && d->pad == 0 && d->C1 == 0 && d->mode0 == ESS_SRC_DIRECT && d->C_out <= 16 && cin <= 64;
   w.bf16 = d->compute == ESS_COMPUTE_BF16 && KS == 3 && S == 1 && d->pad == 1;
   const int npx = w.bf16 ? 128 : 64;
   // pixel tile of 64 (fp32) / 128 (bf16): pick the width that wastes the least
@@ -691,6 +766,10 @@ WPlan wplan(const EssConvDesc* d) {
   if ((size_t)ns > cap) ns = (int)(cap ? cap : 1);
   if (ns < 1) ns = 1;
   w.nsplit = ns;
+  if (w.small1x1) {
+    const int chunks = d->N * ceil_div(d->H_out * d->W_out, 128);
+    w.nsplit = chunks < 1024 ? chunks : 1024;
+  }
   w.lds_bytes = (64 * 65 + (w.taps_variant ? w.IH * w.IW : 64 * w.plx)) * 4;
   if (w.bf16) {
     w.rv = tw / 8 + 2;
@@ -746,7 +825,10 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
     hipLaunchKernelGGL((wgrad_f32_kernel<KS_, S_>), grid, dim3(256), w.lds_bytes, st, a);             \
   } while (0)
-  if (w.bf16) {
+  if (w.small1x1) {
+    const int per_img = ceil_div(d->H_out * d->W_out, 128);
+    hipLaunchKernelGGL(wgrad_small1x1_kernel, dim3(w.nsplit), dim3(256), 0, st, a, per_img, d->N * per_img);
+  } else if (w.bf16) {
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     const bool fast = (d->W_in % 8) == 0 && (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
