@@ -49,7 +49,14 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-__device__ __forceinline__ float ess_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities of the fused epilogues on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// libm's expf/tanhf cost ~25-40 VALU instructions per call, which made the ConvLSTM epilogue as expensive as the K loop
+// of the 8-chunk level-0 gate conv.  Absolute error <= ~3e-7 on outputs in (0,1) / (-1,1).
+__device__ __forceinline__ float ess_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ess_tanh(float x) {
+  const float t = __expf(-2.0f * fabsf(x));  // in (0, 1]: no overflow for any x
+  return copysignf((1.0f - t) * __frcp_rn(1.0f + t), x);
+}
 
 // wave64 all-lanes sum (butterfly through DPP/shuffles)
 __device__ __forceinline__ float wave_sum(float v) {

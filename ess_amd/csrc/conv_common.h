@@ -55,7 +55,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             if (a.residual) v += a.residual[idx];
             if (a.act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
             else if (a.act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
-            else if (a.act == ESS_ACT_TANH) v = tanhf(v);
+            else if (a.act == ESS_ACT_TANH) v = ess_tanh(v);
             if (a.out_split > 0) {
               if (co < a.out_split) a.out[((size_t)n * a.out_split + co) * HW + pix] = v;
               else a.out2[((size_t)n * (a.Cout - a.out_split) + (co - a.out_split)) * HW + pix] = v;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             }
           } else {  // GRU candidate: h' = h (1-u) + tanh(.) u
             const size_t idx = ((size_t)n * a.hid + co) * HW + pix;
-            const float o = tanhf(v), u = a.aux1[idx], h = a.aux0[idx];
+            const float o = ess_tanh(v), u = a.aux1[idx], h = a.aux0[idx];
             a.out[idx] = h * (1.f - u) + o * u;
           }
         }
@@ -79,12 +79,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           const float gi = ess_sigmoid(acc[mb][nb][jj] + a.shift[pr]);
           const float gf = ess_sigmoid(acc[mb][nb][4 + jj] + a.shift[pr + 8]);
           const float go = ess_sigmoid(acc[mb][nb][8 + jj] + a.shift[pr + 16]);
-          const float gc = tanhf(acc[mb][nb][12 + jj] + a.shift[pr + 24]);
+          const float gc = ess_tanh(acc[mb][nb][12 + jj] + a.shift[pr + 24]);
           const size_t idx = ((size_t)n * a.hid + hc) * HW + pix;
           const float cprev = a.aux0 ? a.aux0[idx] : 0.f;
           const float cn = gf * cprev + gi * gc;
           a.out2[idx] = cn;
-          a.out[idx] = go * tanhf(cn);
+          a.out[idx] = go * ess_tanh(cn);
         }
       } else {  // ESS_EPI_GRU_UR
         // packed row 8*q + j: gate q&1 (0 update, 1 reset) of hidden hb*16 + (q>>1)*8 + j

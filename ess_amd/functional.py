@@ -92,12 +92,40 @@ class Conv2dFn(torch.autograd.Function):
         if needw or needb:
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
-            hip.conv_wgrad(spec, x0, x1, dy, dw, db)
+            if s == 2 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1) and \
+                    ((k == 3 and p == 1) or (k == 1 and p == 0)):
+                _wgrad_stride2_by_phases(x0, dy, dw, db, k)
+            else:
+                hip.conv_wgrad(spec, x0, x1, dy, dw, db)
             if not needw:
                 dw = None
             if not needb:
                 db = None
         return d0, d1, dw, db, None, None, None, None
+
+
+def _wgrad_stride2_by_phases(x, dy, dw, db, k):
+    """Weight gradient of a stride-2 conv (ResNet 3x3/s2 pad 1 and 1x1/s2) through the stride-1 kernels: the input splits
+    into its 4 pixel-parity phases X_pq[y][x] = X[2y+p][2x+q] (each at output resolution) and tap (ky, kx) of the stride-2
+    filter is tap (ky', kx') of a stride-1 3x3 correlation of dY with one phase:  p = 0 if ky == 1 else 1,
+    ky' = 0 if ky == 0 else 1 (same in x).  Exact; the direct stride-2 tile kernel stages 5x more input than it uses."""
+    N, C, H, W = x.shape
+    Cout = dy.shape[1]
+    Ho, Wo = H // 2, W // 2
+    if k == 1:
+        spec = hip.conv_spec(N, Ho, Wo, C, 0, Cout, 1, 1, 0)
+        hip.conv_wgrad(spec, x[:, :, ::2, ::2].contiguous(), None, dy, dw, db)
+        return
+    spec = hip.conv_spec(N, Ho, Wo, C, 0, Cout, 3, 1, 1)
+    tmp = torch.empty_like(dw)
+    for p in (0, 1):
+        for q in (0, 1):
+            hip.conv_wgrad(spec, x[:, :, p::2, q::2].contiguous(), None, dy, tmp, db if (p, q) == (0, 0) else None)
+            kys = (1,) if p == 0 else (0, 2)
+            kxs = (1,) if q == 0 else (0, 2)
+            for ky in kys:
+                for kx in kxs:
+                    dw[:, :, ky, kx] = tmp[:, :, 0 if ky == 0 else 1, 0 if kx == 0 else 1]
 
 
 def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT):
