@@ -108,10 +108,19 @@ def roofline_gate_kernels(args, device):
         tot_ms += ms
     achieved = tot_flops / tot_ms / 1e9
     bf16 = args.compute == 'bf16'
+    traffic = None
+    try:  # HBM bytes of the same three launches from the committed PMC passes (null when this shape was not profiled)
+        with open(os.path.join(ROOT, 'profiles', 'gate_kernel_traffic.json')) as f:
+            t = json.load(f).get(f'{args.compute}/{B}/{args.height}x{args.width}')
+        if t:
+            traffic = {'bytes': sum(t['per_level_bytes']), 'algorithmic_bytes': sum(t['algorithmic_bytes']),
+                       'source': 'profiles/r1_gate_kernel_pmc.txt (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'}
+    except OSError:
+        pass
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     return {'bound': 'mfma', 'kernel': ('conv_bf16_kernel' if bf16 else 'conv_f32_kernel') + '<3,1,2,EPI_LSTM>',
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-            'traffic': None, 'per_level': per_level,
+            'traffic': traffic, 'per_level': per_level,
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
                     '; sum over the 3 encoder-level launches of one time step; HIP events on the launch stream'}
 
@@ -139,9 +148,10 @@ def cpu_baseline(args):
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
     return {'value': round(B * T / t, 3), 'unit': 'voxel_grids/s', 'cores': nthreads, 'kind': 'port',
-            'sample': f'{args.trainer} step, B=1 sequence (T={T}, C={C}, {H}x{W}, K={K}), fp32 torch-CPU oracle as written by '
-                      f'the reference (5 decoder forwards, full UNet every time step), mean of 2 steps after 1 warm-up; '
-                      f'{t:.2f} s/step'}
+            'sample': f'{args.trainer} step, B=1 sequence (T={T}, C={C}, {H}x{W}, K={K}), fp32 torch-CPU oracle doing the work as '
+                      f'written by the reference (full UNet every time step' +
+                      (', 5 decoder forwards' if args.trainer == 'ess' else '') +
+                      f'), mean of 2 steps after 1 warm-up; {t:.2f} s/step'}
 
 
 def main():
@@ -214,7 +224,7 @@ def main():
             'data': 'synthetic', 'sequences_per_s': round(world * args.batch * args.steps / elapsed, 3),
             'final_loss': final_loss,
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
-                                   f'DSEC-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
+                                   f'{"DSEC" if args.width == 640 else "DDD17" if args.width == 352 else "custom"}-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
                                    f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
                                    f'conv contractions {args.compute} (fp32 accumulate, fp32 tensors), weight gradients fp32',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
