@@ -118,7 +118,7 @@ def roofline_gate_kernels(args, device):
     except OSError:
         pass
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'kernel': ('conv_bf16_kernel' if bf16 else 'conv_f32_kernel') + '<3,1,2,EPI_LSTM>',
+    return {'bound': 'mfma', 'kernel': 'conv_bf16_ws_k3s1_kernel<2,EPI_LSTM>' if bf16 else 'conv_f32_kernel<3,1,2,EPI_LSTM,8>',
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
             'traffic': traffic, 'per_level': per_level,
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
@@ -165,8 +165,9 @@ def main():
         raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # (a CPU-side `gloo` smoke run may stack ranks on one GPU)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if not os.path.exists(os.path.join(ROOT, 'ess_amd', 'libess_hip.so')):
         import __graft_entry__
         __graft_entry__.build_library(verbose=(rank == 0))
@@ -178,11 +179,15 @@ def main():
     hip.set_compute(args.compute)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=device)
+        backend = os.environ.get('ESS_DIST_BACKEND', 'nccl')  # 'nccl' = RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     torch.manual_seed(6)
     st = synthetic_settings(args.trainer, 'DSEC_events', (args.height, args.width), args.classes, args.batch, args.T, args.C,
-                            device_index=local_rank)
+                            device_index=dev_index)
     if args.trainer == 'ess':
         from ess_amd.training.ess_trainer import ESSModel
         trainer = ESSModel(st)

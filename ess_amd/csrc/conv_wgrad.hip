@@ -760,7 +760,8 @@ WPlan wplan(const EssConvDesc* d) {
   w.ci_tiles = w.taps_variant ? 1 : ceil_div(cin, 64);
   w.slab_floats = (size_t)KS * KS * d->C_out * cin + d->C_out;
   const int pairs = w.co_tiles * w.ci_tiles;
-  int ns = ceil_div(2048, pairs);
+  // the bf16 kernel runs one workgroup per CU (512-register waves): aim at one full round of the 256 CUs
+  int ns = w.bf16 ? ceil_div(256, pairs) : ceil_div(2048, pairs);
   if (ns > w.ntiles) ns = w.ntiles;
   const size_t cap = ((size_t)64 << 20) / (w.slab_floats * 4);
   if ((size_t)ns > cap) ns = (int)(cap ? cap : 1);

@@ -10,6 +10,10 @@ from . import hip
 
 _pack_cache = {}
 
+# When True (set by ess_amd.utils.radam.RAdam), the weight-gradient kernels add straight into an existing leaf `.grad`
+# (a view of the optimiser's flat gradient buffer) instead of materialising dW and letting AccumulateGrad add it.
+DIRECT_GRAD_ACCUM = False
+
 
 def packed_weight(spec, w, w2=None, kind=hip.W_CONV):
     """Tile-major re-layout of a weight tensor, cached until the tensor is modified in place
@@ -60,6 +64,7 @@ class Conv2dFn(torch.autograd.Function):
         hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out)
         ctx.spec = spec
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
+        ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.save_for_backward(x0, x1, weight)
         return out
 
@@ -89,7 +94,21 @@ class Conv2dFn(torch.autograd.Function):
                 d0 = hip.sumpool2x2(dv0) if mode0 == hip.SRC_NEAREST_UP2 else dv0
             if need1:
                 d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
-        if needw or needb:
+        direct = DIRECT_GRAD_ACCUM and needw and weight.is_leaf and weight.grad is not None and weight.grad.is_contiguous() \
+            and not (s == 2 and k == 3)
+        if direct:
+            bias = ctx.bias_ref() if ctx.bias_ref is not None else None
+            db_t = bias.grad if (needb and bias is not None and bias.grad is not None and bias.grad.is_contiguous()) else None
+            if needb and db_t is None:
+                direct = False
+        if direct:
+            if s == 2 and k == 1 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1):
+                sp1 = hip.conv_spec(N, Hv // 2, Wv // 2, C0, 0, Cout, 1, 1, 0)
+                hip.conv_wgrad(sp1, x0[:, :, ::2, ::2].contiguous(), None, dy, weight.grad, db_t, accumulate=True)
+            else:
+                hip.conv_wgrad(spec, x0, x1, dy, weight.grad, db_t, accumulate=True)
+            dw = db = None
+        elif needw or needb:
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
             if s == 2 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1) and \

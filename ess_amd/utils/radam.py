@@ -12,6 +12,7 @@ import torch
 from torch.optim.optimizer import Optimizer
 
 from .. import hip
+from .. import functional as _fn
 from ..functional import invalidate_packed
 
 
@@ -25,6 +26,7 @@ class RAdam(Optimizer):
             raise NotImplementedError('weight_decay is always 0. in the ESS trainers (training/ess_trainer.py:91,99)')
         self._step = 0
         self._flatten()
+        _fn.DIRECT_GRAD_ACCUM = True  # gradients accumulate straight into the flat buffer's views
 
     def _flatten(self):
         ps = [p for p in self.param_groups[0]['params']]
