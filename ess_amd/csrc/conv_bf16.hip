@@ -219,7 +219,7 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
 //   iteration ch: consumers read buffer ch&1 | producers convert+write chunk ch+1 into buffer (ch+1)&1 (its last
 //   readers passed the previous barrier) and then issue the loads of chunk ch+2, which land during iteration ch+1.
 template <int MB, int EPI>
-__global__ __launch_bounds__(512, 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
+__global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16;
   constexpr int COT = MB * 32;
@@ -419,7 +419,8 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   if (use_ws && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
     if (lds2 <= 160 * 1024) {
-      if (mb == 2) launch_ws<2>(d->epilogue, grid, lds2, st, a);
+      if (mb == 4) launch_ws<4>(d->epilogue, grid, lds2, st, a);
+      else if (mb == 2) launch_ws<2>(d->epilogue, grid, lds2, st, a);
       else launch_ws<1>(d->epilogue, grid, lds2, st, a);
       return ess_launch_status("conv2d_forward(bf16, wave-specialised)");
     }
