@@ -30,80 +30,189 @@ struct ConvKArgs {
 
 // ---- shared epilogue: accumulator block (MFMA 32x32 C/D layout: col = lane&31 = pixel, row = (r&3)+8(r>>2)+4(lane>>5)
 // = output channel) -> fused affine / residual / activation / LSTM / GRU maths -> NCHW fp32 stores
+// All epilogue traffic goes through bounds-checked buffer instructions: descriptor base = this sample's tensor (SGPRs),
+// voffset = pixel (+ the 4-channel step of the upper half-wave) kept in ONE register per pixel block, soffset = the
+// wave-uniform channel plane.  No 64-bit per-element addresses (the first version needed ~2 VGPRs per store), no bounds
+// branches (an out-of-tile pixel / out-of-range channel gets an offset past the descriptor: its load returns 0 and
+// its store is dropped), and every read of a block is issued before the block's first store.
+typedef __amdgpu_buffer_rsrc_t ess_rsrc;
+constexpr unsigned ESS_OOB = 0x80000000u;
+__device__ __forceinline__ ess_rsrc ess_make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ess_bload(ess_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void ess_bstore(float v, ess_rsrc r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
+// linear / GRU-candidate epilogue, specialised on what exists (per-row scale, a second input) so that the common
+// bias-only case keeps no dead registers
+template <int MB, int EPI, bool SC, bool IN>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                   const unsigned (&voff)[NBW], unsigned plane_b) {
+  constexpr int COT = MB * 32;
+  const unsigned HW = plane_b / 4u;
+  const int c_out = EPI == ESS_EPI_LINEAR ? a.Cout : a.hid;
+  const int split = EPI == ESS_EPI_LINEAR ? a.out_split : 0;
+  const int c_first = split > 0 ? split : c_out;  // channels of the first output tensor
+  const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * c_first * HW, (size_t)c_first * plane_b);
+  const ess_rsrc r_out2 =
+      ess_make_rsrc(split > 0 ? a.out2 + (size_t)n * (c_out - split) * HW : a.out, (size_t)(c_out - split) * plane_b);
+  const ess_rsrc r_sc = ess_make_rsrc(SC ? a.scale : a.out, SC ? (size_t)c_out * 4 : 0);
+  const ess_rsrc r_sh = ess_make_rsrc(a.shift ? a.shift : a.out, a.shift ? (size_t)c_out * 4 : 0);
+  const float* in0 = EPI == ESS_EPI_LINEAR ? a.residual : a.aux0;
+  const ess_rsrc r_in0 = ess_make_rsrc(IN ? in0 + (size_t)n * c_out * HW : a.out, IN ? (size_t)c_out * plane_b : 0);
+  const ess_rsrc r_in1 = ess_make_rsrc(EPI == ESS_EPI_GRU_OUT ? a.aux1 + (size_t)n * c_out * HW : a.out,
+                                       EPI == ESS_EPI_GRU_OUT ? (size_t)c_out * plane_b : 0);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+    float sc[SC ? 16 : 1], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // soffset is outside the hardware range check: the channel bound is folded into voffset
+      const int cu = rowbase + (r & 3) + 8 * (r >> 2);
+      const unsigned vo = cu + 4 * half < c_out ? 16u * half : ESS_OOB;
+      if constexpr (SC) sc[r] = ess_bload(r_sc, vo, (unsigned)cu * 4u);
+      sh[r] = ess_bload(r_sh, vo, (unsigned)cu * 4u);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      float in0v[IN ? 16 : 1], in1v[EPI == ESS_EPI_GRU_OUT ? 16 : 1];
+      if constexpr (IN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cu = rowbase + (r & 3) + 8 * (r >> 2);
+          const unsigned vo = cu + 4 * half < c_out ? voff[nb] : ESS_OOB;
+          in0v[r] = ess_bload(r_in0, vo, (unsigned)cu * plane_b);
+          if constexpr (EPI == ESS_EPI_GRU_OUT) in1v[r] = ess_bload(r_in1, vo, (unsigned)cu * plane_b);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = rowbase + (r & 3) + 8 * (r >> 2);  // + 4*half = output channel
+        float v = acc[mb][nb][r];
+        if constexpr (SC) v *= sc[r];
+        v += sh[r];
+        if constexpr (EPI == ESS_EPI_LINEAR) {
+          if constexpr (IN) v += in0v[r];
+          if (a.act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
+          else if (a.act == ESS_ACT_TANH) v = ess_tanh(v);
+        } else {  // GRU candidate: h' = h (1-u) + tanh(.) u
+          v = in0v[r] * (1.f - in1v[r]) + ess_tanh(v) * in1v[r];
+        }
+        const int co = cu + 4 * half;
+        if (split > 0) {  // the two halves of a wave may straddle the split: tensor and channel are chosen per lane
+          const unsigned pixo = voff[nb] == ESS_OOB ? ESS_OOB : voff[nb] - 4u * half * plane_b;
+          if (co < split) ess_bstore(v, r_out, pixo + (unsigned)co * plane_b, 0);
+          else if (co < c_out) ess_bstore(v, r_out2, pixo + (unsigned)(co - split) * plane_b, 0);
+        } else {
+          ess_bstore(v, r_out, co < c_out ? voff[nb] : ESS_OOB, (unsigned)cu * plane_b);
+        }
+      }
+    }
+  }
+}
+
 template <int MB, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                               int y0, const int (&ly)[NBW]) {
   constexpr int COT = MB * 32;
-  const size_t HW = (size_t)a.Hout * a.Wout;
+  const unsigned HW = (unsigned)(a.Hout * a.Wout);
+  const unsigned plane_b = HW * 4u;  // bytes of one channel plane
+  unsigned voff[NBW];                // byte offset of (channel 4*half, this lane's pixel) inside one sample
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
     const int y = y0 + ly[nb];
-    if (y >= a.Hout || x >= a.Wout) continue;
-    const size_t pix = (size_t)y * a.Wout + x;
+    voff[nb] = (y < a.Hout && x < a.Wout) ? ((unsigned)(y * a.Wout + x) + 4u * half * HW) * 4u : ESS_OOB;
+  }
+  if constexpr (EPI == ESS_EPI_GRU_OUT) {
+    if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, plane_b);
+    else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, plane_b);
+  } else if constexpr (EPI == ESS_EPI_LINEAR) {
+    if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, plane_b);
+    else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, plane_b);
+    else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false>(a, acc, ct, n, half, voff, plane_b);
+    else conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, plane_b);
+  } else {
+    const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
+    const ess_rsrc r_out2 = ess_make_rsrc(a.out2 + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
+    const ess_rsrc r_prev =
+        ess_make_rsrc(a.aux0 ? a.aux0 + (size_t)n * a.hid * HW : a.out, a.aux0 ? (size_t)a.hid * plane_b : 0);
+    const ess_rsrc r_sh = ess_make_rsrc(a.shift, (size_t)(a.n_cout_tiles * COT) * 4);
+    if constexpr (EPI == ESS_EPI_LSTM) {
+      // packed row 8*g + j of a 32-row block = gate g (in, remember, out, cell) of hidden hb*8 + j
+      float cprev[MB][NBW][4];
+      // soffset is outside the hardware range check: a hidden channel past the end is folded into voffset
+      auto vo = [&](int mb, int nb, int jj) { return (ct * MB + mb) * 8 + 4 * half + jj < a.hid ? voff[nb] : ESS_OOB; };
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int rowbase = ct * COT + mb * 32;
-      if constexpr (EPI == ESS_EPI_LINEAR || EPI == ESS_EPI_GRU_OUT) {
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = rowbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co >= a.Cout) continue;
-          float v = acc[mb][nb][r];
-          if (a.scale) v *= a.scale[co];
-          if (a.shift) v += a.shift[co];
-          if constexpr (EPI == ESS_EPI_LINEAR) {
-            const size_t idx = ((size_t)n * a.Cout + co) * HW + pix;
-            if (a.residual) v += a.residual[idx];
-            if (a.act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (a.act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
-            else if (a.act == ESS_ACT_TANH) v = ess_tanh(v);
-            if (a.out_split > 0) {
-              if (co < a.out_split) a.out[((size_t)n * a.out_split + co) * HW + pix] = v;
-              else a.out2[((size_t)n * (a.Cout - a.out_split) + (co - a.out_split)) * HW + pix] = v;
-            } else {
-              a.out[idx] = v;
-            }
-          } else {  // GRU candidate: h' = h (1-u) + tanh(.) u
-            const size_t idx = ((size_t)n * a.hid + co) * HW + pix;
-            const float o = ess_tanh(v), u = a.aux1[idx], h = a.aux0[idx];
-            a.out[idx] = h * (1.f - u) + o * u;
-          }
-        }
-      } else if constexpr (EPI == ESS_EPI_LSTM) {
-        // packed row 8*g + j of this 32-row block = gate g (in, remember, out, cell) of hidden hb*8 + j
-        const int hb = ct * MB + mb;
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int hc = hb * 8 + 4 * half + jj;
-          if (hc >= a.hid) continue;
-          const int pr = rowbase + 4 * half + jj;
-          const float gi = ess_sigmoid(acc[mb][nb][jj] + a.shift[pr]);
-          const float gf = ess_sigmoid(acc[mb][nb][4 + jj] + a.shift[pr + 8]);
-          const float go = ess_sigmoid(acc[mb][nb][8 + jj] + a.shift[pr + 16]);
-          const float gc = ess_tanh(acc[mb][nb][12 + jj] + a.shift[pr + 24]);
-          const size_t idx = ((size_t)n * a.hid + hc) * HW + pix;
-          const float cprev = a.aux0 ? a.aux0[idx] : 0.f;
-          const float cn = gf * cprev + gi * gc;
-          a.out2[idx] = cn;
-          a.out[idx] = go * ess_tanh(cn);
-        }
-      } else {  // ESS_EPI_GRU_UR
-        // packed row 8*q + j: gate q&1 (0 update, 1 reset) of hidden hb*16 + (q>>1)*8 + j
-        const int hb = ct * MB + mb;
+          for (int jj = 0; jj < 4; ++jj)
+            cprev[mb][nb][jj] = ess_bload(r_prev, vo(mb, nb, jj), (unsigned)((ct * MB + mb) * 8 + jj) * plane_b);
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
+      for (int mb = 0; mb < MB; ++mb) {
+        const int rowbase = ct * COT + mb * 32;
+        float sh[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) sh[4 * g + jj] = ess_bload(r_sh, 16u * half, (unsigned)(rowbase + 8 * g + jj) * 4u);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            const int hc = hb * 16 + q2 * 8 + 4 * half + jj;
-            if (hc >= a.hid) continue;
-            const int pr = rowbase + 16 * q2 + 4 * half + jj;
-            const float u = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + a.shift[pr]);
-            const float rr = ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj] + a.shift[pr + 8]);
-            const size_t idx = ((size_t)n * a.hid + hc) * HW + pix;
-            const float h = a.aux0 ? a.aux0[idx] : 0.f;
-            a.out[idx] = u;
-            a.out2[idx] = rr * h;
+            const float gi = ess_sigmoid(acc[mb][nb][jj] + sh[jj]);
+            const float gf = ess_sigmoid(acc[mb][nb][4 + jj] + sh[4 + jj]);
+            const float go = ess_sigmoid(acc[mb][nb][8 + jj] + sh[8 + jj]);
+            const float gc = ess_tanh(acc[mb][nb][12 + jj] + sh[12 + jj]);
+            const float cn = gf * cprev[mb][nb][jj] + gi * gc;
+            const unsigned so = (unsigned)((ct * MB + mb) * 8 + jj) * plane_b;  // hidden channel (+ 4*half in voff)
+            ess_bstore(cn, r_out2, vo(mb, nb, jj), so);
+            ess_bstore(go * ess_tanh(cn), r_out, vo(mb, nb, jj), so);
           }
+        }
+      }
+    } else {  // ESS_EPI_GRU_UR
+      // packed row 8*q + j: gate q&1 (0 update, 1 reset) of hidden hb*16 + (q>>1)*8 + j
+      float hp[MB][NBW][8];
+      auto vo = [&](int mb, int nb, int q2, int jj) {
+        return (ct * MB + mb) * 16 + q2 * 8 + 4 * half + jj < a.hid ? voff[nb] : ESS_OOB;
+      };
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              hp[mb][nb][4 * q2 + jj] =
+                  ess_bload(r_prev, vo(mb, nb, q2, jj), (unsigned)((ct * MB + mb) * 16 + q2 * 8 + jj) * plane_b);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int rowbase = ct * COT + mb * 32;
+        float sh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[r] = ess_bload(r_sh, 16u * half, (unsigned)(rowbase + (r & 3) + 8 * (r >> 2)) * 4u);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              // accumulator register r holds packed row (r&3) + 8(r>>2) + 4 half: update gate r = 8 q2 + jj, reset r + 4
+              const float u = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + sh[8 * q2 + jj]);
+              const float rr = ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj] + sh[8 * q2 + 4 + jj]);
+              const unsigned so = (unsigned)((ct * MB + mb) * 16 + q2 * 8 + jj) * plane_b;
+              ess_bstore(u, r_out, vo(mb, nb, q2, jj), so);
+              ess_bstore(rr * hp[mb][nb][4 * q2 + jj], r_out2, vo(mb, nb, q2, jj), so);
+            }
         }
       }
     }
@@ -216,6 +325,8 @@ inline int validate(const EssConvDesc* d) {
   if (d->epilogue != ESS_EPI_LINEAR)
     ESS_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->out_split == 0, "conv: recurrent epilogues are 3x3 s1");
   ESS_CHECK_ARG(d->out_split >= 0 && d->out_split < d->C_out, "conv: bad out_split");
+  ESS_CHECK_ARG((int64_t)d->C_out * d->H_out * d->W_out * 4 < (int64_t)1 << 31,
+                "conv: one output sample must stay below 2 GiB (32-bit buffer offsets in the epilogue)");
   return ESS_OK;
 }
 
