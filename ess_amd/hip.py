@@ -40,6 +40,7 @@ EXPORTS = [
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
+    'ess_voxel_grid_trilinear', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
 ]
 
 
@@ -76,6 +77,8 @@ def lib():
         L.ess_task_loss_workspace.argtypes = [c_int32]
         L.ess_norm_workspace.restype = c_size_t
         L.ess_norm_workspace.argtypes = [c_int32]
+        L.ess_voxel_normalize_workspace.restype = c_size_t
+        L.ess_voxel_normalize_workspace.argtypes = [c_int32]
         P, F, I, I64 = c_void_p, c_float, c_int32, c_int64
         D = POINTER(EssConvDesc)
         sig = {
@@ -97,6 +100,9 @@ def lib():
             'ess_l1_loss': [P, P, P, P, F, I64, P, P],
             'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
             'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
+            'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P],
+            'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
+            'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -279,6 +285,56 @@ def event_normalize(x):
     ws = workspace(64, x.device, 'evnorm')
     _check(lib().ess_event_normalize(ptr(x), ptr(y), x.numel(), c_void_p(ws.data_ptr()), stream()), 'ess_event_normalize')
     return y
+
+
+# ------------------------------------------------------------------------------------------ events -> voxel grids
+def _slice_offsets(offsets, n_events, device):
+    off = torch.as_tensor(offsets, dtype=torch.int64)
+    if off.dim() != 1 or off.numel() < 2 or int(off[0]) != 0 or int(off[-1]) != n_events or bool((off[1:] < off[:-1]).any()):
+        raise EssHipError('slice_offsets must be non-decreasing, start at 0 and end at the number of events')
+    return off.to(device)
+
+
+def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, normalize=False):
+    """[n_slices, channels, H, W] grids of VoxelGrid.convert for every slice of a batch in one launch."""
+    n = x.numel()
+    for a in (x, y, pol, t):
+        ptr(a)
+        if a.numel() != n or a.dim() != 1:
+            raise EssHipError('x, y, pol, t must be 1-D and of equal length')
+    off = _slice_offsets(slice_offsets, n, x.device)
+    ns = off.numel() - 1
+    out = torch.empty(ns, channels, height, width, dtype=torch.float32, device=x.device)
+    _check(lib().ess_voxel_grid_trilinear(ptr(x), ptr(y), ptr(pol), ptr(t), ptr(off, torch.int64), n, ns, channels, height, width,
+                                          ptr(out), stream()), 'ess_voxel_grid_trilinear')
+    if normalize:
+        voxel_normalize_(out, mode=0)
+    return out
+
+
+def voxel_grid_temporal(x, y, t, pol, slice_offsets, bins, height, width, separate_pol=True, normalize=False):
+    """generate_voxel_grid for every slice of a batch: x, y int32 pixels, t float64, pol float32 (+1/-1, 0 = -1)."""
+    n = x.numel()
+    off = _slice_offsets(slice_offsets, n, x.device)
+    ns = off.numel() - 1
+    out = torch.empty(ns, (2 if separate_pol else 1) * bins, height, width, dtype=torch.float32, device=x.device)
+    _check(lib().ess_voxel_grid_temporal(ptr(x, torch.int32), ptr(y, torch.int32), ptr(t, torch.float64), ptr(pol),
+                                         ptr(off, torch.int64), n, ns, bins, height, width, int(separate_pol), ptr(out), stream()),
+           'ess_voxel_grid_temporal')
+    if normalize:
+        voxel_normalize_(out, mode=1)
+    return out
+
+
+def voxel_normalize_(grids, mode):
+    """In-place per-slice (dim 0) normalisation over the non-zero voxels; mode 0 = VoxelGrid, 1 = normalize_voxel_grid."""
+    ns = grids.shape[0]
+    L = lib()
+    nbytes = L.ess_voxel_normalize_workspace(ns)
+    ws = workspace(nbytes, grids.device, 'voxnorm')
+    _check(L.ess_voxel_normalize(ptr(grids), ns, grids[0].numel(), mode, c_void_p(ws.data_ptr()), nbytes, stream()),
+           'ess_voxel_normalize')
+    return grids
 
 
 # ------------------------------------------------------------------------------------------ losses / optimiser / metrics

@@ -157,6 +157,30 @@ int ess_add(const float* a, const float* b, float* y, int64_t n, ess_stream_t st
  * workspace: >= 32 bytes, zeroed by the call.  No host synchronisation.                             */
 int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream);
 
+/* ---- events -> voxel grid on the device (the step in front of the encoder) --------------------
+ * All slices of a batch in one launch: events concatenated structure-of-arrays, slice s = [slice_offsets[s],
+ * slice_offsets[s+1]) (int64, device, n_slices+1 entries); `out` is zeroed by the call.
+ *
+ * ess_voxel_grid_trilinear replaces VoxelGrid.convert (DSEC/dataset/representations.py:15-55) as driven by
+ * Sequence.events_to_voxel_grid (DSEC/dataset/sequence.py:144-154): x, y float pixel coordinates, pol in {0,1},
+ * t = any increasing fp32 time; each slice is mapped to [0, channels-1] from its own first/last event.
+ * out: [n_slices][channels][height][width].                                                          */
+int ess_voxel_grid_trilinear(const float* x, const float* y, const float* pol, const float* t,
+                             const int64_t* slice_offsets, int64_t n_events, int32_t n_slices, int32_t channels,
+                             int32_t height, int32_t width, float* out, ess_stream_t stream);
+/* ess_voxel_grid_temporal replaces generate_voxel_grid (datasets/data_util.py:54-126): integer pixels, fp64
+ * timestamps, polarity +1 / -1 (0 counts as -1), bilinear in time only.
+ * out: [n_slices][separate_pol ? 2*bins : bins][height][width] (positive bins first; else positive - negative). */
+int ess_voxel_grid_temporal(const int32_t* x, const int32_t* y, const double* t, const float* pol,
+                            const int64_t* slice_offsets, int64_t n_events, int32_t n_slices, int32_t bins,
+                            int32_t height, int32_t width, int32_t separate_pol, float* out, ess_stream_t stream);
+/* Per-slice normalisation over the non-zero voxels, in place.  mode 0: VoxelGrid(normalize=True)
+ * (representations.py:45-53: unbiased std, divide only if std > 0); mode 1: normalize_voxel_grid
+ * (data_util.py:38-51: sqrt(E[v^2]-mean^2), no guard).  workspace: ess_voxel_normalize_workspace() bytes.        */
+size_t ess_voxel_normalize_workspace(int32_t n_slices);
+int ess_voxel_normalize(float* grid, int32_t n_slices, int64_t elems_per_slice, int32_t mode, void* workspace,
+                        size_t workspace_bytes, ess_stream_t stream);
+
 /* TaskLoss = Dice + CrossEntropy (utils/loss_functions.py:6-24,96-135), forward AND gradient w.r.t.
  * logits in one pass pair.  logits [N][K][H][W], labels int64 [N][H][W].  loss: 1 float.
  * dlogits (nullable): d(loss*loss_scale)/dlogits.  workspace: ess_task_loss_workspace(K) bytes.     */

@@ -349,6 +349,49 @@ def gold_train_steps(R, out):
     out['uda_steps'] = dict(K=K, T=T, C=C, H=H, W=W, B=B, wseed=700, fseed=702, runs=uda)
 
 
+def _load_by_path(name, rel):
+    """datasets/ and DSEC/ have no __init__.py (and `datasets` is shadowed by HuggingFace): load the file itself"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gold_voxel(out):
+    """events -> voxel grid.  Reference: VoxelGrid.convert
+    (DSEC/dataset/representations.py:15-55) driven as Sequence.events_to_voxel_grid does (sequence.py:144-154), and
+    generate_voxel_grid (datasets/data_util.py:54-126).  data_util uses the removed alias np.int: restored here."""
+    import numpy as np
+    if not hasattr(np, 'int'):
+        np.int = int
+    rep = _load_by_path('ref_representations', 'DSEC/dataset/representations.py')
+    du = _load_by_path('ref_data_util', 'datasets/data_util.py')
+    H, W = 48, 64
+    tri, tem = [], []
+    for n, C, norm, seed in [(20000, 2, False, 1), (20000, 5, True, 2), (3000, 2, True, 3), (3, 5, False, 4), (1, 2, False, 5),
+                             (500, 3, True, 6)]:
+        x, y, pol, t = O.synth_events(n, H, W, seed)
+        if seed == 6:
+            t[:] = t[0]  # degenerate slice: one timestamp -> 0/0 -> nothing lands in the grid
+        tf = (t - t[0]).numpy().astype('float32')  # sequence.py:145-146
+        with np.errstate(all='ignore'):
+            tf = torch.from_numpy(tf / tf[-1])
+        grid = rep.VoxelGrid(C, H, W, norm).convert(x, y, pol, tf)
+        assert torch.equal(torch.nan_to_num(grid), torch.nan_to_num(O.voxel_grid_trilinear(x, y, pol, tf, C, H, W, norm)))
+        tri.append(dict(n=n, C=C, normalize=norm, seed=seed, degenerate=seed == 6, grid=grid.clone()))
+    for n, nb, sep, seed, pm in [(20000, 5, True, 11, False), (20000, 5, False, 12, True), (7, 2, True, 13, False),
+                                 (4000, 3, True, 14, True)]:
+        x, y, pol, t = O.synth_events(n, H, W, seed)
+        p = pol.double() * 2 - 1 if pm else pol.double()
+        ev = torch.stack([x.double().floor(), y.double().floor(), t.double(), p], 1).numpy()
+        grid = torch.from_numpy(du.generate_voxel_grid(ev.copy(), (H, W), nb, sep))
+        assert torch.equal(grid, O.voxel_grid_temporal(ev.copy(), (H, W), nb, sep))
+        tem.append(dict(n=n, bins=nb, separate_pol=sep, seed=seed, pm=pm, grid=grid.clone(),
+                        normalized=du.normalize_voxel_grid(grid.clone())))
+    out['voxel'] = dict(H=H, W=W, trilinear=tri, temporal=tem)
+
+
 def main():
     torch.manual_seed(6)
     torch.set_num_threads(8)
@@ -362,6 +405,7 @@ def main():
     gold_losses(R, out)
     gold_radam(R, out)
     gold_train_steps(R, out)
+    gold_voxel(out)
     for k, v in out.items():
         path = os.path.join(HERE, f'{k}.pt')
         torch.save(v, path)

@@ -410,3 +410,94 @@ def test_argmax_confusion(H, golden):
     assert torch.equal(conf.cpu(), g['cm'])
     miou, _, acc = O.miou_acc(conf.cpu())
     assert miou.item() == g['miou'].item()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# events -> voxel grids.  fp32 atomics change only the ORDER of the additions into a voxel: tolerance
+# 1e-5 of the grid's max |value| (each contribution is computed in the reference's operation order and is bit-identical).
+def _slice_time(t):
+    import numpy as np
+    tf = (t - t[0]).numpy().astype('float32')
+    with np.errstate(all='ignore'):
+        return torch.from_numpy(tf / tf[-1])
+
+
+def _vox_close(a, b, tol=1e-5):
+    a, b = a.cpu().double(), b.double()
+    return (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+def test_voxel_trilinear_golden_batch(H, golden):
+    """every golden slice (ragged lengths, a 1-event and a one-timestamp slice) in ONE launch"""
+    from ess_amd.datasets.representations import VoxelGrid
+    g = golden('voxel')
+    for C in sorted({c['C'] for c in g['trilinear']}):
+        for norm in (False, True):
+            cases = [c for c in g['trilinear'] if c['C'] == C and c['normalize'] == norm]
+            if not cases:
+                continue
+            xs, ys, ps, ts, offs = [], [], [], [], [0]
+            for c in cases:
+                x, y, pol, t = O.synth_events(c['n'], g['H'], g['W'], c['seed'])
+                if c['degenerate']:
+                    t[:] = t[0]
+                xs.append(x); ys.append(y); ps.append(pol); ts.append(_slice_time(t)); offs.append(offs[-1] + c['n'])
+            vg = VoxelGrid(C, g['H'], g['W'], norm)
+            out = vg.convert_batch(dev(torch.cat(xs)), dev(torch.cat(ys)), dev(torch.cat(ps)), dev(torch.cat(ts)), offs)
+            for i, c in enumerate(cases):
+                assert _vox_close(out[i], c['grid'], 1e-5 if not norm else 1e-4), (C, norm, c['n'])
+            one = vg.convert(dev(xs[0]), dev(ys[0]), dev(ps[0]), dev(ts[0]))  # the reference's single-slice signature
+            assert _vox_close(one, cases[0]['grid'], 1e-5 if not norm else 1e-4)
+
+
+def test_voxel_temporal_golden(H, golden):
+    from ess_amd.datasets import data_util
+    g = golden('voxel')
+    for c in g['temporal']:
+        x, y, pol, t = O.synth_events(c['n'], g['H'], g['W'], c['seed'])
+        p = pol.double() * 2 - 1 if c['pm'] else pol.double()
+        ev = torch.stack([x.double().floor(), y.double().floor(), t.double(), p], 1)
+        out = data_util.generate_voxel_grid(ev.cuda(), (g['H'], g['W']), c['bins'], c['separate_pol'])
+        assert _vox_close(out, c['grid'])
+        assert _vox_close(data_util.normalize_voxel_grid(out), c['normalized'], 1e-4)
+
+
+def test_voxel_trilinear_properties_full_size(H):
+    """DSEC size (B=8 x T=5 slices of 100k events, 2 bins, 480x640): size-independent checks -- linearity in the event
+    set (grid(A u B) = grid(A) + grid(B) when both halves span the same time range), polarity antisymmetry, and the
+    mass identity: an interior event spreads exactly (2 pol - 1) over its 8 corners."""
+    Hh, Ww, C, n, S = 480, 640, 2, 100_000, 40
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(S * n, generator=gen) * (Ww - 3) + 1)
+    y = (torch.rand(S * n, generator=gen) * (Hh - 3) + 1)
+    pol = (torch.rand(S * n, generator=gen) < 0.5).float()
+    t = torch.rand(S, n, generator=gen).sort(dim=1).values
+    t[:, 0], t[:, -1] = 0.0, 1.0
+    t = t.reshape(-1)
+    offs = [i * n for i in range(S + 1)]
+    full = H.voxel_grid_trilinear(dev(x), dev(y), dev(pol), dev(t), offs, C, Hh, Ww)
+    assert full.shape == (S, C, Hh, Ww)
+    # mass: all events are interior in x, y and t in [0, C-1] -> every event contributes exactly its value
+    mass = (2 * pol - 1).view(S, n).double().sum(1)
+    assert (full.double().sum(dim=(1, 2, 3)).cpu() - mass).abs().max().item() < 0.05  # fp32 sums of 1e5 terms
+    # antisymmetry: flipping every polarity negates the grid
+    neg = H.voxel_grid_trilinear(dev(x), dev(y), dev(1 - pol), dev(t), offs, C, Hh, Ww)
+    assert (full + neg).abs().max().item() < 1e-4
+    # linearity on slice 0: interior events split in two sets that keep the first/last event (time range unchanged)
+    keep = torch.zeros(n, dtype=torch.bool); keep[0] = keep[-1] = True
+    a = keep | (torch.rand(n, generator=gen) < 0.5)
+    b = keep | ~a
+    def grid_of(m):
+        return H.voxel_grid_trilinear(dev(x[:n][m]), dev(y[:n][m]), dev(pol[:n][m]), dev(t[:n][m]), [0, int(m.sum())], C, Hh, Ww)[0]
+    ends = grid_of(keep)
+    assert (grid_of(a) + grid_of(b) - ends - full[0]).abs().max().item() < 1e-4
+
+
+def test_voxel_refuses_bad_input(H):
+    x = torch.zeros(4, device='cuda')
+    with pytest.raises(H.EssHipError):
+        H.voxel_grid_trilinear(x, x, x, x, [0, 3], 2, 8, 8)          # offsets do not cover the events
+    with pytest.raises(H.EssHipError):
+        H.voxel_grid_trilinear(x.cpu(), x.cpu(), x.cpu(), x.cpu(), [0, 4], 2, 8, 8)  # no CPU path
+    empty = H.voxel_grid_trilinear(x[:0], x[:0], x[:0], x[:0], [0, 0], 2, 8, 8)      # an empty slice is a zero grid
+    assert empty.shape == (1, 2, 8, 8) and not empty.any()

@@ -175,3 +175,34 @@ def test_uda_steps(golden, branch):
         if s == 0:  # BN running statistics after the two train-mode forwards of step 1
             for k in ('encoder_scale_1.1.running_mean', 'encoder_scale_3.1.bn2.running_var'):
                 assert stats_close(stats(sd_f[k]), gs['front'][k], 1e-4), k
+
+
+# ---- events -> voxel grids (oracle pinned on the reference's VoxelGrid.convert / generate_voxel_grid)
+def _slice_time(t):
+    import numpy as np
+    tf = (t - t[0]).numpy().astype('float32')  # Sequence.events_to_voxel_grid, sequence.py:145-146
+    with np.errstate(all='ignore'):
+        return torch.from_numpy(tf / tf[-1])
+
+
+def test_voxel_grid_trilinear_oracle(golden):
+    g = golden('voxel')
+    for c in g['trilinear']:
+        x, y, pol, t = O.synth_events(c['n'], g['H'], g['W'], c['seed'])
+        if c['degenerate']:
+            t[:] = t[0]
+        out = O.voxel_grid_trilinear(x, y, pol, _slice_time(t), c['C'], g['H'], g['W'], c['normalize'])
+        assert torch.equal(out, c['grid'])  # same scatter order on the host: bit-exact
+        if c['degenerate'] or c['n'] == 1:
+            assert not out.any()  # 0/0 time: nothing lands in the grid
+
+
+def test_voxel_grid_temporal_oracle(golden):
+    g = golden('voxel')
+    for c in g['temporal']:
+        x, y, pol, t = O.synth_events(c['n'], g['H'], g['W'], c['seed'])
+        p = pol.double() * 2 - 1 if c['pm'] else pol.double()
+        ev = torch.stack([x.double().floor(), y.double().floor(), t.double(), p], 1).numpy()
+        out = O.voxel_grid_temporal(ev, (g['H'], g['W']), c['bins'], c['separate_pol'])
+        assert torch.equal(out, c['grid'])
+        assert torch.equal(O.event_normalize(out.clone()), c['normalized'])  # normalize_voxel_grid == a1's formula
