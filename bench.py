@@ -76,7 +76,7 @@ class HipEvents:
 
 
 def roofline_gate_kernels(args, device):
-    """Time the dominant kernel -- conv_f32_kernel<3,1,2,LSTM>: 3x3 gate conv over cat(x,h) + LSTM epilogue -- on the
+    """Time the dominant kernel -- the fused ConvLSTM step: 3x3 gate conv over cat(x,h) + LSTM epilogue -- on the
     three encoder levels of the workload, with HIP events on the launch stream.  Algorithmic FLOPs per launch =
     2 * B*H*W * 9 * (2*hid) * (4*hid) (2.265e10 MACs per sample per level at 480x640)."""
     from ess_amd import hip
@@ -93,13 +93,19 @@ def roofline_gate_kernels(args, device):
         x, h, c = [torch.randn(B, hid, H, W, generator=g).to(device) for _ in range(3)]
         pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, bias)
         ho, co = torch.empty_like(h), torch.empty_like(c)
-        for _ in range(3):
-            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co)
-        reps = 10
+        kw = {}
+        if args.compute == 'bf16':
+            # exactly the product launch (e2vid/model/submodules.py ConvLSTM.forward): x and h staged from the BF16_C8
+            # copies their producers left, and a BF16_C8 copy of h' written for the next time step
+            x, h = hip.to_bf16_c8(x), hip.to_bf16_c8(h)
+            kw = dict(src_fmt=hip.FMT_BF16_C8, out_bf=hip.bf16_c8_empty(B, hid, H, W, device))
+        for _ in range(5):
+            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, **kw)
+        reps = 20
         e0, e1 = ev.event(), ev.event()
         ev.record(e0, stream)
         for _ in range(reps):
-            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co)
+            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, **kw)
         ev.record(e1, stream)
         ms = ev.elapsed_ms(e0, e1) / reps
         flops = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)
@@ -114,11 +120,11 @@ def roofline_gate_kernels(args, device):
             t = json.load(f).get(f'{args.compute}/{B}/{args.height}x{args.width}')
         if t:
             traffic = {'bytes': sum(t['per_level_bytes']), 'algorithmic_bytes': sum(t['algorithmic_bytes']),
-                       'source': 'profiles/r1_gate_kernel_pmc.txt (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'}
+                       'source': 'profiles/r1_gate_kernel_pmc_c8.txt (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'}
     except OSError:
         pass
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'kernel': 'conv_bf16_ws_k3s1_kernel<2,EPI_LSTM>' if bf16 else 'conv_f32_kernel<3,1,2,EPI_LSTM,8>',
+    return {'bound': 'mfma', 'kernel': 'conv_bf16_ws_k3s1_kernel<MB,EPI_LSTM,BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,EPI_LSTM,8>',
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
             'traffic': traffic, 'per_level': per_level,
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +

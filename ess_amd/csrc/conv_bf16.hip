@@ -218,7 +218,7 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
 // shadow of the matrix pipe instead of in front of it.  LDS is double-buffered; ONE barrier per channel chunk:
 //   iteration ch: consumers read buffer ch&1 | producers convert+write chunk ch+1 into buffer (ch+1)&1 (its last
 //   readers passed the previous barrier) and then issue the loads of chunk ch+2, which land during iteration ch+1.
-template <int MB, int EPI>
+template <int MB, int EPI, bool SRCBF>
 __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16;
@@ -238,6 +238,79 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   const int y0 = ty * TH, x0 = tx * TW;
   const int bufsz = CB8 * a.plane + WSZ;  // one stage: input tile + weight slab (16-byte units)
 
+  if (role == 1 && SRCBF) {
+    // ------------------------------------------------------------------ producer, BF16_C8 sources
+    // The sources are already bf16 pixel vectors ([N][C/8][H][W][8]): staging one is ONE 16-byte load and ONE
+    // ds_write_b128, no conversion.  A halo row of the tile is 34 x 16 B contiguous, so an 8-channel block costs ~5
+    // cache lines per row instead of 8 x 3 with fp32 NCHW planes -- the L1 line rate, not HBM, bounded the fp32 staging.
+    // Padding / overhang positions read a clamped address and are zeroed by a mask; tail channels are zero in memory.
+    const int iy0 = y0 - 1, ix0 = x0 - 1;
+    const size_t hw = (size_t)a.Hin * a.Win;
+    const int nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
+    const u32x4* s0 = (const u32x4*)a.src0 + (size_t)n * nb0 * hw;
+    const u32x4* s1 = a.C1 ? (const u32x4*)a.src1 + (size_t)n * nb1 * hw : s0;
+    unsigned v_pos[KPC], v_keep[KPC];
+    int v_lds[KPC];
+    const int npos = a.IH * a.IW;
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) {
+      const int vi = tid + k * 256;
+      const int iy = vi / a.IW, ix = vi - iy * a.IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool in = vi < npos && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+      v_lds[k] = vi < npos ? iy * a.row_pitch + ix : -1;
+      v_pos[k] = in ? (unsigned)(gy * a.Win + gx) : 0u;
+      v_keep[k] = in ? 0xffffffffu : 0u;
+    }
+    u32x4 pre[CB8][KPC];
+    u32x4 wpre[WV];
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb) {
+        const int c0 = ch * CK + cb * 8;                 // wave-uniform
+        const bool first = c0 < a.C0 || a.C1 == 0;       // a block never straddles the sources (C0 % 8 == 0)
+        const int bi = (first ? c0 : c0 - a.C0) >> 3, nbs = first ? nb0 : nb1;
+        const u32x4* sp = (first ? s0 : s1) + (size_t)(bi < nbs ? bi : 0) * hw;  // blocks past the end: clamped, masked
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) pre[cb][k] = sp[v_pos[k]];
+      }
+      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+    };
+    auto commit = [&](int ch, int buf) {
+      u32x4* in_t = smem16 + buf * bufsz;
+      u32x4* w_t = in_t + CB8 * a.plane;
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb) {
+        const int c0 = ch * CK + cb * 8;
+        const bool first = c0 < a.C0 || a.C1 == 0;
+        const unsigned blk_ok = ((first ? c0 : c0 - a.C0) >> 3) < (first ? nb0 : nb1) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) {
+          const unsigned m = v_keep[k] & blk_ok;
+          u32x4 v = pre[cb][k];
+          v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+          if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = v;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+    };
+    load_chunk(0);
+    commit(0, 0);
+    if (a.n_chunks > 1) load_chunk(1);
+    __syncthreads();  // stage 0 is ready
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+      if (ch + 1 < a.n_chunks) {
+        commit(ch + 1, (ch + 1) & 1);
+        if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   if (role == 1) {
     // ------------------------------------------------------------------------------------------- producer
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
@@ -357,9 +430,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
 }
 
-template <int MB>
+template <int MB, bool SRCBF>
 void launch_ws(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
-#define ESS_WS(E_) { ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, E_>, lds); hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, E_>), grid, dim3(512), lds, st, a); }
+#define ESS_WS(E_) { ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>, lds); hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>), grid, dim3(512), lds, st, a); }
   switch (epi) {
     case ESS_EPI_LSTM: ESS_WS(ESS_EPI_LSTM) break;
     case ESS_EPI_GRU_UR: ESS_WS(ESS_EPI_GRU_UR) break;
@@ -367,6 +440,12 @@ void launch_ws(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& 
     default: ESS_WS(ESS_EPI_LINEAR) break;
   }
 #undef ESS_WS
+}
+template <bool SRCBF>
+void launch_ws_mb(int mb, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if (mb == 4) launch_ws<4, SRCBF>(epi, grid, lds, st, a);
+  else if (mb == 2) launch_ws<2, SRCBF>(epi, grid, lds, st, a);
+  else launch_ws<1, SRCBF>(epi, grid, lds, st, a);
 }
 
 template <int KS, int S, int MB, int CB8>
@@ -419,12 +498,16 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   if (use_ws && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
     if (lds2 <= 160 * 1024) {
-      if (mb == 4) launch_ws<4>(d->epilogue, grid, lds2, st, a);
-      else if (mb == 2) launch_ws<2>(d->epilogue, grid, lds2, st, a);
-      else launch_ws<1>(d->epilogue, grid, lds2, st, a);
+      if (a.fmt0 == ESS_FMT_BF16_C8) {
+        ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
+        launch_ws_mb<true>(mb, d->epilogue, grid, lds2, st, a);
+      } else {
+        launch_ws_mb<false>(mb, d->epilogue, grid, lds2, st, a);
+      }
       return ess_launch_status("conv2d_forward(bf16, wave-specialised)");
     }
   }
+  ESS_CHECK_ARG(a.fmt0 == ESS_FMT_F32_NCHW, "conv(bf16): BF16_C8 sources are only staged by the wave-specialised 3x3 kernel");
   const int key = d->ksize * 10 + d->stride;
   switch (key) {
     case 11: launch_mb<1, 1>(mb, pl.ck / 8, d->epilogue, grid, pl.lds_bytes, st, a); break;

@@ -25,6 +25,8 @@ struct ConvKArgs {
   int IH, IW, row_pitch, par_off, plane;
   int ck, n_chunks;
   int act, hid, out_split;
+  void* out_bf;   // optional BF16_C8 copy of `out`
+  int fmt0, fmt1;  // ESS_FMT_* of the sources
 };
 
 
@@ -49,14 +51,25 @@ __device__ __forceinline__ void ess_bstore(float v, ess_rsrc r, unsigned voff, u
 
 // linear / GRU-candidate epilogue, specialised on what exists (per-row scale, a second input) so that the common
 // bias-only case keeps no dead registers
+// BF16_C8 copy of an output: this lane's 4 consecutive channels (4*half .. 4*half+3 of 8-channel block `blk`) of pixel
+// `pix` are 8 bytes; the two half-waves interleave to full 16-byte pixel vectors, 32 pixels = 512 contiguous bytes.
+__device__ __forceinline__ void ess_store_bf16x4(void* base, size_t sample_blk0, int blk, unsigned HW, int pix, int half,
+                                                 float v0, float v1, float v2, float v3) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 b;
+  b[0] = (__bf16)v0; b[1] = (__bf16)v1; b[2] = (__bf16)v2; b[3] = (__bf16)v3;
+  *(uint2*)((char*)base + ((sample_blk0 + blk) * HW + pix) * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
+}
+
 template <int MB, int EPI, bool SC, bool IN>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                   const unsigned (&voff)[NBW], unsigned plane_b) {
+                                                   const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned plane_b) {
   constexpr int COT = MB * 32;
   const unsigned HW = plane_b / 4u;
   const int c_out = EPI == ESS_EPI_LINEAR ? a.Cout : a.hid;
   const int split = EPI == ESS_EPI_LINEAR ? a.out_split : 0;
   const int c_first = split > 0 ? split : c_out;  // channels of the first output tensor
+  const int nblk = (c_out + 7) >> 3;              // 8-channel blocks of the BF16_C8 copy
   const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * c_first * HW, (size_t)c_first * plane_b);
   const ess_rsrc r_out2 =
       ess_make_rsrc(split > 0 ? a.out2 + (size_t)n * (c_out - split) * HW : a.out, (size_t)(c_out - split) * plane_b);
@@ -90,6 +103,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
           if constexpr (EPI == ESS_EPI_GRU_OUT) in1v[r] = ess_bload(r_in1, vo, (unsigned)cu * plane_b);
         }
       }
+      float q[4];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int cu = rowbase + (r & 3) + 8 * (r >> 2);  // + 4*half = output channel
@@ -105,6 +119,11 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
           v = in0v[r] * (1.f - in1v[r]) + ess_tanh(v) * in1v[r];
         }
         const int co = cu + 4 * half;
+        if (a.out_bf) {  // wave-uniform
+          q[r & 3] = co < c_out ? v : 0.f;  // tail channels of the last block are zero
+          if ((r & 3) == 3 && pixi[nb] >= 0 && (rowbase >> 3) + (r >> 2) < nblk)
+            ess_store_bf16x4(a.out_bf, (size_t)n * nblk, (rowbase >> 3) + (r >> 2), HW, pixi[nb], half, q[0], q[1], q[2], q[3]);
+        }
         if (split > 0) {  // the two halves of a wave may straddle the split: tensor and channel are chosen per lane
           const unsigned pixo = voff[nb] == ESS_OOB ? ESS_OOB : voff[nb] - 4u * half * plane_b;
           if (co < split) ess_bstore(v, r_out, pixo + (unsigned)co * plane_b, 0);
@@ -124,19 +143,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
   const unsigned HW = (unsigned)(a.Hout * a.Wout);
   const unsigned plane_b = HW * 4u;  // bytes of one channel plane
   unsigned voff[NBW];                // byte offset of (channel 4*half, this lane's pixel) inside one sample
+  int pixi[NBW];                     // pixel index, -1 outside the image
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
     const int y = y0 + ly[nb];
-    voff[nb] = (y < a.Hout && x < a.Wout) ? ((unsigned)(y * a.Wout + x) + 4u * half * HW) * 4u : ESS_OOB;
+    const bool inb = y < a.Hout && x < a.Wout;
+    pixi[nb] = inb ? y * a.Wout + x : -1;
+    voff[nb] = inb ? ((unsigned)pixi[nb] + 4u * half * HW) * 4u : ESS_OOB;
   }
   if constexpr (EPI == ESS_EPI_GRU_OUT) {
-    if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, plane_b);
-    else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, plane_b);
+    if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
-    if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, plane_b);
-    else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, plane_b);
-    else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false>(a, acc, ct, n, half, voff, plane_b);
-    else conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, plane_b);
+    if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else {
     const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
     const ess_rsrc r_out2 = ess_make_rsrc(a.out2 + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
@@ -165,6 +187,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           for (int jj = 0; jj < 4; ++jj) sh[4 * g + jj] = ess_bload(r_sh, 16u * half, (unsigned)(rowbase + 8 * g + jj) * 4u);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
+          float hq[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const float gi = ess_sigmoid(acc[mb][nb][jj] + sh[jj]);
@@ -173,9 +196,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             const float gc = ess_tanh(acc[mb][nb][12 + jj] + sh[12 + jj]);
             const float cn = gf * cprev[mb][nb][jj] + gi * gc;
             const unsigned so = (unsigned)((ct * MB + mb) * 8 + jj) * plane_b;  // hidden channel (+ 4*half in voff)
+            const float hn = go * ess_tanh(cn);
             ess_bstore(cn, r_out2, vo(mb, nb, jj), so);
-            ess_bstore(go * ess_tanh(cn), r_out, vo(mb, nb, jj), so);
+            ess_bstore(hn, r_out, vo(mb, nb, jj), so);
+            hq[jj] = (ct * MB + mb) * 8 + 4 * half + jj < a.hid ? hn : 0.f;
           }
+          if (a.out_bf && pixi[nb] >= 0 && ct * MB + mb < ((a.hid + 7) >> 3))  // hidden block ct*MB+mb, channels 4*half..+3
+            ess_store_bf16x4(a.out_bf, (size_t)n * ((a.hid + 7) >> 3), ct * MB + mb, HW, pixi[nb], half, hq[0], hq[1], hq[2], hq[3]);
         }
       }
     } else {  // ESS_EPI_GRU_UR
@@ -325,6 +352,15 @@ inline int validate(const EssConvDesc* d) {
   if (d->epilogue != ESS_EPI_LINEAR)
     ESS_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->out_split == 0, "conv: recurrent epilogues are 3x3 s1");
   ESS_CHECK_ARG(d->out_split >= 0 && d->out_split < d->C_out, "conv: bad out_split");
+  ESS_CHECK_ARG((d->fmt0 == ESS_FMT_F32_NCHW || d->fmt0 == ESS_FMT_BF16_C8) && (d->fmt1 == ESS_FMT_F32_NCHW || d->fmt1 == ESS_FMT_BF16_C8),
+                "conv: bad source format");
+  if (d->fmt0 != ESS_FMT_F32_NCHW || d->fmt1 != ESS_FMT_F32_NCHW) {
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->mode0 == ESS_SRC_DIRECT &&
+                      (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT),
+                  "conv: BF16_C8 sources need bf16 compute, 3x3 stride 1 pad 1 and DIRECT sources");
+    ESS_CHECK_ARG(d->C1 == 0 || d->fmt0 == d->fmt1, "conv: both sources of a concat must use the same format");
+    ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "conv: the first BF16_C8 source of a concat must have a multiple of 8 channels");
+  }
   ESS_CHECK_ARG((int64_t)d->C_out * d->H_out * d->W_out * 4 < (int64_t)1 << 31,
                 "conv: one output sample must stay below 2 GiB (32-bit buffer offsets in the epilogue)");
   return ESS_OK;

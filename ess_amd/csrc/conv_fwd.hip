@@ -217,9 +217,9 @@ extern "C" int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const 
   return ess_launch_status("pack_rows");
 }
 
-extern "C" int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const float* src1, const void* packed_w,
+extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
                                   const float* scale, const float* shift, const float* residual, const float* aux0,
-                                  const float* aux1, float* out, float* out2, ess_stream_t stream) {
+                                  const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && packed_w && out, "conv: null pointer");
@@ -228,12 +228,16 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const
     ESS_CHECK_ARG(shift && out2, "conv: recurrent epilogue needs bias and second output");
   if (d->epilogue == ESS_EPI_GRU_OUT) ESS_CHECK_ARG(aux0 && aux1, "conv: GRU_OUT needs h_prev and u");
   if (d->out_split > 0) ESS_CHECK_ARG(out2, "conv: out_split needs out2");
+  if (out_bf16)
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->out_split == 0 && d->epilogue != ESS_EPI_GRU_UR,
+                  "conv: the BF16_C8 output copy exists for bf16 compute, LINEAR / LSTM / GRU_OUT epilogues, no out_split");
   EssConvPlan pl;
   make_plan(d, &pl);
   ESS_CHECK_ARG(pl.lds_bytes <= 160 * 1024, "conv: LDS tile %d B exceeds 160 KiB", pl.lds_bytes);
   const Geom g = choose_geom(d);
   ConvKArgs a{};
-  a.src0 = src0; a.src1 = src1; a.wpk = packed_w; a.scale = scale; a.shift = shift; a.residual = residual;
+  a.src0 = (const float*)src0; a.src1 = (const float*)src1; a.wpk = packed_w;
+  a.out_bf = out_bf16; a.fmt0 = d->fmt0; a.fmt1 = d->C1 ? d->fmt1 : d->fmt0; a.scale = scale; a.shift = shift; a.residual = residual;
   a.aux0 = aux0; a.aux1 = aux1; a.out = out; a.out2 = out2;
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;

@@ -119,3 +119,32 @@ extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* wo
   hipLaunchKernelGGL(evnorm_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, (const double*)workspace);
   return ess_launch_status("event_normalize");
 }
+
+
+// fp32 NCHW -> BF16_C8 ([N][ceil(C/8)][H][W][8] bfloat16, tail channels zero): one thread = one pixel vector.
+namespace {
+__global__ __launch_bounds__(256) void to_bf16_c8_kernel(const float* __restrict__ x, uint4* __restrict__ y, int C, int64_t hw,
+                                                         int64_t total) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int nblk = (C + 7) >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % hw, nb = i / hw;
+    const int blk = (int)(nb % nblk);
+    const int64_t n = nb / nblk;
+    const float* p = x + ((size_t)n * C + (size_t)blk * 8) * hw + pix;
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)(blk * 8 + j < C ? p[(size_t)j * hw] : 0.f);
+    y[i] = __builtin_bit_cast(uint4, b);
+  }
+}
+}  // namespace
+
+extern "C" int ess_to_bf16_c8(const float* x, void* y, int N, int C, int H, int W, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "to_bf16_c8: bad arguments");
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * ((C + 7) / 8) * hw;
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(to_bf16_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y, C, hw, total);
+  return ess_launch_status("to_bf16_c8");
+}

@@ -25,6 +25,17 @@ def _inference_only(*tensors):
                                   'torch.no_grad() in ESS: training/ess_trainer.py:52-54,277-280)')
 
 
+def _attach_c8(t, c8):
+    """Remember the BF16_C8 staging copy of a freshly written fp32 tensor (and the tensor version it belongs to)."""
+    t.ess_c8 = (c8, t._version)
+
+
+def _c8_of(t):
+    """The staging copy of `t`, unless `t` was modified in place since the producing kernel wrote both."""
+    c8 = getattr(t, 'ess_c8', None)
+    return c8[0] if c8 is not None and c8[1] == t._version else None
+
+
 class _Fold:
     """Per-output-channel (scale, shift) of an eval-mode norm folded behind a conv, packed for the kernel
     and cached until one of the source tensors changes."""
@@ -84,8 +95,10 @@ class ConvLayer(nn.Module):
             self.norm_layer = nl
         self._fold = _Fold()
 
-    def forward(self, x, x1=None, residual=None):
-        """x1: optional second source, channel-concatenated on the fly."""
+    def forward(self, x, x1=None, residual=None, want_c8=False):
+        """x1: optional second source, channel-concatenated on the fly.
+        want_c8: (bf16 arithmetic only) also emit the output as a BF16_C8 staging copy, attached to the returned
+        tensor as `.ess_c8`, for a following 3x3 convolution to stage from (see ConvLSTM.forward)."""
         _inference_only(x, x1)
         _check_eval(self, self.norm)
         c = self.conv2d
@@ -95,7 +108,13 @@ class ConvLayer(nn.Module):
                              act=_ACT[self.activation])
         scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
-        return hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out)
+        c8 = None
+        if want_c8 and spec.desc.compute == hip.COMPUTE_BF16:
+            c8 = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
+        hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8)
+        if c8 is not None:
+            _attach_c8(out, c8)
+        return out
 
 
 class TransposedConvLayer(nn.Module):
@@ -192,7 +211,9 @@ class ConvLSTM(nn.Module):
         if prev_state is None:
             key = (N, hid, H, W, input_.device)
             if key not in self.zero_tensors:
-                self.zero_tensors[key] = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
+                z = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
+                _attach_c8(z, torch.zeros(N, (hid + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=input_.device))
+                self.zero_tensors[key] = z
             prev_hidden, prev_cell = self.zero_tensors[key], None  # a NULL cell pointer reads as zeros
         else:
             prev_hidden, prev_cell = prev_state
@@ -203,8 +224,22 @@ class ConvLSTM(nn.Module):
             self._bias_ver, self._bias = ver, hip.pack_rows(spec, b.detach())
         hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
         cell = torch.empty_like(hidden)
-        hip.conv_forward(spec, input_, prev_hidden, packed_weight(spec, self.Gates.weight), None, self._bias,
-                         aux0=prev_cell, out=hidden, out2=cell)
+        # bf16 arithmetic: stage x and h from their BF16_C8 copies when the producers left them (the encoder conv and
+        # the previous step of this kernel do), and leave one of h' for the next time step.  Bit-identical to staging
+        # from the fp32 tensors -- the copies hold exactly the bf16 operands the MFMA would be fed anyway -- but the
+        # tile loads are 16-byte vectors instead of 8 strided dwords.  A state tensor that went through user code
+        # (clone, detach, arithmetic) simply has no copy any more and takes the fp32 path.
+        bf = spec.desc.compute == hip.COMPUTE_BF16 and (C % 8) == 0
+        x8, h8 = _c8_of(input_), _c8_of(prev_hidden)
+        new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
+        if bf and x8 is not None and h8 is not None:
+            hip.conv_forward(spec, x8, h8, packed_weight(spec, self.Gates.weight), None, self._bias, aux0=prev_cell, out=hidden,
+                             out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
+        else:
+            hip.conv_forward(spec, input_, prev_hidden, packed_weight(spec, self.Gates.weight), None, self._bias,
+                             aux0=prev_cell, out=hidden, out2=cell, out_bf=new8)
+        if new8 is not None:
+            _attach_c8(hidden, new8)
         return hidden, cell
 
 
@@ -262,7 +297,7 @@ class RecurrentConvLayer(nn.Module):
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
 
     def forward(self, x, prev_state):
-        x = self.conv(x)
+        x = self.conv(x, want_c8=self.recurrent_block_type == 'convlstm')
         state = self.recurrent_block(x, prev_state)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state

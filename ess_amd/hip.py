@@ -19,6 +19,7 @@ EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 W_CONV, W_TRANSPOSED = 0, 1
 COMPUTE_FP32, COMPUTE_BF16 = 0, 1
+FMT_F32_NCHW, FMT_BF16_C8 = 0, 1
 
 _default_compute = COMPUTE_FP32
 
@@ -36,7 +37,7 @@ def get_compute():
 
 EXPORTS = [
     'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',
-    'ess_conv2d_forward', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
+    'ess_conv2d_forward', 'ess_to_bf16_c8', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
@@ -47,7 +48,7 @@ EXPORTS = [
 class EssConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         'N', 'H_in', 'W_in', 'C0', 'C1', 'mode0', 'mode1', 'C_out', 'H_out', 'W_out', 'ksize', 'stride', 'pad',
-        'epilogue', 'act', 'hidden', 'out_split', 'compute')]
+        'epilogue', 'act', 'hidden', 'out_split', 'compute', 'fmt0', 'fmt1')]
 
 
 class EssConvPlan(Structure):
@@ -85,7 +86,8 @@ def lib():
             'ess_conv2d_plan': [D, POINTER(EssConvPlan)],
             'ess_conv2d_pack_weights': [D, c_int, P, P, P, P],
             'ess_conv2d_pack_rows': [D, P, P, F, P, P],
-            'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P],
+            'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P, P],
+            'ess_to_bf16_c8': [P, P, I, I, I, I, P],
             'ess_conv2d_wgrad': [D, P, P, P, P, P, c_int, P, c_size_t, P],
             'ess_instnorm_forward': [P, P, P, P, I, I, F, I, P, c_size_t, P],
             'ess_instnorm_backward': [P, P, P, P, I, I, I, P, c_size_t, P],
@@ -148,12 +150,21 @@ class ConvSpec:
         H_out = (H_in + 2 * p - k) // s + 1
         W_out = (W_in + 2 * p - k) // s + 1
         self.desc = EssConvDesc(N, H_in, W_in, C0, C1, mode0, mode1, C_out, H_out, W_out, k, s, p, epi, act, hidden,
-                                out_split, compute)
+                                out_split, compute, FMT_F32_NCHW, FMT_F32_NCHW)
+        self._desc_c8 = None
         self.plan = EssConvPlan()
         _check(lib().ess_conv2d_plan(byref(self.desc), byref(self.plan)), 'ess_conv2d_plan')
         self.key = key
         self.H_out, self.W_out = H_out, W_out
         self.wgrad_ws = None
+
+    def desc_c8(self):
+        """The same convolution reading BF16_C8 sources (same plan, same packed weights)."""
+        if self._desc_c8 is None:
+            d = EssConvDesc.from_buffer_copy(self.desc)
+            d.fmt0 = d.fmt1 = FMT_BF16_C8
+            self._desc_c8 = d
+        return self._desc_c8
 
 
 def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC_DIRECT, epi=EPI_LINEAR, act=ACT_NONE,
@@ -182,11 +193,35 @@ def pack_rows(spec, v, v2=None, fill=0.0):
 
 
 def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None,
-                 out2=None):
-    _check(lib().ess_conv2d_forward(byref(spec.desc), ptr(src0), ptr(src1), ptr(packed_w, torch.uint8), ptr(scale), ptr(shift),
-                                    ptr(residual), ptr(aux0), ptr(aux1), ptr(out), ptr(out2), stream()),
+                 out2=None, out_bf=None, src_fmt=FMT_F32_NCHW):
+    """src_fmt FMT_BF16_C8: src0/src1 are bf16 [N][C/8][H][W][8] staging copies (see bf16_c8_empty);
+    out_bf: receives `out` in that format for the next convolution."""
+    c8 = src_fmt == FMT_BF16_C8
+    sdt = torch.bfloat16 if c8 else torch.float32
+    _check(lib().ess_conv2d_forward(byref(spec.desc_c8() if c8 else spec.desc), ptr(src0, sdt), ptr(src1, sdt),
+                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual), ptr(aux0), ptr(aux1),
+                                    ptr(out), ptr(out2), ptr(out_bf, torch.bfloat16), stream()),
            'ess_conv2d_forward')
     return out
+
+
+def bf16_c8_empty(N, C, H, W, device):
+    """Uninitialised BF16_C8 tensor for a logical [N, C, H, W] activation: bf16 [N][ceil(C/8)][H][W][8]."""
+    return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+
+
+def to_bf16_c8(x):
+    """fp32 NCHW -> BF16_C8 on the device (round to nearest even, tail channels zero)."""
+    N, C, H, W = x.shape
+    y = bf16_c8_empty(N, C, H, W, x.device)
+    _check(lib().ess_to_bf16_c8(ptr(x), ptr(y, torch.bfloat16), N, C, H, W, stream()), 'ess_to_bf16_c8')
+    return y
+
+
+def from_bf16_c8(y, C):
+    """BF16_C8 -> fp32 NCHW (plain torch; test/debug helper, not on the product path)."""
+    N, nb, H, W, _ = y.shape
+    return y.permute(0, 1, 4, 2, 3).reshape(N, nb * 8, H, W)[:, :C].float().contiguous()
 
 
 _ws_cache = {}

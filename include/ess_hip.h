@@ -42,6 +42,11 @@ enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3
 /* arithmetic of the convolution contraction.  Tensors in HBM are fp32 either way; BF16 rounds the MFMA operands
  * (activations while staging the LDS tile, weights at pack time) to bfloat16 and accumulates in fp32.         */
 enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
+/* storage format of a convolution source.  BF16_C8 = the "staging copy" a producing kernel can emit next to its
+ * fp32 NCHW output (out_bf16 of ess_conv2d_forward, or ess_to_bf16_c8): bfloat16 [N][ceil(C/8)][H][W][8], i.e. the
+ * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv
+ * stages it with plain 16-byte copies: 4x fewer cache-line touches and half the bytes of the fp32 NCHW path.      */
+enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1 };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -71,6 +76,8 @@ typedef struct EssConvDesc {
   int32_t out_split;    /* LINEAR: >0 writes channels [0,out_split) to `out` and the rest to `out2`
                            (data-gradient of a two-source conv)                                      */
   int32_t compute;      /* ESS_COMPUTE_*                                                             */
+  int32_t fmt0, fmt1;   /* ESS_FMT_* of source 0 / 1.  BF16_C8 needs: bf16 compute, 3x3, stride 1, DIRECT
+                           sources, and the same format for both sources of a concat                     */
 } EssConvDesc;
 
 typedef struct EssConvPlan {
@@ -102,9 +109,15 @@ int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, 
  * residual: [N][C_out][H_out][W_out] or NULL (LINEAR).
  * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev ; aux1: GRU_OUT u.
  * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h | LINEAR split.  */
-int ess_conv2d_forward(const EssConvDesc* d, const float* src0, const float* src1, const void* packed_w,
+int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
                        const float* scale, const float* shift, const float* residual, const float* aux0,
-                       const float* aux1, float* out, float* out2, ess_stream_t stream);
+                       const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream);
+/* src0/src1: fp32 NCHW or bf16 C8 per d->fmt0/fmt1.  out_bf16 (nullable): additionally receives `out` (LINEAR y,
+ * LSTM h', GRU_OUT h') as a BF16_C8 tensor [N][ceil(C/8)][H_out][W_out][8] for the next convolution to stage from
+ * (bf16 compute only; not with out_split).                                                              */
+
+/* fp32 NCHW -> BF16_C8 (round to nearest even; tail channels zero).  y: N*ceil(C/8)*H*W*8 bfloat16.        */
+int ess_to_bf16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
 
 /* Weight gradient of the same convolution (replaces cuDNN wgrad under autograd for
  * models/style_networks.py:158-193 and the ResNet prefix :116-121).

@@ -501,3 +501,71 @@ def test_voxel_refuses_bad_input(H):
         H.voxel_grid_trilinear(x.cpu(), x.cpu(), x.cpu(), x.cpu(), [0, 4], 2, 8, 8)  # no CPU path
     empty = H.voxel_grid_trilinear(x[:0], x[:0], x[:0], x[:0], [0, 0], 2, 8, 8)      # an empty slice is a zero grid
     assert empty.shape == (1, 2, 8, 8) and not empty.any()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BF16_C8 staging copies: a producer's `out_bf` is RNE(out) in [N][C/8][H][W][8]; a consumer conv that stages from it
+# must give the SAME BITS as the one converting fp32 NCHW on the fly (identical operand rounding, identical MFMA order).
+@pytest.mark.parametrize('case', [
+    (2, 64, 64, 24, 40, 'lstm'),     # gate conv: cat(x, h) -> LSTM epilogue, MB=2
+    (1, 32, 32, 20, 36, 'lstm'),     # partial tiles
+    (2, 24, 0, 40, 16, 24, 'linear'),  # single source, C not a multiple of 16, C_out tail block
+    (1, 256, 256, 12, 20, 'lstm'),   # deep level: MB=4 path
+])
+def test_conv_bf16_c8_sources_and_copy(H, case):
+    g = torch.Generator().manual_seed(11)
+    if case[-1] == 'lstm':
+        N, C, hid, Hh, Ww, _ = case
+        x, h, c = [torch.randn(N, ch, Hh, Ww, generator=g) for ch in (C, hid, hid)]
+        w = torch.randn(4 * hid, C + hid, 3, 3, generator=g) / (9 * (C + hid)) ** 0.5
+        b = torch.randn(4 * hid, generator=g)
+        spec = H.conv_spec(N, Hh, Ww, C, hid, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=H.COMPUTE_BF16)
+        pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+        outs = []
+        for c8 in (False, True):
+            ho, co = torch.empty(N, hid, Hh, Ww, device='cuda'), torch.empty(N, hid, Hh, Ww, device='cuda')
+            hb = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
+            s0, s1 = (H.to_bf16_c8(dev(x)), H.to_bf16_c8(dev(h))) if c8 else (dev(x), dev(h))
+            H.conv_forward(spec, s0, s1, pw, None, pb, aux0=dev(c), out=ho, out2=co, out_bf=hb,
+                           src_fmt=H.FMT_BF16_C8 if c8 else H.FMT_F32_NCHW)
+            outs.append((ho.cpu(), co.cpu(), hb.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for ho, _, hb in outs:
+            assert torch.equal(H.from_bf16_c8(hb, hid), ho.bfloat16().float())
+    else:
+        N, C, _, Cout, Hh, Ww, _ = case
+        x = torch.randn(N, C, Hh, Ww, generator=g)
+        w = torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        spec = H.conv_spec(N, Hh, Ww, C, 0, Cout, 3, 1, 1, act=H.ACT_RELU, compute=H.COMPUTE_BF16)
+        pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+        outs = []
+        for c8 in (False, True):
+            o = torch.empty(N, Cout, Hh, Ww, device='cuda')
+            ob = H.bf16_c8_empty(N, Cout, Hh, Ww, 'cuda')
+            H.conv_forward(spec, H.to_bf16_c8(dev(x)) if c8 else dev(x), None, pw, None, pb, out=o, out_bf=ob,
+                           src_fmt=H.FMT_BF16_C8 if c8 else H.FMT_F32_NCHW)
+            outs.append((o.cpu(), ob.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1))
+        assert relerr(outs[0][0], ref) < 1e-4
+        for o, ob in outs:
+            assert torch.equal(H.from_bf16_c8(ob, Cout), o.bfloat16().float())
+            assert not ob.view(N, -1, Hh, Ww, 8).float().permute(0, 1, 4, 2, 3).reshape(N, -1, Hh, Ww)[:, Cout:].any()  # zero tail
+
+
+def test_bf16_c8_roundtrip_and_refusals(H):
+    x = torch.randn(2, 13, 6, 10)
+    y = H.to_bf16_c8(dev(x))
+    assert y.shape == (2, 2, 6, 10, 8)
+    assert torch.equal(H.from_bf16_c8(y.cpu(), 13), x.bfloat16().float())
+    spec = H.conv_spec(1, 8, 8, 8, 0, 8, 5, 1, 2, compute=H.COMPUTE_BF16)   # 5x5: no BF16_C8 staging
+    w = H.pack_weights(spec, dev(torch.randn(8, 8, 5, 5)))
+    with pytest.raises(H.EssHipError):
+        H.conv_forward(spec, H.to_bf16_c8(dev(torch.randn(1, 8, 8, 8))), None, w, out=torch.empty(1, 8, 8, 8, device='cuda'),
+                       src_fmt=H.FMT_BF16_C8)
+    spec32 = H.conv_spec(1, 8, 8, 8, 0, 8, 3, 1, 1, compute=H.COMPUTE_FP32)  # fp32 compute: no copy
+    w32 = H.pack_weights(spec32, dev(torch.randn(8, 8, 3, 3)))
+    with pytest.raises(H.EssHipError):
+        H.conv_forward(spec32, dev(torch.randn(1, 8, 8, 8)), None, w32, out=torch.empty(1, 8, 8, 8, device='cuda'),
+                       out_bf=H.bf16_c8_empty(1, 8, 8, 8, 'cuda'))
