@@ -253,8 +253,15 @@ struct Geom {
 
 inline bool is_bf16(const EssConvDesc* d) { return d->compute == ESS_COMPUTE_BF16; }
 
+// bf16 5x5 convolutions run on the tap-paired wave-specialised kernel (conv_bf16.hip): 8-channel chunks, two taps per MFMA
+inline bool is_paired(const EssConvDesc* d) {
+  static const bool on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
+  return on && is_bf16(d) && d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR;
+}
+
 inline int pick_ck(const EssConvDesc* d) {
   const int cin = d->C0 + d->C1;
+  if (is_paired(d)) return 8;
   if (is_bf16(d)) return (d->ksize == 1 && d->stride == 1 && cin >= 32) ? 32 : 16;  // one v_mfma_f32_32x32x16_bf16 K-step = 16 channels
   // fp32: K-step = 2 channels; chunk sized for LDS.  Only the 2-channel 5x5 head gets a narrower chunk.
   if (d->ksize == 5 && d->stride == 1 && cin <= 2) return 2;
@@ -355,9 +362,9 @@ inline int validate(const EssConvDesc* d) {
   ESS_CHECK_ARG((d->fmt0 == ESS_FMT_F32_NCHW || d->fmt0 == ESS_FMT_BF16_C8) && (d->fmt1 == ESS_FMT_F32_NCHW || d->fmt1 == ESS_FMT_BF16_C8),
                 "conv: bad source format");
   if (d->fmt0 != ESS_FMT_F32_NCHW || d->fmt1 != ESS_FMT_F32_NCHW) {
-    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->mode0 == ESS_SRC_DIRECT &&
-                      (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT),
-                  "conv: BF16_C8 sources need bf16 compute, 3x3 stride 1 pad 1 and DIRECT sources");
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->mode0 == ESS_SRC_DIRECT && (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT) &&
+                      ((d->ksize == 3 && d->stride == 1 && d->pad == 1) || (d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR)),
+                  "conv: BF16_C8 sources need bf16 compute, DIRECT sources and a 3x3 stride-1 pad-1 or a 5x5 convolution");
     ESS_CHECK_ARG(d->C1 == 0 || d->fmt0 == d->fmt1, "conv: both sources of a concat must use the same format");
     ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "conv: the first BF16_C8 source of a concat must have a multiple of 8 channels");
   }
@@ -384,7 +391,12 @@ inline void make_plan(const EssConvDesc* d, EssConvPlan* pl) {
   pl->rows_padded = pl->n_cout_tiles * pl->cout_tile;
   pl->packed_elems = (int64_t)pl->rows_padded * pl->n_chunks * pl->ck * d->ksize * d->ksize;
   const Geom g = choose_geom(d);
-  if (is_bf16(d)) {
+  if (is_paired(d)) {
+    const int np = (d->ksize * d->ksize + 1) / 2;  // tap pairs; 16 k-values each
+    pl->packed_elems = (int64_t)pl->rows_padded * pl->n_chunks * np * 16;
+    pl->packed_bytes = pl->packed_elems * 2;
+    pl->lds_bytes = (g.plane + np * 2 * pl->cout_tile) * 16;  // one stage; the kernel double-buffers
+  } else if (is_bf16(d)) {
     pl->packed_bytes = pl->packed_elems * 2;
     pl->lds_bytes = ((pl->ck / 8) * g.plane + d->ksize * d->ksize * (pl->ck / 8) * pl->cout_tile) * 16;
   } else {

@@ -109,9 +109,16 @@ class ConvLayer(nn.Module):
         scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
         c8 = None
-        if want_c8 and spec.desc.compute == hip.COMPUTE_BF16:
+        bf = spec.desc.compute == hip.COMPUTE_BF16
+        if want_c8 and bf:
             c8 = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
-        hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8)
+        k = c.kernel_size[0]
+        x8 = _c8_of(x) if bf and x1 is None and (k == 5 or (k == 3 and c.stride[0] == 1 and c.padding[0] == 1)) else None
+        if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
+            hip.conv_forward(spec, x8, None, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8,
+                             src_fmt=hip.FMT_BF16_C8)
+        else:
+            hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8)
         if c8 is not None:
             _attach_c8(out, c8)
         return out

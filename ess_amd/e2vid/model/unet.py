@@ -117,7 +117,7 @@ class UNetRecurrent(BaseUNet):
         self.build_prediction_layer()
 
     def forward(self, x, prev_states, encoder_only=False):
-        x = self.head(x)
+        x = self.head(x, want_c8=True)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic only)
         head = x
         if prev_states is None:
             prev_states = [None] * self.num_encoders

@@ -554,13 +554,37 @@ def test_conv_bf16_c8_sources_and_copy(H, case):
             assert not ob.view(N, -1, Hh, Ww, 8).float().permute(0, 1, 4, 2, 3).reshape(N, -1, Hh, Ww)[:, Cout:].any()  # zero tail
 
 
+@pytest.mark.parametrize('case', [(2, 32, 64, 48, 80, 2), (1, 24, 40, 22, 36, 2), (2, 64, 32, 24, 40, 1), (1, 8, 16, 19, 27, 1)])
+def test_conv5x5_paired_c8_sources(H, case):
+    """5x5 (tap-paired kernel), stride 1 and 2: BF16_C8 sources give the same bits as fp32 NCHW sources, and both
+    match fp32 math on bf16-rounded operands."""
+    N, C, Cout, Hh, Ww, s = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, C, Hh, Ww, generator=g)
+    w = torch.randn(Cout, C, 5, 5, generator=g) / (25 * C) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    spec = H.conv_spec(N, Hh, Ww, C, 0, Cout, 5, s, 2, act=H.ACT_RELU, compute=H.COMPUTE_BF16)
+    pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+    outs = []
+    for c8 in (False, True):
+        o = torch.empty(N, Cout, spec.H_out, spec.W_out, device='cuda')
+        ob = H.bf16_c8_empty(N, Cout, spec.H_out, spec.W_out, 'cuda')
+        H.conv_forward(spec, H.to_bf16_c8(dev(x)) if c8 else dev(x), None, pw, None, pb, out=o, out_bf=ob,
+                       src_fmt=H.FMT_BF16_C8 if c8 else H.FMT_F32_NCHW)
+        outs.append((o.cpu(), ob.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, stride=s, padding=2))
+    assert relerr(outs[0][0], ref) < 1e-4
+    assert torch.equal(H.from_bf16_c8(outs[1][1], Cout), outs[1][0].bfloat16().float())
+
+
 def test_bf16_c8_roundtrip_and_refusals(H):
     x = torch.randn(2, 13, 6, 10)
     y = H.to_bf16_c8(dev(x))
     assert y.shape == (2, 2, 6, 10, 8)
     assert torch.equal(H.from_bf16_c8(y.cpu(), 13), x.bfloat16().float())
-    spec = H.conv_spec(1, 8, 8, 8, 0, 8, 5, 1, 2, compute=H.COMPUTE_BF16)   # 5x5: no BF16_C8 staging
-    w = H.pack_weights(spec, dev(torch.randn(8, 8, 5, 5)))
+    spec = H.conv_spec(1, 8, 8, 8, 0, 8, 1, 1, 0, compute=H.COMPUTE_BF16)   # 1x1: no BF16_C8 staging
+    w = H.pack_weights(spec, dev(torch.randn(8, 8, 1, 1)))
     with pytest.raises(H.EssHipError):
         H.conv_forward(spec, H.to_bf16_c8(dev(torch.randn(1, 8, 8, 8))), None, w, out=torch.empty(1, 8, 8, 8, device='cuda'),
                        src_fmt=H.FMT_BF16_C8)
