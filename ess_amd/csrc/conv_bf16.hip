@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 // row (packed [tile][chunk][pair][half][cout][8]).  13 pairs cover the 25 taps (the 26th has zero weights: 4 % waste);
 // a stage is one 8-channel input tile + 26.6 KB of weights, double-buffered like the 3x3 kernel, one barrier per chunk.
 template <int KS, int S, int MB, bool SRCBF>
-__global__ __launch_bounds__(512, S == 2 ? 2 : 4) void conv_bf16_ws_pair_kernel(const ConvKArgs a) {
+__global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws_pair_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int NT = KS * KS, NP = (NT + 1) / 2;
   constexpr int COT = MB * 32;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 4) void conv_bf16_ws_pair_kernel(
     const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
     const int npos = a.IH * a.IW;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
-    u32x4 wpre[WV];
+    constexpr bool DEEP = S == 2;
     int v_lds[KPC];
     if constexpr (SRCBF) {
       const size_t hw = (size_t)a.Hin * a.Win;
@@ -481,19 +481,22 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 4) void conv_bf16_ws_pair_kernel(
         v_pos[k] = in ? (unsigned)(gy * a.Win + gx) : 0u;
         v_keep[k] = in ? 0xffffffffu : 0u;
       }
-      u32x4 pre[KPC];
-      auto load_chunk = [&](int ch) {
+      // DEEP (stride 2: one workgroup per CU, nothing else hides the memory latency): two chunks of loads in flight in
+      // two register sets -- a load issued in iteration ch is committed in iteration ch+2
+      struct Set { u32x4 pre[KPC]; u32x4 wpre[WV]; };
+      Set sa, sb;
+      auto load_chunk = [&](int ch, Set& r) {
         const int c0 = ch * 8;
         const bool first = c0 < a.C0 || a.C1 == 0;
         const int bi = (first ? c0 : c0 - a.C0) >> 3, nbs = first ? nb0 : nb1;
         const u32x4* sp8 = (first ? s0 : s1) + (size_t)(bi < nbs ? bi : 0) * hw;
 #pragma unroll
-        for (int k = 0; k < KPC; ++k) pre[k] = sp8[v_pos[k]];
+        for (int k = 0; k < KPC; ++k) r.pre[k] = sp8[v_pos[k]];
         const u32x4* wsrc = wbase + (size_t)ch * WSZ;
 #pragma unroll
-        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; r.wpre[it] = wsrc[i < WSZ ? i : 0]; }
       };
-      auto commit = [&](int ch, int buf) {
+      auto commit = [&](int ch, int buf, const Set& r) {
         u32x4* in_t = smem16 + buf * bufsz;
         u32x4* w_t = in_t + a.plane;
         const int c0 = ch * 8;
@@ -502,23 +505,46 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 4) void conv_bf16_ws_pair_kernel(
 #pragma unroll
         for (int k = 0; k < KPC; ++k) {
           const unsigned m = v_keep[k] & blk_ok;
-          u32x4 v = pre[k];
+          u32x4 v = r.pre[k];
           v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
           if (v_lds[k] >= 0) in_t[v_lds[k]] = v;
         }
 #pragma unroll
-        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
       };
-      load_chunk(0);
-      commit(0, 0);
-      if (a.n_chunks > 1) load_chunk(1);
-      __syncthreads();
-      for (int ch = 0; ch < a.n_chunks; ++ch) {
-        if (ch + 1 < a.n_chunks) {
-          commit(ch + 1, (ch + 1) & 1);
-          if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+      const int nch = a.n_chunks;
+      if constexpr (DEEP) {
+        load_chunk(0, sa);
+        if (nch > 1) load_chunk(1, sb);
+        commit(0, 0, sa);
+        if (nch > 2) load_chunk(2, sa);
+        __syncthreads();  // stage 0 is ready
+        for (int ch = 0; ch < nch; ch += 2) {
+          if (ch + 1 < nch) {
+            commit(ch + 1, 1, sb);
+            if (ch + 3 < nch) load_chunk(ch + 3, sb);
+          }
+          __syncthreads();
+          if (ch + 1 < nch) {
+            if (ch + 2 < nch) {
+              commit(ch + 2, 0, sa);
+              if (ch + 4 < nch) load_chunk(ch + 4, sa);
+            }
+            __syncthreads();
+          }
         }
+      } else {
+        load_chunk(0, sa);
+        commit(0, 0, sa);
+        if (nch > 1) load_chunk(1, sa);
         __syncthreads();
+        for (int ch = 0; ch < nch; ++ch) {
+          if (ch + 1 < nch) {
+            commit(ch + 1, (ch + 1) & 1, sa);
+            if (ch + 2 < nch) load_chunk(ch + 2, sa);
+          }
+          __syncthreads();
+        }
       }
     } else {
       const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
@@ -542,6 +568,7 @@ __global__ __launch_bounds__(512, S == 2 ? 2 : 4) void conv_bf16_ws_pair_kernel(
       }
       struct Raw8 { float v[8]; };
       Raw8 pre[KPC];
+      u32x4 wpre[WV];
       auto load_chunk = [&](int ch) {
         const int c0 = ch * 8;
         const bool first = c0 < a.C0 || a.C1 == 0;

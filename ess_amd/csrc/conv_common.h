@@ -277,6 +277,13 @@ inline int pick_mb(const EssConvDesc* d) {
     static const bool mb4 = [] { const char* e = getenv("ESS_CONV_MB4"); return !(e && e[0] == '0'); }();
     if (mb4) return 4;
   }
+  // tap-paired 5x5 / stride 2: the input tile is 4x the output tile, so a 64-row workgroup needs 95 KB of LDS and runs
+  // alone on its CU with prologue, K loop and epilogue strictly in sequence; 32-row tiles fit twice
+  // (measured, B=8 encoder convs: 0.191 / 0.117 / 0.105 ms -> 0.167 / 0.102 / 0.085 ms)
+  if (is_paired(d) && d->stride == 2) {
+    static const int m = [] { const char* e = getenv("ESS_PAIR_S2_MB"); return e ? atoi(e) : 1; }();
+    if (m == 1) return 1;
+  }
   return d->C_out > 32 ? 2 : 1;
 }
 
@@ -296,6 +303,7 @@ inline Geom choose_geom(const EssConvDesc* d) {
       const int tx = ceil_div(d->W_out, TW), ty = ceil_div(d->H_out, TH);
       const int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
       if (IH * IW > stage_kpc(KS, S) * 256) continue;  // would not fit the staging registers
+      { const char* e = getenv("ESS_CONV_GEOM"); if (e && (e[0] - '0' != bwl || e[1] - '0' != wxl)) continue; }  // tuning hook
       // padded MACs (dominant) + a small halo/staging term; prefer wide blocks on ties
       const double cost = (double)tx * ty * TW * TH * (1.0 + 0.02 * (double)(IH * IW) / (TH * TW * S * S)) +
                           1e-3 * (5 - bwl);
