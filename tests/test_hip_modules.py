@@ -273,3 +273,45 @@ def test_config3_bf16_vs_oracle_and_bf16_reference():
     assert int((mism & (margin > 2 * e16)).sum()) == 0
     assert agree > 0.9
     assert relerr(out['bf16'][3], out['fp32'][3]) < 3e-2  # recurrent state drift over T steps stays at bf16 rounding level
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE full size (DSEC shape: B=8, C=2, 480x640).  The oracle needs ~7 s per step per sample there, so the checks
+# are the size-independent properties of the path: determinism, batch independence (recurrent state, InstanceNorm and
+# every conv tile are per-sample), equality of the BF16_C8-staged and fp32-staged encoder, and bf16-vs-fp32 agreement.
+def test_full_size_encoder_properties():
+    from ess_amd import hip
+    B, T, C, H, W = 8, 3, 2, 480, 640
+    cfg = O.e2vid_config(num_bins=C)
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 31)
+    ev, _, _, _ = O.synth_batch(B, T, C, H, W, 11, seed=9)
+    ev = ev.cuda()
+
+    def run(events, strip_copies=False):
+        model = _e2vid(cfg, sd_e)
+        states, lat = None, None
+        with torch.no_grad():
+            for t in range(T):
+                _, states, lat = model(events[:, t * C:(t + 1) * C].contiguous(), states)
+                if strip_copies:  # drop the BF16_C8 staging copies: the next step stages from the fp32 tensors
+                    states = [(h.clone(), c) for h, c in states]
+        return [lat[k].clone() for k in (1, 2, 4, 8)] + [s[1].clone() for s in states]
+
+    outs = {}
+    for mode in ('fp32', 'bf16'):
+        hip.set_compute(mode)
+        try:
+            a = run(ev)
+            b = run(ev)
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f'{mode}: not deterministic'
+            one = run(ev[3:4].contiguous())
+            assert all(torch.equal(x[3:4], y) for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
+            if mode == 'bf16':
+                c = run(ev, strip_copies=True)
+                assert all(torch.equal(x, y) for x, y in zip(a, c)), 'BF16_C8-staged and fp32-staged encoders differ'
+            outs[mode] = a
+        finally:
+            hip.set_compute('fp32')
+    for x32, x16 in zip(outs['fp32'], outs['bf16']):
+        assert relerr(x16, x32) < 3e-2
+    assert all(torch.isfinite(x).all() for x in outs['bf16'])
