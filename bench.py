@@ -237,7 +237,7 @@ def main():
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
                                    f'{"DSEC" if args.width == 640 else "DDD17" if args.width == 352 else "custom"}-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
                                    f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
-                                   f'conv contractions {args.compute} (fp32 accumulate, fp32 tensors), weight gradients fp32',
+                                   f'conv contractions {args.compute} (fp32 accumulate; tensors fp32 NCHW' + (', plus BF16_C8 staging copies inside the frozen encoder' if args.compute == 'bf16' else '') + '), weight gradients fp32',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
         }
         if not args.no_roofline:

@@ -304,8 +304,10 @@ inline Geom choose_geom(const EssConvDesc* d) {
       const int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
       if (IH * IW > stage_kpc(KS, S) * 256) continue;  // would not fit the staging registers
       { const char* e = getenv("ESS_CONV_GEOM"); if (e && (e[0] - '0' != bwl || e[1] - '0' != wxl)) continue; }  // tuning hook
-      // padded MACs (dominant) + a small halo/staging term; prefer wide blocks on ties
-      const double cost = (double)tx * ty * TW * TH * (1.0 + 0.02 * (double)(IH * IW) / (TH * TW * S * S)) +
+      // padded MACs (dominant) + a small halo/staging term + a coalescing term: a tile row is one contiguous run of the
+      // NCHW planes for both the staging loads and the epilogue stores, and the large-plane layers are bound by how
+      // HBM traffic is shaped (64->64 @240x320, B=8: 16x16 tiles 131 us, 32x8 121 us, 64x4 114 us); prefer wide blocks on ties
+      const double cost = (double)tx * ty * TW * TH * (1.0 + 0.02 * (double)(IH * IW) / (TH * TW * S * S) + 0.04 * 64.0 / TW) +
                           1e-3 * (5 - bwl);
       if (cost < best_cost) {
         best_cost = cost;
