@@ -166,3 +166,65 @@ def test_data_parallel_reducer_gloo_world2():
     a, b = res
     assert a == b  # both ranks hold the same averaged gradients and the same broadcast weights
     assert a[0] == pytest.approx(1.5) and a[3] == pytest.approx(1.5 * 1) and a[4] == pytest.approx(1.5 * 2)
+
+
+def test_load_model_reads_the_reference_checkpoint_layout(tmp_path):
+    """e2vid/utils/loading_utils.py:5-38: {'arch', 'model' | 'config'['model'], 'state_dict'} -> (model, decoder);
+    both spellings of the config location, unknown arch refused (no eval())."""
+    from oracle import ess_oracle as O
+    from ess_amd.e2vid.utils.loading_utils import load_model
+    cfg = O.e2vid_config(num_bins=2, recurrent_block_type='convgru', norm='none')
+    sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 5)
+    for layout in ('model', 'config'):
+        ck = {'arch': 'E2VIDRecurrent', 'state_dict': sd}
+        if layout == 'model':
+            ck['model'] = dict(cfg)
+        else:
+            ck['config'] = {'model': dict(cfg)}
+        path = tmp_path / f'{layout}.pth.tar'
+        torch.save(ck, path)
+        model, decoder = load_model(str(path))
+        got = model.state_dict()
+        assert list(got.keys()) == list(sd.keys())
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+        assert model.num_bins == 2 and model.num_encoders == 3
+        assert decoder is not None
+    torch.save({'arch': '__import__("os").system("true")', 'model': dict(cfg), 'state_dict': sd}, tmp_path / 'bad.pth.tar')
+    with pytest.raises(ValueError):
+        load_model(str(tmp_path / 'bad.pth.tar'))
+
+
+def test_checkpoint_saver_roundtrip(tmp_path):
+    """utils/saver.py:15-60 file layout: Epoch_<n>.pt with one entry per model / optimiser name + epoch, step_count,
+    batch sizes; a second set of modules restored from it is identical."""
+    from oracle import ess_oracle as O
+    from ess_amd.models.style_networks import SemSegE2VID
+    from ess_amd.utils.saver import CheckpointSaver
+
+    def make(seed):
+        torch.manual_seed(seed)
+        dec = SemSegE2VID(256, 6, skip_connect=True, skip_type='concat')
+        dec.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, 6), seed, decoder_style=True))
+        return dec
+
+    a, b = make(1), make(2)
+    opt_a = torch.optim.SGD(a.parameters(), lr=0.1, momentum=0.9)
+    opt_b = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9)
+    for p in a.parameters():
+        p.grad = torch.ones_like(p)
+    opt_a.step()
+    saver = CheckpointSaver(str(tmp_path))
+    saver.save_checkpoint({'back_end': a}, {'optimizer_back': opt_a}, epoch=3, step_count=17, batch_size_a=8, batch_size_b=8)
+    path = tmp_path / 'Epoch_3.pt'
+    raw = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(raw) == {'back_end', 'optimizer_back', 'epoch', 'step_count', 'batch_size_a', 'batch_size_b'}
+    meta = saver.load_checkpoint({'back_end': b}, {'optimizer_back': opt_b}, checkpoint_file=str(path))
+    assert meta == {'epoch': 3, 'step_count': 17, 'batch_size_a': 8, 'batch_size_b': 8}
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    ma = opt_a.state_dict()['state'][0]['momentum_buffer']
+    mb = opt_b.state_dict()['state'][0]['momentum_buffer']
+    assert torch.equal(ma, mb)
+    c = make(4)
+    saver.load_pretrained_weights({'back_end': c, 'front_sensor_b': None}, ['front_sensor_b', 'back_end'], checkpoint_file=str(path))
+    assert all(torch.equal(sa[k], c.state_dict()[k]) for k in sa)
