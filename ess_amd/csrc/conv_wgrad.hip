@@ -695,6 +695,60 @@ __global__ __launch_bounds__(256) void wgrad_small1x1_kernel(const WgradArgs a, 
   if (a.ws_b && tid < Cout) a.ws_b[(size_t)blockIdx.x * Cout + tid] = bacc;
 }
 
+// ---- the same 1x1 head on the fp32 matrix core, for C_in <= 32 (C_out <= 16 as above), H*W a multiple of 64.
+// dW[co][ci] = sum_px dY[co][px] * X[ci][px] is ONE 32x32 output tile with K = all pixels: v_mfma_f32_32x32x2_f32 (exact
+// fp32) contracts 2 pixels per instruction, lane (p, half) feeding channel p.  The pixel order inside a group is free (it
+// is a sum), so lane (p, half) takes the 32 CONSECUTIVE pixels 32*half .. 32*half+31 of a 64-pixel group of its channel
+// plane -- one whole 128-byte line per tensor per lane -- straight from global memory: no LDS, no conversion, a pure
+// stream over dY and X.  Each wave walks a contiguous range of groups.  The VALU version above is LDS-bound (2
+// ds_read_b32 per FMA: 393 us on the 32 -> 11 @480x640 B=8 head).
+__global__ __launch_bounds__(256) void wgrad_small1x1_mfma_kernel(const WgradArgs a, int groups_per_img, int total_groups) {
+  __shared__ float red[4][16 * 64];
+  __shared__ float redb[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int Cin = a.C0, Cout = a.Cout;
+  const size_t HW = (size_t)a.Hout * a.Wout;
+  const float dmask = p < Cout ? 1.f : 0.f, xmask = p < Cin ? 1.f : 0.f;
+  const int pc_d = p < Cout ? p : Cout - 1, pc_x = p < Cin ? p : Cin - 1;  // clamped channel: always a valid address
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+  const int per = (total_groups + nw - 1) / nw;
+  const int g_lo = wid * per, g_hi = g_lo + per < total_groups ? g_lo + per : total_groups;
+  for (int g = g_lo; g < g_hi; ++g) {
+    const int n = g / groups_per_img;
+    const size_t px = (size_t)(g - n * groups_per_img) * 64 + 32 * half;
+    const f32x4* dp = (const f32x4*)(a.dy + ((size_t)n * Cout + pc_d) * HW + px);
+    const f32x4* xp = (const f32x4*)(a.src0 + ((size_t)n * Cin + pc_x) * HW + px);
+    f32x4 dv[8], xv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { dv[q] = dp[q]; xv[q] = xp[q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d1 = dv[q][j] * dmask, x1 = xv[q][j] * xmask;
+        bsum += d1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, x1, acc, 0, 0, 0);
+      }
+  }
+  // workgroup reduction of the 4 waves, then one slab per workgroup: [split = blockIdx.x][tap 0][co][ci]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (half == 0) redb[wave][p] = bsum;
+  __syncthreads();
+  for (int i = tid; i < 16 * 64; i += 256) {
+    const int r = i >> 6, l = i & 63;
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31;
+    if (co < Cout && ci < Cin)
+      a.ws[(size_t)blockIdx.x * Cout * Cin + co * Cin + ci] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+  if (a.ws_b && tid < Cout) a.ws_b[(size_t)blockIdx.x * Cout + tid] = (redb[0][tid] + redb[1][tid]) + (redb[2][tid] + redb[3][tid]);
+}
+
 __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
                                     int Cin, int accumulate) {
   const size_t total = (size_t)T * Cout * Cin;
@@ -722,7 +776,7 @@ __global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* d
 
 struct WPlan {
   int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
-  bool taps_variant, bf16, small1x1;
+  bool taps_variant, bf16, small1x1, small1x1_mfma;
   int pyv, pxv, rv;
   size_t slab_floats;
 };
@@ -770,6 +824,11 @@ WPlan wplan(const EssConvDesc* d) {
   if (w.small1x1) {
     const int chunks = d->N * ceil_div(d->H_out * d->W_out, 128);
     w.nsplit = chunks < 1024 ? chunks : 1024;
+    w.small1x1_mfma = cin <= 32 && ((d->H_out * d->W_out) % 64) == 0;
+    if (w.small1x1_mfma) {  // one slab per workgroup of 4 waves, two workgroups per CU
+      const int groups = d->N * (d->H_out * d->W_out / 64);
+      w.nsplit = groups < 4 * 512 ? ceil_div(groups, 4) : 512;
+    }
   }
   w.lds_bytes = (64 * 65 + (w.taps_variant ? w.IH * w.IW : 64 * w.plx)) * 4;
   if (w.bf16) {
@@ -826,7 +885,10 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
     hipLaunchKernelGGL((wgrad_f32_kernel<KS_, S_>), grid, dim3(256), w.lds_bytes, st, a);             \
   } while (0)
-  if (w.small1x1) {
+  if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {
+    const int per_img = d->H_out * d->W_out / 64;
+    hipLaunchKernelGGL(wgrad_small1x1_mfma_kernel, dim3(w.nsplit), dim3(256), 0, st, a, per_img, d->N * per_img);
+  } else if (w.small1x1) {
     const int per_img = ceil_div(d->H_out * d->W_out, 128);
     hipLaunchKernelGGL(wgrad_small1x1_kernel, dim3(w.nsplit), dim3(256), 0, st, a, per_img, d->N * per_img);
   } else if (w.bf16) {

@@ -224,6 +224,8 @@ GRAD_CASES = [
     (2, 64, 0, 128, 12, 20, 1, 2, 0, 0, False),
     (1, 24, 0, 40, 9, 14, 3, 1, 1, 0, True),
     (3, 64, 64, 64, 25, 44, 3, 1, 1, 0, True),
+    (1, 20, 0, 6, 8, 16, 1, 1, 0, 0, True),    # 1x1 head, channel tails, MFMA stream kernel (H*W % 64 == 0)
+    (1, 32, 0, 11, 5, 7, 1, 1, 0, 0, True),    # 1x1 head, H*W % 64 != 0: VALU kernel
 ]
 
 
