@@ -749,28 +749,45 @@ __global__ __launch_bounds__(256) void wgrad_small1x1_mfma_kernel(const WgradArg
   if (a.ws_b && tid < Cout) a.ws_b[(size_t)blockIdx.x * Cout + tid] = (redb[0][tid] + redb[1][tid]) + (redb[2][tid] + redb[3][tid]);
 }
 
-__global__ void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T, int Cout,
-                                    int Cin, int accumulate) {
+// Deterministic reduction of the split-K slabs: dw[co][ci][tap] (+)= sum_split ws[split][tap][co][ci].
+// One workgroup = 64 consecutive slab elements (coalesced) x 16 waves, wave w summing splits w, w+16, ... with 8
+// independent accumulators, then a fixed-order combine through LDS.  (The first version gave each thread the whole
+// split loop: 256-512 dependent-latency iterations, 30-90 us for a few MB.)  Elements past `total` belong to the bias
+// slabs: element total + co sums ws_b[split][co].
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T,
+                                                            int Cout, int Cin, int accumulate) {
+  __shared__ float part[16][64];
   const size_t total = (size_t)T * Cout * Cin;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
-      s0 += ws[(size_t)k * total + i]; s1 += ws[(size_t)(k + 1) * total + i];
-      s2 += ws[(size_t)(k + 2) * total + i]; s3 += ws[(size_t)(k + 3) * total + i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const bool is_w = i < total;
+  const bool is_b = !is_w && db && ws_b && i < total + (size_t)Cout;
+  const float* src = is_w ? ws + i : ws_b + (i - total);
+  const size_t stride = is_w ? total : (size_t)Cout;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (is_w || is_b) {
+    int k = wave;
+    for (; k + 7 * 16 < nsplit; k += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(k + 16 * u) * stride];
     }
-    for (; k < nsplit; ++k) s0 += ws[(size_t)k * total + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    const int t = i / ((size_t)Cout * Cin);
-    const size_t rem = i - (size_t)t * Cout * Cin;  // co*Cin + ci
-    float* dst = dw + rem * T + t;
-    *dst = accumulate ? *dst + s : s;
+    for (int u = 0; k < nsplit; k += 16, ++u) s[u] += src[(size_t)k * stride];
   }
-  if (db && ws_b && i < (size_t)Cout) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws_b[(size_t)k * Cout + i];
-    db[i] = accumulate ? db[i] + s : s;
+  part[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (wave == 0 && (is_w || is_b)) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane];
+    if (is_w) {
+      const int tap = i / ((size_t)Cout * Cin);
+      const size_t rem = i - (size_t)tap * Cout * Cin;  // co*Cin + ci
+      float* dst = dw + rem * T + tap;
+      *dst = accumulate ? *dst + t : t;
+    } else {
+      const size_t co = i - total;
+      db[co] = accumulate ? db[co] + t : t;
+    }
   }
 }
 
@@ -917,7 +934,7 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
   if (rc) return rc;
   ESS_CHECK_ARG(!(w.taps_variant && db), "wgrad: the stem variant has no bias gradient");
   const size_t total = (size_t)T * d->C_out * cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total > (size_t)d->C_out ? total : d->C_out, 256)),
-                     dim3(256), 0, st, a.ws, a.ws_b, dw, db, w.nsplit, T, d->C_out, cin, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total + d->C_out, 64)), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
+                     w.nsplit, T, d->C_out, cin, accumulate);
   return ess_launch_status("conv2d_wgrad_reduce");
 }
