@@ -209,6 +209,29 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
   if (threadIdx.x == 0) atomicAdd(ws, acc);
 }
 
+// 16-byte variant (n % 4 == 0, aligned pointers): same per-element arithmetic, a quarter of the memory instructions
+__global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, double* ws,
+                                                    f32x4* __restrict__ da, float scale, int64_t n4, int64_t n) {
+  __shared__ double red[16];
+  const float gs = scale / (float)n;
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 va = a[i], vb = b[i];
+    f32x4 g;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = va[j] - vb[j];
+      part += fabsf(d);
+      g[j] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
+    acc += part;
+    if (da) da[i] = g;
+  }
+  acc = block_sum_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(ws, acc);
+}
+
 __global__ void mean_finalize_kernel(const double* ws, float* loss, double denom, float scale) {
   *loss = (float)(ws[0] / denom * scale);
 }
@@ -314,8 +337,12 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
   ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("l1_loss: memset failed"); return ESS_ELAUNCH; }
-  hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                     loss_scale, n);
+  if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0)
+    hipLaunchKernelGGL(l1_x4_kernel, dim3(wave_uniform_grid((size_t)n / 4, 2048)), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b,
+                       (double*)workspace, (f32x4*)da, loss_scale, n / 4, n);
+  else
+    hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+                       loss_scale, n);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
   return ess_launch_status("l1_loss");
 }
