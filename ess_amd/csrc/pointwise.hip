@@ -110,9 +110,18 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 __global__ __launch_bounds__(256) void evnorm_reduce_kernel(const float* __restrict__ x, int64_t n, double* ws) {
   __shared__ double red[16];
   double c = 0, s = 0, ss = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float v = x[i];
-    if (v != 0.f) { c += 1; s += v; ss += (double)v * v; }
+  if ((n & 3) == 0 && (((uintptr_t)x) & 15) == 0) {  // 16-byte loads; zeros contribute nothing to either sum
+    const f32x4* x4 = (const f32x4*)x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+      const f32x4 v = x4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c += v[j] != 0.f ? 1.0 : 0.0; s += v[j]; ss += (double)v[j] * v[j]; }
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const float v = x[i];
+      if (v != 0.f) { c += 1; s += v; ss += (double)v * v; }
+    }
   }
   c = block_sum_d(c, red);
   s = block_sum_d(s, red);
