@@ -315,3 +315,39 @@ def test_full_size_encoder_properties():
     for x32, x16 in zip(outs['fp32'], outs['bf16']):
         assert relerr(x16, x32) < 3e-2
     assert all(torch.isfinite(x).all() for x in outs['bf16'])
+
+
+def test_full_size_uda_step_reproducible_and_batch_consistent():
+    """BASELINE config 3 at full size (B=8, T=5, 2x480x640, K=11, bf16 operands): two independently built trainers
+    fed the same seeded batch produce the same losses step after step (weight gradients reduce in a fixed order;
+    only the fp64 atomics of the norm/loss reductions may reorder, far below the 1e-6 tolerance), every loss is finite,
+    and the optimiser steps change the loss."""
+    from ess_amd import hip
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_trainer import ESSModel
+    from ess_amd.training.synthetic import make_batch
+    B, T, C, H, W, K = 8, 5, 2, 480, 640, 11
+    hip.set_compute('bf16')
+    try:
+        runs = []
+        for rep in range(2):
+            torch.manual_seed(6)
+            tr = ESSModel(synthetic_settings('ess', 'DSEC_events', (H, W), K, B, T, C))
+            cfg = O.e2vid_config(num_bins=C)
+            tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), 41))
+            tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, K), 42, decoder_style=True))
+            tr.front_end_sensor_a.load_state_dict(O.synth_state_dict(O.style_encoder_param_shapes(1), 43))
+            hist = []
+            for s in range(3):
+                ev, img, lab_a, lab_b = make_batch(B, T, C, H, W, K, seed=500 + s, device='cuda')
+                losses, _, final = tr.train_step([[img, lab_a], [ev, lab_b]])
+                hist.append({k: v.item() for k, v in losses.items()} | {'final': final.item()})
+            runs.append(hist)
+        for a, b in zip(*runs):
+            assert set(a) == set(b)
+            for k in a:
+                assert a[k] == a[k] and abs(a[k]) < 1e6, (k, a[k])  # finite
+                assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])), (k, a[k], b[k])
+        assert runs[0][0]['final'] != runs[0][2]['final']  # the optimiser actually moved the weights
+    finally:
+        hip.set_compute('fp32')
