@@ -128,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
           const unsigned pixo = voff[nb] == ESS_OOB ? ESS_OOB : voff[nb] - 4u * half * plane_b;
           if (co < split) ess_bstore(v, r_out, pixo + (unsigned)co * plane_b, 0);
           else if (co < c_out) ess_bstore(v, r_out2, pixo + (unsigned)(co - split) * plane_b, 0);
-        } else {
+        } else if (a.out) {  // (NULL: the caller only wants the BF16_C8 copy)
           ess_bstore(v, r_out, co < c_out ? voff[nb] : ESS_OOB, (unsigned)cu * plane_b);
         }
       }
@@ -198,7 +198,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             const unsigned so = (unsigned)((ct * MB + mb) * 8 + jj) * plane_b;  // hidden channel (+ 4*half in voff)
             const float hn = go * ess_tanh(cn);
             ess_bstore(cn, r_out2, vo(mb, nb, jj), so);
-            ess_bstore(hn, r_out, vo(mb, nb, jj), so);
+            if (a.out) ess_bstore(hn, r_out, vo(mb, nb, jj), so);  // (NULL: only the BF16_C8 copy of h' is wanted)
             hq[jj] = (ct * MB + mb) * 8 + 4 * half + jj < a.hid ? hn : 0.f;
           }
           if (a.out_bf && pixi[nb] >= 0 && ct * MB + mb < ((a.hid + 7) >> 3))  // hidden block ct*MB+mb, channels 4*half..+3

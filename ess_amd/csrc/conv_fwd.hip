@@ -222,7 +222,9 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
                                   const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
-  ESS_CHECK_ARG(src0 && packed_w && out, "conv: null pointer");
+  ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
+  ESS_CHECK_ARG(out || (out_bf16 && d->out_split == 0 && (d->epilogue == ESS_EPI_LINEAR || d->epilogue == ESS_EPI_LSTM)),
+                "conv: `out` may only be NULL when the BF16_C8 copy is requested (LINEAR / LSTM epilogues)");
   ESS_CHECK_ARG(d->C1 == 0 || src1, "conv: second source missing");
   if (d->epilogue == ESS_EPI_LSTM || d->epilogue == ESS_EPI_GRU_UR)
     ESS_CHECK_ARG(shift && out2, "conv: recurrent epilogue needs bias and second output");

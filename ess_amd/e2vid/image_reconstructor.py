@@ -7,10 +7,14 @@ not change results: no CudaTimer device synchronisations inside the hot loop (th
 per time step, e2vid/utils/timers.py:23-26), and an extra keyword `need_image=False` that lets the trainers
 skip the decoder half of the UNet for all but the last time step.
 """
+import os
+
 import torch
 
 from .utils.inference_utils import CropParameters, EventPreprocessor
 
+
+_LEAN = os.environ.get('ESS_LEAN', '1') != '0'  # diagnostic switch: materialise every fp32 state
 
 class ImageReconstructor:
     def __init__(self, model, height, width, num_bins, device, options, augmentation=False, standardization=False):
@@ -35,7 +39,7 @@ class ImageReconstructor:
         self.last_states_for_each_channel = {'grayscale': None}
         self.event_preprocessor = EventPreprocessor(options)
 
-    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, need_image=True):
+    def update_reconstruction(self, event_tensor, event_tensor_id=None, stamp=None, need_image=True, lean_state=False):
         with torch.no_grad():
             events = event_tensor.to(self.device)
             events = self.event_preprocessor(events)
@@ -45,7 +49,10 @@ class ImageReconstructor:
             if need_image:
                 out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'])
             else:
-                out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], encoder_only=True)
+                # lean_state: this step only advances the recurrent state (callers: every time step but the last of a
+                # training / validation sequence); latent is then None and the fp32 hidden states are not materialised
+                out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], encoder_only=True,
+                                                 lean=lean_state and not self.no_recurrent and _LEAN)
             self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
             if self.standardization and out is not None:
                 b, h, w = out.size(0), out.size(2), out.size(3)

@@ -30,6 +30,19 @@ def _attach_c8(t, c8):
     t.ess_c8 = (c8, t._version)
 
 
+def _mark_fp32_unwritten(t):
+    """`t` was allocated but only its BF16_C8 copy was computed (a tensor whose single consumer stages from the copy)."""
+    t.ess_fp32_unwritten = True
+
+
+def _fp32(t):
+    """The fp32 tensor itself -- refused when only the BF16_C8 copy of it exists."""
+    if getattr(t, 'ess_fp32_unwritten', False):
+        raise hip.EssHipError('this tensor was produced as a BF16_C8 copy only (lean recurrent state / internal activation); '
+                              'its fp32 values do not exist')
+    return t
+
+
 def _c8_of(t):
     """The staging copy of `t`, unless `t` was modified in place since the producing kernel wrote both."""
     c8 = getattr(t, 'ess_c8', None)
@@ -95,10 +108,12 @@ class ConvLayer(nn.Module):
             self.norm_layer = nl
         self._fold = _Fold()
 
-    def forward(self, x, x1=None, residual=None, want_c8=False):
+    def forward(self, x, x1=None, residual=None, want_c8=False, c8_only=False):
         """x1: optional second source, channel-concatenated on the fly.
         want_c8: (bf16 arithmetic only) also emit the output as a BF16_C8 staging copy, attached to the returned
-        tensor as `.ess_c8`, for a following 3x3 convolution to stage from (see ConvLSTM.forward)."""
+        tensor as `.ess_c8`, for a following 3x3 / 5x5 convolution to stage from (see ConvLSTM.forward).
+        c8_only: (with want_c8, bf16 arithmetic) do not write the fp32 output at all -- for an activation whose only
+        consumer stages from the copy; the returned tensor is a placeholder that refuses fp32 use (`_fp32`)."""
         _inference_only(x, x1)
         _check_eval(self, self.norm)
         c = self.conv2d
@@ -114,13 +129,17 @@ class ConvLayer(nn.Module):
             c8 = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
         k = c.kernel_size[0]
         x8 = _c8_of(x) if bf and x1 is None and (k == 5 or (k == 3 and c.stride[0] == 1 and c.padding[0] == 1)) else None
+        skip_fp32 = c8_only and c8 is not None
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
-            hip.conv_forward(spec, x8, None, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8,
-                             src_fmt=hip.FMT_BF16_C8)
+            hip.conv_forward(spec, x8, None, packed_weight(spec, c.weight), scale, shift, residual,
+                             out=None if skip_fp32 else out, out_bf=c8, src_fmt=hip.FMT_BF16_C8)
         else:
-            hip.conv_forward(spec, x, x1, packed_weight(spec, c.weight), scale, shift, residual, out=out, out_bf=c8)
+            hip.conv_forward(spec, _fp32(x), None if x1 is None else _fp32(x1), packed_weight(spec, c.weight), scale, shift,
+                             residual, out=None if skip_fp32 else out, out_bf=c8)
         if c8 is not None:
             _attach_c8(out, c8)
+        if skip_fp32:
+            _mark_fp32_unwritten(out)
         return out
 
 
@@ -211,7 +230,9 @@ class ConvLSTM(nn.Module):
         self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=kernel_size // 2)
         self._bias_ver, self._bias = None, None
 
-    def forward(self, input_, prev_state=None):
+    def forward(self, input_, prev_state=None, lean=False):
+        """lean: (bf16 arithmetic, BF16_C8 path) do not write the fp32 hidden state -- only its BF16_C8 copy and the fp32
+        cell; for a time step whose state is consumed by the next step of this module and nothing else."""
         _inference_only(input_)
         N, C, H, W = input_.shape
         hid = self.hidden_size
@@ -239,14 +260,17 @@ class ConvLSTM(nn.Module):
         bf = spec.desc.compute == hip.COMPUTE_BF16 and (C % 8) == 0
         x8, h8 = _c8_of(input_), _c8_of(prev_hidden)
         new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
+        skip_fp32 = lean and new8 is not None
         if bf and x8 is not None and h8 is not None:
-            hip.conv_forward(spec, x8, h8, packed_weight(spec, self.Gates.weight), None, self._bias, aux0=prev_cell, out=hidden,
-                             out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
+            hip.conv_forward(spec, x8, h8, packed_weight(spec, self.Gates.weight), None, self._bias, aux0=prev_cell,
+                             out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
         else:
-            hip.conv_forward(spec, input_, prev_hidden, packed_weight(spec, self.Gates.weight), None, self._bias,
-                             aux0=prev_cell, out=hidden, out2=cell, out_bf=new8)
+            hip.conv_forward(spec, _fp32(input_), _fp32(prev_hidden), packed_weight(spec, self.Gates.weight), None, self._bias,
+                             aux0=prev_cell, out=None if skip_fp32 else hidden, out2=cell, out_bf=new8)
         if new8 is not None:
             _attach_c8(hidden, new8)
+        if skip_fp32:
+            _mark_fp32_unwritten(hidden)
         return hidden, cell
 
 
@@ -303,11 +327,22 @@ class RecurrentConvLayer(nn.Module):
         self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, padding, activation, norm)
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
 
-    def forward(self, x, prev_state):
-        x = self.conv(x, want_c8=self.recurrent_block_type == 'convlstm')
-        state = self.recurrent_block(x, prev_state)
+    def forward(self, x, prev_state, lean=False):
+        lstm = self.recurrent_block_type == 'convlstm'
+        # the conv output never leaves this module: in bf16 arithmetic the ConvLSTM stages it from the BF16_C8 copy
+        # (a 64 | 128 | 256-channel tensor, always a whole number of 8-channel blocks), so its fp32 form is not written
+        x = self.conv(x, want_c8=lstm, c8_only=lstm and self.conv.conv2d.out_channels % 8 == 0 and self._prev_has_c8(prev_state))
+        state = self.recurrent_block(x, prev_state, lean=lean) if lstm else self.recurrent_block(x, prev_state)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state
+
+
+def _rcl_prev_has_c8(self, prev_state):
+    """True when the ConvLSTM will take the BF16_C8 path for this step (zero state, or a state that still carries its copy)."""
+    return prev_state is None or _c8_of(prev_state[0]) is not None
+
+
+RecurrentConvLayer._prev_has_c8 = _rcl_prev_has_c8
 
 
 class ResidualBlock(nn.Module):

@@ -116,16 +116,24 @@ class UNetRecurrent(BaseUNet):
         self.build_decoders()
         self.build_prediction_layer()
 
-    def forward(self, x, prev_states, encoder_only=False):
-        x = self.head(x, want_c8=True)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic only)
+    def forward(self, x, prev_states, encoder_only=False, lean=False):
+        """lean (needs encoder_only; effective in bf16 arithmetic with ConvLSTM blocks): the step's only purpose is the
+        recurrent state for the NEXT step, so the fp32 forms of the head output and of the hidden states are not written
+        (their BF16_C8 copies and the fp32 cell states are); `latent` is None.  Result-identical for the steps t < T-1 of
+        a sequence: the next step stages x and h from the copies anyway."""
+        if lean and not encoder_only:
+            raise ValueError('lean needs encoder_only')
+        x = self.head(x, want_c8=True, c8_only=lean)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic)
         head = x
         if prev_states is None:
             prev_states = [None] * self.num_encoders
         blocks, states = [], []
         for i, encoder in enumerate(self.encoders):
-            x, state = encoder(x, prev_states[i])
+            x, state = encoder(x, prev_states[i], lean=lean)
             blocks.append(x)
             states.append(state)
+        if lean:
+            return None, states, None
         latent = {1: head}
         for i, b in enumerate(blocks):
             latent[2 ** (i + 1)] = b

@@ -79,7 +79,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         for i in range(T):
             # only the encoder half feeds the recurrent state; the image half is needed at the last step only
             img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
-                data_b[:, i * C:(i + 1) * C, :, :], need_image=False)
+                data_b[:, i * C:(i + 1) * C, :, :], need_image=False, lean_state=i < T - 1)
         losses, outputs = {}, {}
         loss, pred_b = self.trainTaskStep('sensor_b', latent_real, labels_b, losses)
         return loss, losses, outputs
@@ -109,7 +109,8 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         T, C = s.nr_events_data_b, s.input_channels_b
         for i in range(T):
-            _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False)
+            _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False,
+                                                                    lean_state=i < T - 1)
         pred = self.models_dict['back_end'](latent)[1]
         if tuple(pred.shape[2:]) != tuple(labels.shape[1:]):
             pred = torch.nn.functional.interpolate(pred, size=tuple(labels.shape[1:]), mode='nearest')

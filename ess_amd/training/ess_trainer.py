@@ -211,7 +211,7 @@ class ESSModel(base_trainer.BaseTrainer):
         with torch.no_grad():
             for i in range(T):
                 img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
-                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1))
+                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1), lean_state=i < T - 1)
         latent_fake = gen_model_sensor_a(img_fake.detach())
         latent_real = {k: v.detach() for k, v in latent_real.items()}
 
@@ -275,7 +275,7 @@ class ESSModel(base_trainer.BaseTrainer):
         rec.last_states_for_each_channel = {'grayscale': None}
         T, C = s.nr_events_data_b, s.input_channels_b
         for i in range(T):
-            _, _, latent = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False)
+            _, _, latent = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False, lean_state=i < T - 1)
         return self.valTaskStep(latent, labels, self.metrics_semseg_b)
 
     def valTaskStep(self, content, labels, metrics):

@@ -114,7 +114,8 @@ int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1,
                        const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream);
 /* src0/src1: fp32 NCHW or bf16 C8 per d->fmt0/fmt1.  out_bf16 (nullable): additionally receives `out` (LINEAR y,
  * LSTM h', GRU_OUT h') as a BF16_C8 tensor [N][ceil(C/8)][H_out][W_out][8] for the next convolution to stage from
- * (bf16 compute only; not with out_split).                                                              */
+ * (bf16 compute only; not with out_split).  With out_bf16 given, `out` may be NULL for the LINEAR and LSTM epilogues:
+ * the fp32 tensor is then not written at all (a producer whose only consumer stages from the copy).               */
 
 /* fp32 NCHW -> BF16_C8 (round to nearest even; tail channels zero).  y: N*ceil(C/8)*H*W*8 bfloat16.        */
 int ess_to_bf16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
