@@ -287,12 +287,14 @@ def test_full_size_encoder_properties():
     ev, _, _, _ = O.synth_batch(B, T, C, H, W, 11, seed=9)
     ev = ev.cuda()
 
-    def run(events, strip_copies=False):
+    def run(events, strip_copies=False, lean=False):
         model = _e2vid(cfg, sd_e)
         states, lat = None, None
         with torch.no_grad():
             for t in range(T):
-                _, states, lat = model(events[:, t * C:(t + 1) * C].contiguous(), states)
+                last = t == T - 1
+                _, states, lat = model(events[:, t * C:(t + 1) * C].contiguous(), states, encoder_only=lean and not last,
+                                       lean=lean and not last)
                 if strip_copies:  # drop the BF16_C8 staging copies: the next step stages from the fp32 tensors
                     states = [(h.clone(), c) for h, c in states]
         return [lat[k].clone() for k in (1, 2, 4, 8)] + [s[1].clone() for s in states]
@@ -309,6 +311,8 @@ def test_full_size_encoder_properties():
             if mode == 'bf16':
                 c = run(ev, strip_copies=True)
                 assert all(torch.equal(x, y) for x, y in zip(a, c)), 'BF16_C8-staged and fp32-staged encoders differ'
+            e = run(ev, lean=True)  # steps t < T-1 advance the state only (no fp32 hidden state / head output is written)
+            assert all(torch.equal(x, y) for x, y in zip(a, e)), f'{mode}: lean recurrent steps change the result'
             outs[mode] = a
         finally:
             hip.set_compute('fp32')
