@@ -355,3 +355,40 @@ def test_full_size_uda_step_reproducible_and_batch_consistent():
         assert runs[0][0]['final'] != runs[0][2]['final']  # the optimiser actually moved the weights
     finally:
         hip.set_compute('fp32')
+
+
+def test_events_to_latents_pipeline_vs_oracle():
+    """SURVEY 8(f)1 joined to the path: raw events -> per-slice voxel grids (ess_voxel_grid_trilinear + normalisation, one
+    launch for all B*T slices) -> [B, T*C, H, W] -> T recurrent encoder steps, against the oracle's VoxelGrid restatement
+    feeding the oracle's E2VID (fp32 arithmetic; tolerance 1e-4 after T steps as in the sequence goldens)."""
+    from ess_amd import hip
+    from ess_amd.datasets.representations import VoxelGrid
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.options.inference_options import default_options
+    B, T, C, H, W, n = 2, 3, 2, 48, 64, 4000
+    xs, ys, ps, ts, offs, ref = [], [], [], [], [0], []
+    for b in range(B):
+        slices = []
+        for t in range(T):
+            x, y, pol, tt = O.synth_events(n + 37 * t, H, W, 100 * b + t)
+            tf = (tt - tt[0]).float()
+            tf = tf / tf[-1]
+            xs.append(x); ys.append(y); ps.append(pol); ts.append(tf); offs.append(offs[-1] + x.numel())
+            slices.append(O.voxel_grid_trilinear(x, y, pol, tf, C, H, W, normalize=True))
+        ref.append(torch.cat(slices, 0))
+    ref_ev = torch.stack(ref)  # [B, T*C, H, W], the channel concatenation of sequence.py:246-249
+    vg = VoxelGrid(C, H, W, normalize=True)
+    ev = vg.convert_sequences(*[torch.cat(v).cuda() for v in (xs, ys, ps, ts)], offs, T)
+    assert ev.shape == ref_ev.shape and relerr(ev, ref_ev) < 1e-5
+    cfg = O.e2vid_config(num_bins=C)
+    sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 77)
+    states, lat_ref = None, None
+    for t in range(T):
+        _, states, lat_ref = O.e2vid_step(sd, cfg, O.crop_pad(O.event_normalize(ref_ev[:, t * C:(t + 1) * C]), 3), states)
+    hip.set_compute('fp32')
+    rec = ImageReconstructor(_e2vid(cfg, sd), H, W, C, torch.device('cuda:0'), default_options())
+    rec.last_states_for_each_channel = {'grayscale': None}
+    for t in range(T):
+        _, _, lat = rec.update_reconstruction(ev[:, t * C:(t + 1) * C], need_image=False, lean_state=t < T - 1)
+    for k in (1, 2, 4, 8):
+        assert relerr(lat[k], lat_ref[k]) < 1e-4, k
