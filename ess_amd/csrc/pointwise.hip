@@ -192,7 +192,8 @@ extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* wo
       return ESS_ELAUNCH;
     }
   }
-  hipLaunchKernelGGL(evnorm_reduce_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, st, x, n, (double*)workspace);
+  // (few workgroups: each ends in three fp64 atomics on the same totals -- 1024 of them serialised for longer than the read took)
+  hipLaunchKernelGGL(evnorm_reduce_kernel, dim3(grid_for(n / 4, 256, 128)), dim3(256), 0, st, x, n, (double*)workspace);
   hipLaunchKernelGGL(evnorm_apply_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n, (const double*)workspace);
   return ess_launch_status("event_normalize");
 }

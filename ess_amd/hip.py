@@ -41,7 +41,7 @@ EXPORTS = [
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
-    'ess_voxel_grid_trilinear', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
+    'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
 ]
 
 
@@ -80,6 +80,8 @@ def lib():
         L.ess_norm_workspace.argtypes = [c_int32]
         L.ess_voxel_normalize_workspace.restype = c_size_t
         L.ess_voxel_normalize_workspace.argtypes = [c_int32]
+        L.ess_voxel_grid_trilinear_workspace.restype = c_size_t
+        L.ess_voxel_grid_trilinear_workspace.argtypes = [c_int64, c_int32, c_int32, c_int32]
         P, F, I, I64 = c_void_p, c_float, c_int32, c_int64
         D = POINTER(EssConvDesc)
         sig = {
@@ -102,7 +104,7 @@ def lib():
             'ess_l1_loss': [P, P, P, P, F, I64, P, P],
             'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
             'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
-            'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P],
+            'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P, c_size_t, I64, P],
             'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
             'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
         }
@@ -330,8 +332,9 @@ def _slice_offsets(offsets, n_events, device):
     return off.to(device)
 
 
-def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, normalize=False):
-    """[n_slices, channels, H, W] grids of VoxelGrid.convert for every slice of a batch in one launch."""
+def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, normalize=False, binned=True):
+    """[n_slices, channels, H, W] grids of VoxelGrid.convert for every slice of a batch in one call.
+    binned=False: the direct 8-atomics-per-event kernel (no workspace); default: tile-binned LDS accumulation."""
     n = x.numel()
     for a in (x, y, pol, t):
         ptr(a)
@@ -340,8 +343,13 @@ def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, n
     off = _slice_offsets(slice_offsets, n, x.device)
     ns = off.numel() - 1
     out = torch.empty(ns, channels, height, width, dtype=torch.float32, device=x.device)
-    _check(lib().ess_voxel_grid_trilinear(ptr(x), ptr(y), ptr(pol), ptr(t), ptr(off, torch.int64), n, ns, channels, height, width,
-                                          ptr(out), stream()), 'ess_voxel_grid_trilinear')
+    L = lib()
+    wsb = L.ess_voxel_grid_trilinear_workspace(n, ns, height, width) if binned and n > 0 else 0
+    ws = workspace(wsb, x.device, 'voxbin') if wsb else None
+    longest = int((off[1:] - off[:-1]).max()) if n > 0 else 0  # (offsets are host knowledge of the caller)
+    _check(L.ess_voxel_grid_trilinear(ptr(x), ptr(y), ptr(pol), ptr(t), ptr(off, torch.int64), n, ns, channels, height, width,
+                                      ptr(out), c_void_p(ws.data_ptr() if ws is not None else 0), wsb, longest, stream()),
+           'ess_voxel_grid_trilinear')
     if normalize:
         voxel_normalize_(out, mode=0)
     return out

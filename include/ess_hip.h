@@ -181,7 +181,12 @@ int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, es
  * out: [n_slices][channels][height][width].                                                          */
 int ess_voxel_grid_trilinear(const float* x, const float* y, const float* pol, const float* t,
                              const int64_t* slice_offsets, int64_t n_events, int32_t n_slices, int32_t channels,
-                             int32_t height, int32_t width, float* out, ess_stream_t stream);
+                             int32_t height, int32_t width, float* out, void* workspace, size_t workspace_bytes,
+                             int64_t max_events_per_slice, ess_stream_t stream);
+/* workspace NULL: every event issues its (up to) 8 atomic adds straight to `out`.  With a workspace of
+ * ess_voxel_grid_trilinear_workspace() bytes and max_events_per_slice = the longest slice (host knowledge: it sizes the
+ * launch), events are first grouped by 32x32-pixel tile and each tile is accumulated in LDS (about 8x faster).      */
+size_t ess_voxel_grid_trilinear_workspace(int64_t n_events, int32_t n_slices, int32_t height, int32_t width);
 /* ess_voxel_grid_temporal replaces generate_voxel_grid (datasets/data_util.py:54-126): integer pixels, fp64
  * timestamps, polarity +1 / -1 (0 counts as -1), bilinear in time only.
  * out: [n_slices][separate_pol ? 2*bins : bins][height][width] (positive bins first; else positive - negative). */

@@ -448,6 +448,11 @@ def test_voxel_trilinear_golden_batch(H, golden):
             out = vg.convert_batch(dev(torch.cat(xs)), dev(torch.cat(ys)), dev(torch.cat(ps)), dev(torch.cat(ts)), offs)
             for i, c in enumerate(cases):
                 assert _vox_close(out[i], c['grid'], 1e-5 if not norm else 1e-4), (C, norm, c['n'])
+            # the direct (8 atomics per event, no workspace) kernel gives the same grids
+            direct = H.voxel_grid_trilinear(dev(torch.cat(xs)), dev(torch.cat(ys)), dev(torch.cat(ps)), dev(torch.cat(ts)), offs, C,
+                                            g['H'], g['W'], normalize=norm, binned=False)
+            for i, c in enumerate(cases):
+                assert _vox_close(direct[i], c['grid'], 1e-5 if not norm else 1e-4), (C, norm, c['n'], 'direct')
             one = vg.convert(dev(xs[0]), dev(ys[0]), dev(ps[0]), dev(ts[0]))  # the reference's single-slice signature
             assert _vox_close(one, cases[0]['grid'], 1e-5 if not norm else 1e-4)
 
@@ -479,6 +484,8 @@ def test_voxel_trilinear_properties_full_size(H):
     offs = [i * n for i in range(S + 1)]
     full = H.voxel_grid_trilinear(dev(x), dev(y), dev(pol), dev(t), offs, C, Hh, Ww)
     assert full.shape == (S, C, Hh, Ww)
+    direct = H.voxel_grid_trilinear(dev(x), dev(y), dev(pol), dev(t), offs, C, Hh, Ww, binned=False)
+    assert (full - direct).abs().max().item() < 1e-4  # tile-binned LDS accumulation vs direct atomics
     # mass: all events are interior in x, y and t in [0, C-1] -> every event contributes exactly its value
     mass = (2 * pol - 1).view(S, n).double().sum(1)
     assert (full.double().sum(dim=(1, 2, 3)).cpu() - mass).abs().max().item() < 0.05  # fp32 sums of 1e5 terms
