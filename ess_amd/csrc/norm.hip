@@ -183,17 +183,41 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
   float mean = 0.f, rstd = 0.f;
   if (MODE == 1) { mean = stats[2 * g]; rstd = stats[2 * g + 1]; }
   double s0 = 0, s1 = 0;
+  // 16-byte loads when the planes allow it (hw % 4 == 0: every segment start is then a multiple of 4 elements); the
+  // per-element arithmetic and its fp64 accumulation are unchanged
+  const bool vec = (hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy)) & 15) == 0;
   for (int j = 0; j < nseg; ++j) {
     const size_t base = ((size_t)j * seg_stride + g) * hw;
-    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-      if (MODE == 0) {
-        const double v = x[base + i];
-        s0 += v; s1 += v * v;
-      } else {
-        const float xh = (x[base + i] - mean) * rstd;
-        float gr = dy[base + i];
-        if (relu && (relu_from_y ? y[base + i] <= 0.f : xh <= 0.f)) gr = 0.f;
-        s0 += gr; s1 += (double)gr * xh;
+    if (vec) {
+      for (int i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+        const f32x4 xv = *(const f32x4*)(x + base + i);
+        if (MODE == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const double v = xv[k]; s0 += v; s1 += v * v; }
+        } else {
+          const f32x4 gv = *(const f32x4*)(dy + base + i);
+          f32x4 yv = xv;
+          if (relu && relu_from_y) yv = *(const f32x4*)(y + base + i);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mean) * rstd;
+            float gr = gv[k];
+            if (relu && (relu_from_y ? yv[k] <= 0.f : xh <= 0.f)) gr = 0.f;
+            s0 += gr; s1 += (double)gr * xh;
+          }
+        }
+      }
+    } else {
+      for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (MODE == 0) {
+          const double v = x[base + i];
+          s0 += v; s1 += v * v;
+        } else {
+          const float xh = (x[base + i] - mean) * rstd;
+          float gr = dy[base + i];
+          if (relu && (relu_from_y ? y[base + i] <= 0.f : xh <= 0.f)) gr = 0.f;
+          s0 += gr; s1 += (double)gr * xh;
+        }
       }
     }
   }
@@ -213,6 +237,24 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (blockIdx.y == 0 && threadIdx.x == 0) { stats[2 * g] = mean; stats[2 * g + 1] = rstd; }
   const size_t base = (size_t)g * hw;
+  if ((hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)y)) & 15) == 0) {  // 16-byte accesses
+    for (int i = 4 * (blockIdx.y * 256 + threadIdx.x); i < hw; i += gridDim.y * 1024) {
+      const f32x4 xv = *(const f32x4*)(x + base + i);
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (res) rv = *(const f32x4*)(res + base + i);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = (xv[k] - mean) * rstd;
+        if (relu == 1) t = fmaxf(t, 0.f);
+        if (res) t += rv[k];
+        if (relu == 2) t = fmaxf(t, 0.f);
+        o[k] = t;
+      }
+      *(f32x4*)(y + base + i) = o;
+    }
+    return;
+  }
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
     float t = (x[base + i] - mean) * rstd;
     if (relu == 1) t = fmaxf(t, 0.f);
@@ -229,6 +271,21 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __
   const float mean = stats[2 * g], rstd = stats[2 * g + 1];
   const float m1 = (float)(sums[2 * g] / hw), m2 = (float)(sums[2 * g + 1] / hw);
   const size_t base = (size_t)g * hw;
+  if ((hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {  // 16-byte accesses
+    for (int i = 4 * (blockIdx.y * 256 + threadIdx.x); i < hw; i += gridDim.y * 1024) {
+      const f32x4 xv = *(const f32x4*)(x + base + i), gv = *(const f32x4*)(dy + base + i);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xv[k] - mean) * rstd;
+        float gr = gv[k];
+        if (relu && xh <= 0.f) gr = 0.f;
+        o[k] = rstd * (gr - m1 - xh * m2);
+      }
+      *(f32x4*)(dx + base + i) = o;
+    }
+    return;
+  }
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
     const float xh = (x[base + i] - mean) * rstd;
     float gr = dy[base + i];
@@ -259,6 +316,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
   const float gm = gamma[c], bt = beta[c];
   const size_t base = (size_t)plane * hw;
+  if ((hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)y)) & 15) == 0) {  // 16-byte accesses
+    for (int i = 4 * (blockIdx.y * 256 + threadIdx.x); i < hw; i += gridDim.y * 1024) {
+      const f32x4 xv = *(const f32x4*)(x + base + i);
+      f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+      if (res) rv = *(const f32x4*)(res + base + i);
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = (xv[k] - mean) * rstd * gm + bt;
+        if (res) t += rv[k];
+        if (relu) t = fmaxf(t, 0.f);
+        o[k] = t;
+      }
+      *(f32x4*)(y + base + i) = o;
+    }
+    return;
+  }
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
     float t = (x[base + i] - mean) * rstd * gm + bt;
     if (res) t += res[base + i];
@@ -282,6 +356,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt), gr = gamma[c] * rstd;
   const size_t base = (size_t)plane * hw;
+  if ((hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)dres)) & 15) == 0) {
+    for (int i = 4 * (blockIdx.y * 256 + threadIdx.x); i < hw; i += gridDim.y * 1024) {  // 16-byte accesses
+      f32x4 g = *(const f32x4*)(dy + base + i);
+      if (relu) {
+        const f32x4 yv = *(const f32x4*)(y + base + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (yv[k] <= 0.f) g[k] = 0.f;
+      }
+      if (dres) *(f32x4*)(dres + base + i) = g;
+      if (dx) {
+        const f32x4 xv = *(const f32x4*)(x + base + i);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = gr * (g[k] - m1 - (xv[k] - mean) * rstd * m2);
+        *(f32x4*)(dx + base + i) = o;
+      }
+    }
+    return;
+  }
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
     float g = dy[base + i];
     if (relu && y[base + i] <= 0.f) g = 0.f;
