@@ -69,6 +69,41 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_kernel(const float* __restric
   const float* gp = dy + base;
   const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
   double s1 = 0, s2 = 0;
+  // small planes (<= 3 x 16 bytes per thread: the 60x80 decoder planes): one 16-byte read of x and dy, the normalised
+  // values and masked gradients stay in registers between the reduction and the map
+  constexpr int MAXV = 3;
+  if ((hw & 3) == 0 && hw <= NT * 4 * MAXV && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+    f32x4 xh[MAXV], g[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = (threadIdx.x + k * NT) * 4;
+      if (i < hw) {
+        const f32x4 xv = *(const f32x4*)(xp + i);
+        g[k] = *(const f32x4*)(gp + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[k][j] = (xv[j] - mean) * rstd;
+          if (relu && xh[k][j] <= 0.f) g[k][j] = 0.f;
+          s1 += g[k][j];
+          s2 += (double)g[k][j] * xh[k][j];
+        }
+      }
+    }
+    s1 = block_sum_d(s1, red);
+    s2 = block_sum_d(s2, red);
+    const float m1 = (float)(s1 / hw), m2 = (float)(s2 / hw);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = (threadIdx.x + k * NT) * 4;
+      if (i < hw) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[k][j] - m1 - xh[k][j] * m2);
+        *(f32x4*)(dx + base + i) = o;
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < hw; i += NT) {
     const float xh = (xp[i] - mean) * rstd;
     float g = gp[i];
