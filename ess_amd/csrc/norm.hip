@@ -14,6 +14,48 @@ __global__ __launch_bounds__(NT) void instnorm_fwd_kernel(const float* __restric
   const size_t base = (size_t)blockIdx.x * hw;
   const float* xp = x + base;
   double s = 0, ss = 0;
+  // small planes (<= 3 x 16 bytes per thread): x is read once and stays in registers between the reduction and the map
+  constexpr int MAXV = 3;
+  if ((hw & 3) == 0 && hw <= NT * 4 * MAXV && ((((uintptr_t)x) | ((uintptr_t)res) | ((uintptr_t)y)) & 15) == 0) {
+    f32x4 xv[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = (threadIdx.x + k * NT) * 4;
+      if (i < hw) {
+        xv[k] = *(const f32x4*)(xp + i);
+        s += (double)xv[k][0] + (double)xv[k][1] + (double)xv[k][2] + (double)xv[k][3];
+        ss += (double)xv[k][0] * xv[k][0] + (double)xv[k][1] * xv[k][1] + (double)xv[k][2] * xv[k][2] + (double)xv[k][3] * xv[k][3];
+      }
+    }
+    s = block_sum_d(s, red);
+    ss = block_sum_d(ss, red);
+    const double mean_d = s / hw;
+    double var = ss / hw - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const int i = (threadIdx.x + k * NT) * 4;
+      if (i < hw) {
+        f32x4 v = xv[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = (v[j] - mean) * rstd;
+          if (relu == 1) t = fmaxf(t, 0.f);
+          v[j] = t;
+        }
+        if (res) { const f32x4 r = *(const f32x4*)(res + base + i); v += r; }
+        if (relu == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *(f32x4*)(y + base + i) = v;
+      }
+    }
+    return;
+  }
   if ((hw & 3) == 0) {
     for (int i = threadIdx.x * 4; i < hw; i += NT * 4) {
       const f32x4 v = *(const f32x4*)(xp + i);
