@@ -329,7 +329,8 @@ def _slice_offsets(offsets, n_events, device):
     off = torch.as_tensor(offsets, dtype=torch.int64)
     if off.dim() != 1 or off.numel() < 2 or int(off[0]) != 0 or int(off[-1]) != n_events or bool((off[1:] < off[:-1]).any()):
         raise EssHipError('slice_offsets must be non-decreasing, start at 0 and end at the number of events')
-    return off.to(device)
+    longest = int((off[1:] - off[:-1]).max()) if off.numel() > 1 else 0  # host-side: sizes the binning launches
+    return off.to(device), longest
 
 
 def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, normalize=False, binned=True):
@@ -340,13 +341,12 @@ def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, n
         ptr(a)
         if a.numel() != n or a.dim() != 1:
             raise EssHipError('x, y, pol, t must be 1-D and of equal length')
-    off = _slice_offsets(slice_offsets, n, x.device)
+    off, longest = _slice_offsets(slice_offsets, n, x.device)
     ns = off.numel() - 1
     out = torch.empty(ns, channels, height, width, dtype=torch.float32, device=x.device)
     L = lib()
     wsb = L.ess_voxel_grid_trilinear_workspace(n, ns, height, width) if binned and n > 0 else 0
     ws = workspace(wsb, x.device, 'voxbin') if wsb else None
-    longest = int((off[1:] - off[:-1]).max()) if n > 0 else 0  # (offsets are host knowledge of the caller)
     _check(L.ess_voxel_grid_trilinear(ptr(x), ptr(y), ptr(pol), ptr(t), ptr(off, torch.int64), n, ns, channels, height, width,
                                       ptr(out), c_void_p(ws.data_ptr() if ws is not None else 0), wsb, longest, stream()),
            'ess_voxel_grid_trilinear')
@@ -358,7 +358,7 @@ def voxel_grid_trilinear(x, y, pol, t, slice_offsets, channels, height, width, n
 def voxel_grid_temporal(x, y, t, pol, slice_offsets, bins, height, width, separate_pol=True, normalize=False):
     """generate_voxel_grid for every slice of a batch: x, y int32 pixels, t float64, pol float32 (+1/-1, 0 = -1)."""
     n = x.numel()
-    off = _slice_offsets(slice_offsets, n, x.device)
+    off, _ = _slice_offsets(slice_offsets, n, x.device)
     ns = off.numel() - 1
     out = torch.empty(ns, (2 if separate_pol else 1) * bins, height, width, dtype=torch.float32, device=x.device)
     _check(lib().ess_voxel_grid_temporal(ptr(x, torch.int32), ptr(y, torch.int32), ptr(t, torch.float64), ptr(pol),
