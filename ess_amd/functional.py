@@ -49,7 +49,11 @@ class Conv2dFn(torch.autograd.Function):
     transposed weights) + weight gradient kernel, each only when needed."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1):
+    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1, passthrough=False):
+        """passthrough=True additionally returns x0 itself as a second output.  A residual block uses THAT as its
+        skip operand (y = f(conv(x)) + x_passthrough), so the gradient of the skip branch arrives in this function's
+        backward next to the conv's own and is added inside the data-gradient kernel's epilogue (`residual`), instead
+        of by a separate elementwise add that autograd would launch for a tensor with two consumers."""
         N, C0 = x0.shape[0], x0.shape[1]
         C1 = x1.shape[1] if x1 is not None else 0
         Hv, Wv = _virt(x0, mode0)
@@ -66,10 +70,11 @@ class Conv2dFn(torch.autograd.Function):
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
         ctx.save_for_backward(x0, x1, weight)
-        return out
+        ctx.passthrough = passthrough
+        return (out, x0) if passthrough else out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_skip=None):
         x0, x1, weight = ctx.saved_tensors
         spec = ctx.spec
         (N, Hv, Wv, C0, C1, mode0, mode1, Cout, k, s, p, _, _, _, _, _) = spec.key
@@ -89,7 +94,12 @@ class Conv2dFn(torch.autograd.Function):
             assert (dspec.H_out, dspec.W_out) == (Hv, Wv), (dspec.H_out, dspec.W_out, Hv, Wv)
             dv0 = torch.empty(N, C0, Hv, Wv, dtype=torch.float32, device=dy.device)
             dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if C1 > 0 else None
-            hip.conv_forward(dspec, dy, None, packed_weight(dspec, weight, kind=hip.W_TRANSPOSED), out=dv0, out2=dv1)
+            # the skip-branch gradient (see forward) rides in the epilogue when the data-gradient IS d(x0)
+            fuse_skip = d_skip is not None and need0 and C1 == 0 and mode0 == hip.SRC_DIRECT
+            hip.conv_forward(dspec, dy, None, packed_weight(dspec, weight, kind=hip.W_TRANSPOSED),
+                             residual=d_skip.contiguous() if fuse_skip else None, out=dv0, out2=dv1)
+            if fuse_skip:
+                d_skip = None
             if need0:
                 d0 = hip.sumpool2x2(dv0) if mode0 == hip.SRC_NEAREST_UP2 else dv0
             if need1:
@@ -120,7 +130,9 @@ class Conv2dFn(torch.autograd.Function):
                 dw = None
             if not needb:
                 db = None
-        return d0, d1, dw, db, None, None, None, None
+        if d_skip is not None and need0:  # not fusable (or no data-gradient was computed): plain sum
+            d0 = d_skip if d0 is None else hip.add(d0, d_skip.contiguous())
+        return d0, d1, dw, db, None, None, None, None, None
 
 
 def _wgrad_stride2_by_phases(x, dy, dw, db, k):
@@ -149,6 +161,11 @@ def _wgrad_stride2_by_phases(x, dy, dw, db, k):
 
 def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT):
     return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1)
+
+
+def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0):
+    """-> (conv2d(x0), x0): use the second value as the skip operand of a residual block (see Conv2dFn.forward)."""
+    return Conv2dFn.apply(x0, None, weight, bias, stride, pad, hip.SRC_DIRECT, hip.SRC_DIRECT, True)
 
 
 class InstanceNormFn(torch.autograd.Function):

@@ -57,10 +57,12 @@ class INSResBlock(nn.Module):
 
     def forward(self, x):
         c1, c2 = self.model[0], self.model[3]
-        y = Fn.conv2d(x, c1.weight, c1.bias, c1.stride[0], 1)
+        # x enters the graph ONCE: conv1 hands it through as the skip operand, so the skip gradient is added inside
+        # conv1's data-gradient kernel instead of by a separate elementwise pass (functional.Conv2dFn.forward)
+        y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1)
         y = Fn.instance_norm(y, None, True, self.model[1].eps)
         y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1)
-        return Fn.instance_norm(y, x, False, self.model[4].eps)  # IN(.) + residual in one pass
+        return Fn.instance_norm(y, skip, False, self.model[4].eps)  # IN(.) + residual in one pass
 
 
 class SemSegE2VID(nn.Module):
@@ -134,14 +136,20 @@ class _ConvBN(nn.Module):
     statistics; eval mode = one fused conv kernel with the running statistics folded into its epilogue."""
 
     @staticmethod
-    def run(conv, bn, x, residual=None, relu=True):
+    def run(conv, bn, x, residual=None, relu=True, passthrough=False):
+        """passthrough (train mode): -> (out, x handed through conv's autograd node) for an identity skip."""
         if bn.training:
-            y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0])
+            if passthrough:
+                y, skip = Fn.conv2d_passthrough(x, conv.weight, None, conv.stride[0], conv.padding[0])
+            else:
+                y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0])
             out = Fn.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu,
                                       bn.momentum, bn.eps)
             with torch.no_grad():
                 bn.num_batches_tracked += 1
-            return out
+            return (out, skip) if passthrough else out
+        if passthrough:
+            raise NotImplementedError('passthrough is a train-mode (autograd) feature')
         if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
             raise NotImplementedError('eval-mode BatchNorm is forward-only here (validation runs under no_grad, '
                                       'training/base_trainer.py:419)')
@@ -175,10 +183,15 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
         if self.downsample is not None:
             identity = _ConvBN.run(self.downsample[0], self.downsample[1], x, None, relu=False)
-        out = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True)
+            out = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True)
+        elif self.bn1.training:
+            # identity skip: x enters the graph once, conv1 hands it through (skip gradient added in its dgrad epilogue)
+            out, identity = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True, passthrough=True)
+        else:
+            identity = x
+            out = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True)
         return _ConvBN.run(self.conv2, self.bn2, out, identity, relu=True)
 
 
