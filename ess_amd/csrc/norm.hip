@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restric
 // group g covers `nseg` segments of `hw` contiguous floats, segment j at ((j * seg_stride) + g) * hw
 // (InstanceNorm: nseg = 1; BatchNorm: nseg = N, seg_stride = C).
 
-// sums[g][0] += sum f0, sums[g][1] += sum f1 with (f0, f1) = (x, x^2) [MODE 0] or (g, g*xhat) [MODE 1, backward]
+// sums[g][slice][0..1] = (sum f0, sum f1) over the slice, with (f0, f1) = (x, x^2) [MODE 0] or (g, g*xhat) [MODE 1, backward]
 template <int MODE>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ stats,
@@ -300,16 +300,25 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
   }
   s0 = block_sum_d(s0, red);
   s1 = block_sum_d(s1, red);
-  if (threadIdx.x == 0) { atomicAdd(sums + 2 * g, s0); atomicAdd(sums + 2 * g + 1, s1); }
+  // one partial per (group, slice): no atomics, no zeroing of the workspace, and a fixed summation order downstream
+  if (threadIdx.x == 0) { sums[((size_t)g * nsl + sl) * 2] = s0; sums[((size_t)g * nsl + sl) * 2 + 1] = s1; }
+}
+
+// total of a group's partials (wave-uniform addresses: scalar loads), in slice order
+__device__ __forceinline__ void group_total(const double* sums, int g, int nsl, double& t0, double& t1) {
+  t0 = 0; t1 = 0;
+  for (int k = 0; k < nsl; ++k) { t0 += sums[((size_t)g * nsl + k) * 2]; t1 += sums[((size_t)g * nsl + k) * 2 + 1]; }
 }
 
 // InstanceNorm forward map: y = act(IN(x)) (+ residual) from the group sums; (chunk 0, thread 0) writes (mean, rstd)
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              float* __restrict__ y, float* __restrict__ stats,
-                                                             const double* sums, int hw, float eps, int relu) {
+                                                             const double* sums, int nsl, int hw, float eps, int relu) {
   const int g = blockIdx.x;
-  const double mean_d = sums[2 * g] / hw;
-  double var = sums[2 * g + 1] / hw - mean_d * mean_d;
+  double t0, t1;
+  group_total(sums, g, nsl, t0, t1);
+  const double mean_d = t0 / hw;
+  double var = t1 / hw - mean_d * mean_d;
   if (var < 0) var = 0;
   const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (blockIdx.y == 0 && threadIdx.x == 0) { stats[2 * g] = mean; stats[2 * g + 1] = rstd; }
@@ -342,11 +351,13 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 const float* __restrict__ stats, const double* sums,
+                                                                 const float* __restrict__ stats, const double* sums, int nsl,
                                                                  float* __restrict__ dx, int hw, int relu) {
   const int g = blockIdx.x;
   const float mean = stats[2 * g], rstd = stats[2 * g + 1];
-  const float m1 = (float)(sums[2 * g] / hw), m2 = (float)(sums[2 * g + 1] / hw);
+  double t0, t1;
+  group_total(sums, g, nsl, t0, t1);
+  const float m1 = (float)(t0 / hw), m2 = (float)(t1 / hw);
   const size_t base = (size_t)g * hw;
   if ((hw & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {  // 16-byte accesses
     for (int i = 4 * (blockIdx.y * 256 + threadIdx.x); i < hw; i += gridDim.y * 1024) {
@@ -376,11 +387,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* running_mean, float* running_var, float momentum, float eps,
                                                        float* __restrict__ y, float* __restrict__ stats, const double* sums,
-                                                       int N, int C, int hw, int relu) {
+                                                       int nsl, int N, int C, int hw, int relu) {
   const int plane = blockIdx.x, c = plane % C;
   const double cnt = (double)N * hw;
-  const double mean_d = sums[2 * c] / cnt;
-  double var = sums[2 * c + 1] / cnt - mean_d * mean_d;
+  double t0, t1;
+  group_total(sums, c, nsl, t0, t1);
+  const double mean_d = t0 / cnt;
+  double var = t1 / cnt - mean_d * mean_d;
   if (var < 0) var = 0;
   const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
   if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -420,13 +433,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ gamma,
-                                                           const float* __restrict__ stats, const double* sums,
+                                                           const float* __restrict__ stats, const double* sums, int nsl,
                                                            float* __restrict__ dx, float* __restrict__ dres, float* dgamma,
                                                            float* dbeta, int accumulate, int N, int C, int hw, int relu) {
   const int plane = blockIdx.x, c = plane % C;
   const float mean = stats[2 * c], rstd = stats[2 * c + 1];
   const double cnt = (double)N * hw;
-  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  double s1, s2;
+  group_total(sums, c, nsl, s1, s2);
   if (plane < C && blockIdx.y == 0 && threadIdx.x == 0) {
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
@@ -472,16 +486,15 @@ inline int chunks_for(int planes, int hw) {
   if (c > maxc) c = maxc;
   return c < 1 ? 1 : c;
 }
-inline int zero_ws(void* ws, size_t need, size_t have, hipStream_t st, const char* what) {
+inline int zero_ws(void* ws, size_t need, size_t have, hipStream_t, const char* what) {  // (nothing left to zero: see group_reduce_kernel)
   if (!ws || have < need) { ess_set_error("%s: workspace too small (%zu < %zu)", what, have, need); return ESS_EINVAL; }
-  hipError_t e = hipMemsetAsync(ws, 0, need, st);
-  if (e != hipSuccess) { ess_set_error("%s: memset failed: %s", what, hipGetErrorString(e)); return ESS_ELAUNCH; }
   return ESS_OK;
 }
 
 }  // namespace
 
-extern "C" size_t ess_norm_workspace(int32_t groups) { return (size_t)(groups > 0 ? groups : 0) * 16; }
+// one (sum, sum) pair of doubles per group and slice; split_for() keeps groups * slices <= 2048 + groups
+extern "C" size_t ess_norm_workspace(int32_t groups) { return (size_t)(groups > 0 ? groups + 2048 : 0) * 16; }
 
 extern "C" int ess_instnorm_forward(const float* x, const float* residual, float* y, float* stats, int32_t planes, int32_t hw,
                                     float eps, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
@@ -496,7 +509,7 @@ extern "C" int ess_instnorm_forward(const float* x, const float* residual, float
   hipLaunchKernelGGL((group_reduce_kernel<0>), dim3(planes, split_for(planes, hw)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      (double*)workspace, hw, 1, 0, 0, 0);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(planes, chunks_for(planes, hw)), dim3(256), 0, st, x, residual, y, stats,
-                     (const double*)workspace, hw, eps, relu);
+                     (const double*)workspace, split_for(planes, hw), hw, eps, relu);
   return ess_launch_status("instnorm_forward(split)");
 }
 
@@ -514,7 +527,7 @@ extern "C" int ess_instnorm_backward(const float* x, const float* dy, const floa
   hipLaunchKernelGGL((group_reduce_kernel<1>), dim3(planes, split_for(planes, hw)), dim3(256), 0, st, x, nullptr, dy, stats,
                      (double*)workspace, hw, 1, 0, relu, 0);
   hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(planes, chunks_for(planes, hw)), dim3(256), 0, st, x, dy, stats,
-                     (const double*)workspace, dx, hw, relu);
+                     (const double*)workspace, split_for(planes, hw), dx, hw, relu);
   return ess_launch_status("instnorm_backward(split)");
 }
 
@@ -530,7 +543,7 @@ extern "C" int ess_batchnorm_train_forward(const float* x, const float* residual
   hipLaunchKernelGGL((group_reduce_kernel<0>), dim3(C, split_for(C, hw)), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
                      (double*)workspace, hw, N, C, 0, 0);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(N * C, chunks_for(N * C, hw)), dim3(256), 0, st, x, residual, gamma, beta, running_mean,
-                     running_var, momentum, eps, y, stats, (const double*)workspace, N, C, hw, relu);
+                     running_var, momentum, eps, y, stats, (const double*)workspace, split_for(C, hw), N, C, hw, relu);
   return ess_launch_status("batchnorm_train_forward");
 }
 
@@ -545,6 +558,6 @@ extern "C" int ess_batchnorm_train_backward(const float* x, const float* y, cons
   hipLaunchKernelGGL((group_reduce_kernel<1>), dim3(C, split_for(C, hw)), dim3(256), 0, st, x, y, dy, stats, (double*)workspace, hw,
                      N, C, relu, 1);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(N * C, chunks_for(N * C, hw)), dim3(256), 0, st, x, y, dy, gamma, stats,
-                     (const double*)workspace, dx, d_residual, dgamma, dbeta, accumulate, N, C, hw, relu);
+                     (const double*)workspace, split_for(C, hw), dx, d_residual, dgamma, dbeta, accumulate, N, C, hw, relu);
   return ess_launch_status("batchnorm_train_backward");
 }

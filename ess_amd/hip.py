@@ -253,7 +253,7 @@ def instnorm_forward(x, residual, relu, eps=1e-5):
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
-    ws = workspace(N * C * 16, x.device, 'norm')
+    ws = workspace(lib().ess_norm_workspace(N * C), x.device, 'norm')
     _check(lib().ess_instnorm_forward(ptr(x), ptr(residual), ptr(y), ptr(stats), N * C, H * W, c_float(eps), int(relu),
                                       c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_forward')
     return y, stats
@@ -262,7 +262,7 @@ def instnorm_forward(x, residual, relu, eps=1e-5):
 def instnorm_backward(x, dy, stats, relu):
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
-    ws = workspace(N * C * 16, x.device, 'norm')
+    ws = workspace(lib().ess_norm_workspace(N * C), x.device, 'norm')
     _check(lib().ess_instnorm_backward(ptr(x), ptr(dy), ptr(stats), ptr(dx), N * C, H * W, int(relu),
                                        c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward')
     return dx
@@ -272,7 +272,7 @@ def batchnorm_train_forward(x, residual, gamma, beta, running_mean, running_var,
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
-    ws = workspace(C * 16, x.device, 'norm')
+    ws = workspace(lib().ess_norm_workspace(C), x.device, 'norm')
     _check(lib().ess_batchnorm_train_forward(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(running_mean),
                                              ptr(running_var), c_float(momentum), c_float(eps), ptr(y), ptr(stats), N, C,
                                              H * W, int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
@@ -285,7 +285,7 @@ def batchnorm_train_backward(x, y, dy, gamma, stats, relu, need_dx=True, need_dr
     N, C, H, W = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dres = torch.empty_like(x) if need_dres else None
-    ws = workspace(C * 16, x.device, 'norm')
+    ws = workspace(lib().ess_norm_workspace(C), x.device, 'norm')
     _check(lib().ess_batchnorm_train_backward(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(stats), ptr(dx), ptr(dres),
                                               ptr(dgamma), ptr(dbeta), int(accumulate), N, C, H * W, int(relu),
                                               c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),

@@ -323,8 +323,8 @@ def test_full_size_encoder_properties():
 
 def test_full_size_uda_step_reproducible_and_batch_consistent():
     """BASELINE config 3 at full size (B=8, T=5, 2x480x640, K=11, bf16 operands): two independently built trainers
-    fed the same seeded batch produce the same losses step after step (weight gradients reduce in a fixed order;
-    only the fp64 atomics of the norm/loss reductions may reorder, far below the 1e-6 tolerance), every loss is finite,
+    fed the same seeded batch produce the same losses step after step (weight gradients and norm statistics reduce in a
+    fixed order; only the fp64 atomics of the loss reductions may reorder, far below the 1e-6 tolerance), every loss is finite,
     and the optimiser steps change the loss."""
     from ess_amd import hip
     from ess_amd.config.settings import synthetic_settings
