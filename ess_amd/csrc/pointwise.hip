@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void sumpool2_x2_kernel(const float* __restric
 }
 
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0) {  // 16-byte accesses
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x)
+      ((f32x4*)y)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a[i] + b[i];
 }

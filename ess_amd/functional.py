@@ -30,6 +30,20 @@ def packed_weight(spec, w, w2=None, kind=hip.W_CONV):
     return pw
 
 
+def packed_rows(spec, v):
+    """Tile-padded copy of a per-output-channel vector (a conv bias), cached like packed_weight."""
+    ent = _pack_cache.get(id(v))
+    ver = (v._version, -1, v.data_ptr())
+    if ent is None or ent[0]() is not v or ent[1] != ver:
+        ent = (weakref.ref(v, lambda _, k=id(v): _pack_cache.pop(k, None)), ver, {})
+        _pack_cache[id(v)] = ent
+    key = (spec.plan.rows_padded, spec.desc.epilogue, 'rows')
+    pr = ent[2].get(key)
+    if pr is None:
+        pr = ent[2][key] = hip.pack_rows(spec, v.detach())
+    return pr
+
+
 def invalidate_packed(params):
     """Drop cached re-layouts of tensors that a kernel modified through a raw pointer (the flat RAdam update does
     not bump ``_version``)."""
@@ -64,7 +78,7 @@ class Conv2dFn(torch.autograd.Function):
             raise hip.EssHipError(f'Conv2dFn: weight expects {weight.shape[1]} input channels, got {C0}+{C1}')
         spec = hip.conv_spec(N, Hv, Wv, C0, C1, Cout, k, stride, pad, mode0, mode1)
         out = torch.empty(N, Cout, spec.H_out, spec.W_out, dtype=torch.float32, device=x0.device)
-        shift = hip.pack_rows(spec, bias.detach()) if bias is not None else None
+        shift = packed_rows(spec, bias) if bias is not None else None
         hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out)
         ctx.spec = spec
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None

@@ -131,6 +131,17 @@ class SemSegE2VID(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
+_PENDING_BN_COUNTERS = []
+
+
+def flush_bn_counters():
+    """num_batches_tracked += 1 for every train-mode BatchNorm that ran since the last flush, as one multi-tensor launch."""
+    if _PENDING_BN_COUNTERS:
+        with torch.no_grad():
+            torch._foreach_add_(_PENDING_BN_COUNTERS, 1)
+        _PENDING_BN_COUNTERS.clear()
+
+
 class _ConvBN(nn.Module):
     """Bias-free conv + BatchNorm2d (+residual) (+ReLU): train mode = conv kernel + BN plane kernel with batch
     statistics; eval mode = one fused conv kernel with the running statistics folded into its epilogue."""
@@ -145,8 +156,7 @@ class _ConvBN(nn.Module):
                 y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0])
             out = Fn.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu,
                                       bn.momentum, bn.eps)
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
+            _PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # incremented together (flush_bn_counters): 1 launch, not 15
             return (out, skip) if passthrough else out
         if passthrough:
             raise NotImplementedError('passthrough is a train-mode (autograd) feature')
@@ -265,6 +275,7 @@ class StyleEncoderE2VID(nn.Module):
             self.update_skip_dict(out, x, sz_in)
         x = self.encoder_scale_3(x)
         self.update_skip_dict(out, x, sz_in)
+        flush_bn_counters()
         return out
 
 
