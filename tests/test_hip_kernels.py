@@ -602,3 +602,20 @@ def test_bf16_c8_roundtrip_and_refusals(H):
     with pytest.raises(H.EssHipError):
         H.conv_forward(spec32, dev(torch.randn(1, 8, 8, 8)), None, w32, out=torch.empty(1, 8, 8, 8, device='cuda'),
                        out_bf=H.bf16_c8_empty(1, 8, 8, 8, 'cuda'))
+
+
+@pytest.mark.parametrize('shape', [(3, 30, 50), (5, 33, 65), (2, 200, 346), (7, 64, 128)])
+def test_voxel_trilinear_partial_tiles_vs_oracle(H, shape):
+    """grids that are not whole 64x32 tiles (incl. the DDD17 346-wide frame), 1..7 channels, ragged slices, both variants"""
+    C, Hh, Ww = shape
+    xs, ys, ps, ts, offs, refs = [], [], [], [], [0], []
+    for s, n in enumerate((5000, 1, 777, 12000)):
+        x, y, pol, t = O.synth_events(n, Hh, Ww, 900 + 10 * C + s)
+        tf = _slice_time(t)
+        xs.append(x); ys.append(y); ps.append(pol); ts.append(tf); offs.append(offs[-1] + n)
+        refs.append(O.voxel_grid_trilinear(x, y, pol, tf, C, Hh, Ww, False))
+    args = [dev(torch.cat(v)) for v in (xs, ys, ps, ts)]
+    for binned in (True, False):
+        out = H.voxel_grid_trilinear(*args, offs, C, Hh, Ww, binned=binned)
+        for i, r in enumerate(refs):
+            assert _vox_close(out[i], torch.nan_to_num(r)), (shape, binned, i)
