@@ -228,3 +228,26 @@ def test_checkpoint_saver_roundtrip(tmp_path):
     c = make(4)
     saver.load_pretrained_weights({'back_end': c, 'front_sensor_b': None}, ['front_sensor_b', 'back_end'], checkpoint_file=str(path))
     assert all(torch.equal(sa[k], c.state_dict()[k]) for k in sa)
+
+
+def test_voxel_api_mirrors_reference_and_refuses_cpu(built_lib):
+    """ess_amd.datasets mirrors DSEC/dataset/representations.py and datasets/data_util.py by name; without a GPU the
+    product refuses to run (no host fallback: the host algorithm lives in oracle/ only)."""
+    from ess_amd import hip
+    from ess_amd.datasets import data_util
+    from ess_amd.datasets.representations import EventRepresentation, VoxelGrid
+    vg = VoxelGrid(2, 8, 8, normalize=False)
+    assert isinstance(vg, EventRepresentation) and vg.nb_channels == 2
+    x = torch.zeros(4)
+    with pytest.raises(hip.EssHipError):
+        vg.convert(x, x, x, x)
+    with pytest.raises(hip.EssHipError):
+        data_util.generate_voxel_grid(torch.zeros(4, 4, dtype=torch.float64), (8, 8), 2)
+    with pytest.raises(NotImplementedError):
+        data_util.generate_input_representation(torch.zeros(4, 4), 'histogram', (8, 8))
+    lib = ctypes.CDLL(built_lib)
+    lib.ess_voxel_grid_trilinear_workspace.restype = ctypes.c_size_t
+    lib.ess_voxel_grid_trilinear_workspace.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    ws = lib.ess_voxel_grid_trilinear_workspace(4_000_000, 40, 480, 640)
+    assert 4_000_000 * 16 <= ws < 4_000_000 * 16 + (32 << 20)  # sorted events + per-tile tables (halo table sized for 7 channels)
+    assert lib.ess_voxel_grid_trilinear_workspace(0, 40, 480, 640) == 0
