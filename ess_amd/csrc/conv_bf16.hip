@@ -771,7 +771,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     else { if (mb == 2) launch_pair<2, 2>(c8, grid, lds2, st, a); else launch_pair<2, 1>(c8, grid, lds2, st, a); }
     return ess_launch_status("conv2d_forward(bf16, tap-paired)");
   }
-  static const bool use_ws = [] { const char* e = getenv("ESS_CONV_WS"); return !(e && e[0] == '0'); }();
+  const bool use_ws = ws_enabled();
   if (use_ws && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
     if (lds2 <= 160 * 1024) {

@@ -268,12 +268,18 @@ inline int pick_ck(const EssConvDesc* d) {
   return d->ksize >= 7 ? 2 : (d->ksize == 5 ? 4 : 8);
 }
 
+// diagnostic switch ESS_CONV_WS=0: the generic tile kernel instead of the wave-specialised 3x3 one
+inline bool ws_enabled() {
+  static const bool on = [] { const char* e = getenv("ESS_CONV_WS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 inline int packed_rows(const EssConvDesc* d);
 inline int pick_mb(const EssConvDesc* d) {
   // bf16 3x3/s1 (wave-specialised kernel): 128-channel tiles where there are enough output channels -- halves the
   // activation staging and the weight re-fetch per MFMA
   // (measured: pays only for the deepest layer -- 512 -> 1024 @ 60x80: 779 -> 859 TFLOP/s; one workgroup per CU hurts the rest)
-  if (d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= 512) {
+  if (ws_enabled() && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= 512) {
     static const bool mb4 = [] { const char* e = getenv("ESS_CONV_MB4"); return !(e && e[0] == '0'); }();
     if (mb4) return 4;
   }

@@ -128,7 +128,7 @@ class ConvLayer(nn.Module):
         if want_c8 and bf:
             c8 = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
         k = c.kernel_size[0]
-        x8 = _c8_of(x) if bf and x1 is None and (k == 5 or (k == 3 and c.stride[0] == 1 and c.padding[0] == 1)) else None
+        x8 = _c8_of(x) if bf and x1 is None and hip.c8_stageable(k, c.stride[0], c.padding[0]) else None
         skip_fp32 = c8_only and c8 is not None
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
             hip.conv_forward(spec, x8, None, packed_weight(spec, c.weight), scale, shift, residual,
@@ -258,9 +258,10 @@ class ConvLSTM(nn.Module):
         # tile loads are 16-byte vectors instead of 8 strided dwords.  A state tensor that went through user code
         # (clone, detach, arithmetic) simply has no copy any more and takes the fp32 path.
         bf = spec.desc.compute == hip.COMPUTE_BF16 and (C % 8) == 0
-        x8, h8 = _c8_of(input_), _c8_of(prev_hidden)
+        stage8 = bf and hip.c8_stageable(3, 1, 1)
+        x8, h8 = (_c8_of(input_), _c8_of(prev_hidden)) if stage8 else (None, None)
         new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
-        skip_fp32 = lean and new8 is not None
+        skip_fp32 = lean and new8 is not None and stage8
         if bf and x8 is not None and h8 is not None:
             hip.conv_forward(spec, x8, h8, packed_weight(spec, self.Gates.weight), None, self._bias, aux0=prev_cell,
                              out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
@@ -331,7 +332,8 @@ class RecurrentConvLayer(nn.Module):
         lstm = self.recurrent_block_type == 'convlstm'
         # the conv output never leaves this module: in bf16 arithmetic the ConvLSTM stages it from the BF16_C8 copy
         # (a 64 | 128 | 256-channel tensor, always a whole number of 8-channel blocks), so its fp32 form is not written
-        x = self.conv(x, want_c8=lstm, c8_only=lstm and self.conv.conv2d.out_channels % 8 == 0 and self._prev_has_c8(prev_state))
+        x = self.conv(x, want_c8=lstm, c8_only=lstm and self.conv.conv2d.out_channels % 8 == 0 and hip.c8_stageable(3, 1, 1) and
+                      self._prev_has_c8(prev_state))
         state = self.recurrent_block(x, prev_state, lean=lean) if lstm else self.recurrent_block(x, prev_state)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state

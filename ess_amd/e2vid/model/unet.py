@@ -123,6 +123,8 @@ class UNetRecurrent(BaseUNet):
         a sequence: the next step stages x and h from the copies anyway."""
         if lean and not encoder_only:
             raise ValueError('lean needs encoder_only')
+        # every consumer of the unwritten fp32 tensors must be able to stage their BF16_C8 copies (diagnostic switches may forbid it)
+        lean = lean and hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2)
         x = self.head(x, want_c8=True, c8_only=lean)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic)
         head = x
         if prev_states is None:

@@ -207,6 +207,16 @@ def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=No
     return out
 
 
+def c8_stageable(ksize, stride, pad):
+    """Can a bf16 convolution of this geometry stage BF16_C8 sources?  Only the wave-specialised 3x3 and the tap-paired 5x5
+    kernels do; both can be switched off for diagnostics (ESS_CONV_WS=0 / ESS_CONV_PAIR=0, read by the library as well)."""
+    if ksize == 3:
+        return stride == 1 and pad == 1 and os.environ.get('ESS_CONV_WS', '1')[:1] != '0'
+    if ksize == 5:
+        return os.environ.get('ESS_CONV_PAIR', '1')[:1] != '0'
+    return False
+
+
 def bf16_c8_empty(N, C, H, W, device):
     """Uninitialised BF16_C8 tensor for a logical [N, C, H, W] activation: bf16 [N][ceil(C/8)][H][W][8]."""
     return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)

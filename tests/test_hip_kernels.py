@@ -522,6 +522,8 @@ def test_voxel_refuses_bad_input(H):
     (1, 256, 256, 12, 20, 'lstm'),   # deep level: MB=4 path
 ])
 def test_conv_bf16_c8_sources_and_copy(H, case):
+    if not H.c8_stageable(3, 1, 1):
+        pytest.skip('ESS_CONV_WS=0: only the wave-specialised kernel stages BF16_C8 sources')
     g = torch.Generator().manual_seed(11)
     if case[-1] == 'lstm':
         N, C, hid, Hh, Ww, _ = case
@@ -567,6 +569,8 @@ def test_conv_bf16_c8_sources_and_copy(H, case):
 def test_conv5x5_paired_c8_sources(H, case):
     """5x5 (tap-paired kernel), stride 1 and 2: BF16_C8 sources give the same bits as fp32 NCHW sources, and both
     match fp32 math on bf16-rounded operands."""
+    if not H.c8_stageable(5, 1, 2):
+        pytest.skip('ESS_CONV_PAIR=0: only the tap-paired kernel stages BF16_C8 sources')
     N, C, Cout, Hh, Ww, s = case
     g = torch.Generator().manual_seed(21)
     x = torch.randn(N, C, Hh, Ww, generator=g)
