@@ -232,57 +232,85 @@ def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, r
     return BatchNormTrainFn.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
 
 
+# ---- losses.  The kernels produce the loss AND its gradient w.r.t. the first argument in one pass, both already scaled by
+# `weight` (the python-side loss weight of the trainers).  backward() then has to multiply that gradient by the incoming
+# scalar `g` -- a full elementwise pass over a logits-sized tensor -- unless g is known to be 1: `unit_backward` starts the
+# backward pass from the weighted terms themselves with ONE shared unit gradient tensor, which autograd hands to the
+# root functions unchanged, so they can recognise it by identity and return the stored gradient as is.
+_UNIT_GRAD = {}
+
+
+def _unit_grad(device):
+    u = _UNIT_GRAD.get(device)
+    if u is None:
+        u = _UNIT_GRAD[device] = torch.ones((), dtype=torch.float32, device=device)
+    return u
+
+
+def unit_backward(terms):
+    """backward() of sum(terms) for scalar loss terms (weights already folded into them), without the per-term
+    gradient-times-scalar passes.  Equivalent to sum(terms).backward()."""
+    terms = [t for t in terms if t.requires_grad]
+    if terms:
+        torch.autograd.backward(terms, [_unit_grad(t.device) for t in terms])
+
+
+def _times(grad, g):
+    u = _UNIT_GRAD.get(g.device)
+    return grad if (u is not None and g.data_ptr() == u.data_ptr()) else grad * g
+
+
 class TaskLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index, use_dice, use_ce):
-        loss, dz = hip.task_loss(logits, labels, ctx.needs_input_grad[0], 1.0, ignore_index, use_dice, use_ce)
+    def forward(ctx, logits, labels, ignore_index, use_dice, use_ce, weight=1.0):
+        loss, dz = hip.task_loss(logits, labels, ctx.needs_input_grad[0], float(weight), ignore_index, use_dice, use_ce)
         ctx.save_for_backward(dz)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dz, = ctx.saved_tensors
-        return dz * g, None, None, None, None
+        return _times(dz, g), None, None, None, None, None
 
 
 class SymJSFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
-        loss, da = hip.sym_js_loss(a, b, ctx.needs_input_grad[0], 1.0)
+    def forward(ctx, a, b, weight=1.0):
+        loss, da = hip.sym_js_loss(a, b, ctx.needs_input_grad[0], float(weight))
         ctx.save_for_backward(da)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         da, = ctx.saved_tensors
-        return da * g, None
+        return _times(da, g), None, None
 
 
 class L1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
-        loss, da = hip.l1_loss(a, b, ctx.needs_input_grad[0], 1.0)
+    def forward(ctx, a, b, weight=1.0):
+        loss, da = hip.l1_loss(a, b, ctx.needs_input_grad[0], float(weight))
         ctx.save_for_backward(da)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         da, = ctx.saved_tensors
-        return da * g, None
+        return _times(da, g), None, None
 
 
-def task_loss(logits, labels, ignore_index=255, use_dice=True, use_ce=True):
-    return TaskLossFn.apply(logits.contiguous(), labels.contiguous(), ignore_index, use_dice, use_ce)
+def task_loss(logits, labels, ignore_index=255, use_dice=True, use_ce=True, weight=1.0):
+    return TaskLossFn.apply(logits.contiguous(), labels.contiguous(), ignore_index, use_dice, use_ce, weight)
 
 
-def sym_js_div(a, b):
-    """Gradient flows to `a` only; `b` is always a no-grad prediction in the trainers."""
+def sym_js_div(a, b, weight=1.0):
+    """weight * symJS; gradient flows to `a` only; `b` is always a no-grad prediction in the trainers."""
     if b.requires_grad:
         raise hip.EssHipError('sym_js_div: the second argument must not require grad (training/ess_trainer.py:234-237)')
-    return SymJSFn.apply(a.contiguous(), b.contiguous())
+    return SymJSFn.apply(a.contiguous(), b.contiguous(), weight)
 
 
-def l1_loss(a, b):
+def l1_loss(a, b, weight=1.0):
     if b.requires_grad:
         raise hip.EssHipError('l1_loss: the second argument must not require grad')
-    return L1Fn.apply(a.contiguous(), b.contiguous())
+    return L1Fn.apply(a.contiguous(), b.contiguous(), weight)

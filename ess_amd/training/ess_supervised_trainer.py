@@ -7,6 +7,7 @@ import math
 
 import torch
 
+from .. import functional as Fn
 from ..e2vid.image_reconstructor import ImageReconstructor
 from ..e2vid.utils.loading_utils import load_model
 from ..evaluation.metrics import MetricsSemseg
@@ -60,7 +61,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         opt = self.optimizers_dict['optimizer_back']
         opt.zero_grad()
         d_final_loss, d_losses, d_outputs = self.task_train_step(input_batch)
-        d_final_loss.backward()
+        Fn.unit_backward([d_final_loss])  # == d_final_loss.backward(), without the gradient-times-one pass
         self.grad_reducer.launch(opt.flat_grad)
         self.grad_reducer.wait()
         opt.step()
@@ -87,7 +88,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
     def trainTaskStep(self, sensor_name, content_features, labels, losses):
         content_features = {k: v.detach() for k, v in content_features.items()}
         pred = self.models_dict['back_end'](content_features)
-        loss_pred = self.task_loss(pred[1], labels) * self.settings.weight_task_loss
+        loss_pred = self.task_loss(pred[1], labels, weight=self.settings.weight_task_loss)  # weight folded into the kernel
         losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
         return loss_pred, pred
 

@@ -20,6 +20,7 @@ import math
 
 import torch
 
+from .. import functional as Fn
 from ..e2vid.image_reconstructor import ImageReconstructor
 from ..e2vid.model.model import E2VIDRecurrent
 from ..e2vid.utils.loading_utils import load_model
@@ -120,15 +121,16 @@ class ESSModel(base_trainer.BaseTrainer):
 
         t_final_loss, t_losses, t_outputs = self.img_train_step(input_batch)
         # DSEC: the image latents were detached, so this reaches the decoder only; DDD17: decoder + image encoder
-        t_final_loss.backward()
+        # (unit_backward == .backward() of the sum of the weighted terms, minus one gradient-times-scalar pass per term)
+        Fn.unit_backward([t_final_loss])
         final_loss = t_final_loss.detach()
         losses.update(t_losses)
         outputs.update(t_outputs)
 
         e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch)
-        e_loss.backward()  # image encoder only: the decoder was frozen while this graph was recorded
+        Fn.unit_backward(self._e_terms)  # image encoder only: the decoder was frozen while this graph was recorded
         self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
-        t_loss.backward()  # decoder only
+        Fn.unit_backward(self._t_terms)  # decoder only
         self.grad_reducer.launch(opt_back.flat_grad)
         final_loss = final_loss + e_loss.detach() + t_loss.detach()
         losses.update(event_losses)
@@ -163,7 +165,7 @@ class ESSModel(base_trainer.BaseTrainer):
             if self.settings.dataset_name_b == 'DSEC_events':
                 latent_fake = {k: v.detach() for k, v in latent_fake.items()}
             pred = self.models_dict['back_end'](latent_fake)
-        loss_pred = self.task_loss(pred[1], labels) * self.settings.weight_task_loss
+        loss_pred = self.task_loss(pred[1], labels, weight=self.settings.weight_task_loss)  # weight folded into the kernel
         losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
         return loss_pred, pred
 
@@ -174,10 +176,12 @@ class ESSModel(base_trainer.BaseTrainer):
         output on the event latents instead of recomputing it."""
         s = self.settings
         g_loss = 0.
+        terms = self._e_terms = []  # the weighted terms g_loss is the sum of (train_step starts the backward pass from them)
         cycle_name = first_sensor_name + '_to_' + second_sensor_name
         scales = (2, 4, 8) if s.skip_connect_encoder else (8,)
         for k in scales:
-            li = self.cycle_content_loss(content_second_sensor[k], content_first_sensor[k]) * s.weight_cycle_loss
+            li = self.cycle_content_loss(content_second_sensor[k], content_first_sensor[k], weight=s.weight_cycle_loss)
+            terms.append(li)
             g_loss = g_loss + li
             losses['cycle_latent_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
         task_backend = self.models_dict['back_end']
@@ -188,9 +192,11 @@ class ESSModel(base_trainer.BaseTrainer):
         js = self.cycle_pred_loss(pred_second_sensor[1], pred_first_sensor_no_grad[1])
         losses['cycle_pred_1x_' + cycle_name + '_loss'] = js.detach()
         if s.dataset_name_b == 'DSEC_events':
+            terms.append(js)
             g_loss = g_loss + js
         for k in (2, 4):
-            li = self.cycle_content_loss(pred_second_sensor[k], pred_first_sensor_no_grad[k]) * s.weight_cycle_task_loss
+            li = self.cycle_content_loss(pred_second_sensor[k], pred_first_sensor_no_grad[k], weight=s.weight_cycle_task_loss)
+            terms.append(li)
             g_loss = g_loss + li
             losses['cycle_pred_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
         return g_loss, pred_first_sensor_no_grad, pred_second_sensor
@@ -235,6 +241,7 @@ class ESSModel(base_trainer.BaseTrainer):
                                          pred_first_sensor=pred_real, pred_second_sensor_no_grad=pred_fake_ng)
         if s.train_on_event_labels:
             t_loss_b, _ = self.trainTaskStep('sensor_b', latent_real, labels_b, losses, pred=pred_real)
+            self._t_terms.append(t_loss_b)
             t_loss = t_loss + t_loss_b
         return e_loss, t_loss, losses, out
 
@@ -248,10 +255,12 @@ class ESSModel(base_trainer.BaseTrainer):
         if pred_second_sensor_no_grad is None:
             with torch.no_grad():
                 pred_second_sensor_no_grad = task_backend(content_second_sensor)
-        t_loss = self.cycle_pred_loss(pred_first_sensor[1], pred_second_sensor_no_grad[1]) * s.weight_KL_loss
+        t_loss = self.cycle_pred_loss(pred_first_sensor[1], pred_second_sensor_no_grad[1], weight=s.weight_KL_loss)
+        terms = self._t_terms = [t_loss]
         for k in (2, 4):
-            t_loss = t_loss + self.cycle_content_loss(pred_first_sensor[k], pred_second_sensor_no_grad[k]) * \
-                s.weight_cycle_task_loss
+            li = self.cycle_content_loss(pred_first_sensor[k], pred_second_sensor_no_grad[k], weight=s.weight_cycle_task_loss)
+            terms.append(li)
+            t_loss = t_loss + li
         return t_loss
 
     # ------------------------------------------------------------------ validation (reference :364-493)

@@ -19,10 +19,11 @@ class TaskLoss(torch.nn.Module):
         self.num_classes = num_classes
         self.ignore_index = ignore_index
 
-    def forward(self, predict, target):
+    def forward(self, predict, target, weight=1.0):
+        """weight: the trainer's loss weight, folded into the kernel (loss and gradient come out scaled)."""
         assert predict.shape[1] == self.num_classes, 'predict & target shape do not match'
         ign = -1 if self.ignore_index is None else self.ignore_index
-        return Fn.task_loss(predict, target, ign, 'dice' in self.losses, 'cross_entropy' in self.losses)
+        return Fn.task_loss(predict, target, ign, 'dice' in self.losses, 'cross_entropy' in self.losses, weight)
 
 
 class DiceLoss(torch.nn.Module):
@@ -43,12 +44,12 @@ class symJSDivLoss(torch.nn.Module):
     """0.5*KL(p||q) + 0.5*KL(q||p) with element-mean reduction and 1e-10 clamps (reference :27-37).
     Gradient flows to `predict`; `target` is a no-grad prediction in every call site."""
 
-    def forward(self, predict, target):
-        return Fn.sym_js_div(predict, target.detach())
+    def forward(self, predict, target, weight=1.0):
+        return Fn.sym_js_div(predict, target.detach(), weight)
 
 
 class L1Loss(torch.nn.Module):
     """torch.nn.L1Loss() as used for the cycle losses (training/ess_trainer.py:28,217-253)."""
 
-    def forward(self, predict, target):
-        return Fn.l1_loss(predict, target.detach())
+    def forward(self, predict, target, weight=1.0):
+        return Fn.l1_loss(predict, target.detach(), weight)
