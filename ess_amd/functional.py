@@ -214,6 +214,7 @@ class BatchNormTrainFn(torch.autograd.Function):
         y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps, relu)
         ctx.relu = relu
+        ctx.beta_ref = weakref.ref(beta)
         ctx.save_for_backward(x, y, gamma, stats)
         return y
 
@@ -222,6 +223,15 @@ class BatchNormTrainFn(torch.autograd.Function):
         x, y, gamma, stats = ctx.saved_tensors
         dy = dy.contiguous()
         need_dx, need_dres, need_g, need_b = ctx.needs_input_grad[0:4]
+        beta = ctx.beta_ref()
+        # like the conv weight gradients: add straight into the leaves' .grad (views of the optimiser's flat buffer)
+        # instead of returning two C-element tensors for AccumulateGrad to add with one tiny launch each
+        direct = DIRECT_GRAD_ACCUM and need_g and need_b and beta is not None and gamma.is_leaf and beta.is_leaf and \
+            gamma.grad is not None and beta.grad is not None and gamma.grad.is_contiguous() and beta.grad.is_contiguous()
+        if direct:
+            dx, dres = hip.batchnorm_train_backward(x, y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, gamma.grad,
+                                                    beta.grad, accumulate=True)
+            return dx, dres, None, None, None, None, None, None, None
         dgamma = torch.empty_like(gamma) if (need_g or need_b) else None
         dbeta = torch.empty_like(gamma) if (need_g or need_b) else None
         dx, dres = hip.batchnorm_train_backward(x, y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, dgamma, dbeta)
