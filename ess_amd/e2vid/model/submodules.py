@@ -237,14 +237,12 @@ class ConvLSTM(nn.Module):
         N, C, H, W = input_.shape
         hid = self.hidden_size
         if prev_state is None:
-            key = (N, hid, H, W, input_.device)
-            if key not in self.zero_tensors:
-                z = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
-                _attach_c8(z, torch.zeros(N, (hid + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=input_.device))
-                self.zero_tensors[key] = z
-            prev_hidden, prev_cell = self.zero_tensors[key], None  # a NULL cell pointer reads as zeros
-        else:
-            prev_hidden, prev_cell = prev_state
+            # first step of a sequence: h = 0 and c = 0 (a NULL cell pointer reads as zeros), so the h half of the contraction
+            # adds exact zeros -- run the gate conv over x alone with the x columns of the weight: bit-identical, half the MFMA
+            # work of this launch, and no zero state tensors (the reference caches them, submodules.py:196-207)
+            hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
+            return self._first_step(input_, hidden, torch.empty_like(hidden), lean)
+        prev_hidden, prev_cell = prev_state
         spec = hip.conv_spec(N, H, W, C, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
         b = self.Gates.bias
         ver = (spec.key, b._version, b.data_ptr())
@@ -273,6 +271,39 @@ class ConvLSTM(nn.Module):
         if skip_fp32:
             _mark_fp32_unwritten(hidden)
         return hidden, cell
+
+
+def _convlstm_first_step(self, input_, hidden, cell, lean):
+    N, C, H, W = input_.shape
+    hid = self.hidden_size
+    w = self.Gates.weight
+    ver = (w._version, w.data_ptr(), C)
+    if getattr(self, '_wx_ver', None) != ver:  # the x columns of the gate weight as their own (packable) tensor
+        self._wx_ver, self._wx = ver, w.detach()[:, :C].contiguous()
+    spec = hip.conv_spec(N, H, W, C, 0, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
+    b = self.Gates.bias
+    bver = (spec.key, b._version, b.data_ptr())
+    if getattr(self, '_bias0_ver', None) != bver:
+        self._bias0_ver, self._bias0 = bver, hip.pack_rows(spec, b.detach())
+    bf = spec.desc.compute == hip.COMPUTE_BF16 and (C % 8) == 0
+    stage8 = bf and hip.c8_stageable(3, 1, 1)
+    x8 = _c8_of(input_) if stage8 else None
+    new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
+    skip_fp32 = lean and new8 is not None and stage8
+    if x8 is not None:
+        hip.conv_forward(spec, x8, None, packed_weight(spec, self._wx), None, self._bias0, aux0=None,
+                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
+    else:
+        hip.conv_forward(spec, _fp32(input_), None, packed_weight(spec, self._wx), None, self._bias0, aux0=None,
+                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8)
+    if new8 is not None:
+        _attach_c8(hidden, new8)
+    if skip_fp32:
+        _mark_fp32_unwritten(hidden)
+    return hidden, cell
+
+
+ConvLSTM._first_step = _convlstm_first_step
 
 
 class ConvGRU(nn.Module):
