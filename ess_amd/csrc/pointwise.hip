@@ -221,7 +221,31 @@ __global__ __launch_bounds__(256) void to_bf16_c8_kernel(const float* __restrict
     y[i] = __builtin_bit_cast(uint4, b);
   }
 }
+
+// F.interpolate(mode='nearest') to an arbitrary size: src = min(floor(dst * (float)in / out), in - 1), the index
+// arithmetic of torch's legacy nearest mode in fp32 (validation resizes logits to img_size_b before argmax / loss).
+__global__ void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int H, int W, int64_t total) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % W);
+    const int64_t r = i / W;
+    const int oy = (int)(r % H);
+    const int64_t pl = r / H;
+    const int iy = min((int)floorf(oy * sy), h - 1), ix = min((int)floorf(ox * sx), w - 1);
+    y[i] = x[(pl * h + iy) * w + ix];
+  }
+}
 }  // namespace
+
+extern "C" int ess_resize_nearest(const float* x, float* y, int32_t planes, int32_t H_in, int32_t W_in, int32_t H_out, int32_t W_out,
+                                  ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "resize_nearest: bad arguments");
+  const int64_t total = (int64_t)planes * H_out * W_out;
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, H_in, W_in, H_out, W_out, total);
+  return ess_launch_status("resize_nearest");
+}
 
 extern "C" int ess_to_bf16_c8(const float* x, void* y, int N, int C, int H, int W, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "to_bf16_c8: bad arguments");

@@ -52,16 +52,22 @@ class MetricsSemseg:
     def update_batch(self, y_hat_lbl, y_lbl):
         with torch.no_grad():
             batch = semseg_compute_confusion(y_hat_lbl, y_lbl, self.num_classes, self.ignore_label).cpu()
-            self.metrics_acc = batch if self.metrics_acc is None else self.metrics_acc + batch
+            self.metrics_acc = batch if self.metrics_acc is None else self.metrics_acc.cpu() + batch
 
     def update_batch_logits(self, logits, y_lbl):
+        """argmax + confusion in one kernel, accumulated into a device-resident matrix: no host read per batch (the
+        reference's update_batch moves every batch's matrix to the CPU, evaluation/metrics.py:50-57)."""
         with torch.no_grad():
-            pred, conf = logits_to_confusion(logits, y_lbl, self.num_classes, self.ignore_label)
-            conf = conf.cpu()
-            self.metrics_acc = conf if self.metrics_acc is None else self.metrics_acc + conf
+            if self.metrics_acc is None or self.metrics_acc.device != logits.device:
+                prev = self.metrics_acc
+                self.metrics_acc = torch.zeros(self.num_classes, self.num_classes, dtype=torch.int64, device=logits.device)
+                if prev is not None:
+                    self.metrics_acc += prev.to(logits.device)
+            pred, _ = logits_to_confusion(logits, y_lbl, self.num_classes, self.ignore_label, conf=self.metrics_acc)
         return pred
 
     def get_metrics_summary(self):
+        self.metrics_acc = self.metrics_acc.cpu()  # the one host read; the reference keeps the accumulator on the CPU
         iou_mean, iou_per_class = semseg_accum_confusion_to_iou(self.metrics_acc)
         out = {self.class_names[i]: iou for i, iou in enumerate(iou_per_class)}
         out['mean_iou'] = iou_mean

@@ -40,7 +40,7 @@ EXPORTS = [
     'ess_conv2d_forward', 'ess_to_bf16_c8', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
-    'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion',
+    'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
 ]
 
@@ -104,6 +104,7 @@ def lib():
             'ess_l1_loss': [P, P, P, P, F, I64, P, P],
             'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
             'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
+            'ess_resize_nearest': [P, P, I, I, I, I, I, P],
             'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P, c_size_t, I64, P],
             'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
             'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
@@ -425,6 +426,17 @@ def radam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_size, n_sm
     _check(lib().ess_radam_step(ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), p.numel(), c_float(lr), c_float(beta1),
                                 c_float(beta2), c_float(eps), c_float(step_size), int(n_sma_ge5), stream()),
            'ess_radam_step')
+
+
+def resize_nearest(x, size):
+    """F.interpolate(x, size=size, mode='nearest') for fp32 NCHW (identity when the size already matches)."""
+    N, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    if (h, w) == (H, W):
+        return x
+    y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    _check(lib().ess_resize_nearest(ptr(x), ptr(y), N * C, h, w, H, W, stream()), 'ess_resize_nearest')
+    return y
 
 
 def argmax_confusion(logits, labels=None, conf=None, ignore_index=255, want_pred=True):

@@ -74,13 +74,14 @@ class BaseTrainer(object):
         cfg = s.synthetic_cfg
         H, W = self.input_height, self.input_width
         rank = D.rank()
-        mk = lambda steps, seed, ev_only: SyntheticPairedLoader(
+        mk = lambda steps, seed, ev_only, img_only=False: SyntheticPairedLoader(
             steps, s.batch_size_a, s.batch_size_b, s.nr_events_data_b, s.input_channels_b, H, W, s.semseg_num_classes,
-            self.device, seed=seed + 100003 * rank, events_only=ev_only)
+            self.device, seed=seed + 100003 * rank, events_only=ev_only, images_only=img_only)
         ev_only = s.model_name == 'ess_supervised'
         self.train_loader = mk(int(cfg.get('steps_per_epoch', 8)), 0, ev_only)
         self.train_loader_sensor_b = self.train_loader
         self.val_loader_sensor_b = mk(int(cfg.get('val_steps', 2)), 7919, True)
+        self.val_loader_sensor_a = None if ev_only else mk(int(cfg.get('val_steps', 2)), 7907, False, True)
 
     # ------------------------------------------------------------------ loops (reference :361-453)
     def train(self):
@@ -118,6 +119,8 @@ class BaseTrainer(object):
         with torch.no_grad():
             for model in self.models_dict:
                 self.models_dict[model].eval()
+            if getattr(self, 'val_loader_sensor_a', None) is not None:  # the UDA trainer validates both sensors (:423-424)
+                self.validationEpoch(self.val_loader_sensor_a, 'sensor_a')
             self.validationEpoch(self.val_loader_sensor_b, 'sensor_b')
         self.epoch_count_val = self.epoch_count
 

@@ -8,6 +8,7 @@ import math
 import torch
 
 from .. import functional as Fn
+from .. import hip
 from ..e2vid.image_reconstructor import ImageReconstructor
 from ..e2vid.utils.loading_utils import load_model
 from ..evaluation.metrics import MetricsSemseg
@@ -92,27 +93,49 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
         return loss_pred, pred
 
-    # ------------------------------------------------------------------ validation (reference :235-292)
-    def validationEpoch(self, data_loader, sensor_name):
+    # ------------------------------------------------------------------ validation (reference :191-292)
+    def resetValidationStatistics(self):
         self.metrics_semseg_b.reset()
-        for batch in data_loader:
-            self.val_step(batch, sensor_name)
-        if self.metrics_semseg_b.metrics_acc is not None:
-            m = self.metrics_semseg_b.get_metrics_summary()
-            self.summary_writer.add_scalar('val_{}/mean_iou'.format(sensor_name), float(m['mean_iou']), self.epoch_count)
-            self.summary_writer.add_scalar('val_{}/acc'.format(sensor_name), float(m['acc']), self.epoch_count)
-            self.last_val_metrics = m
 
-    def val_step(self, batch, sensor):
+    def validationEpoch(self, data_loader, sensor_name):
+        cumulative_losses, n = {}, 0
+        for i_batch, batch in enumerate(data_loader):
+            losses, _ = self.val_step([t.to(self.device) for t in batch], sensor_name, i_batch, -1)
+            for k, v in losses.items():
+                cumulative_losses[k] = cumulative_losses[k] + v if k in cumulative_losses else v
+            n += 1
+        if n == 0:
+            return
+        m = self.metrics_semseg_b.get_metrics_summary()
+        summary = {k: float(v) / n for k, v in cumulative_losses.items()}
+        summary['semseg_sensor_b_mean_iou'], summary['semseg_sensor_b_acc'] = float(m['mean_iou']), float(m['acc'])
+        for k, v in summary.items():
+            self.summary_writer.add_scalar('val_{}/{}'.format(sensor_name, k), v, self.epoch_count)
+        self.last_val_metrics, self.last_val_summary = m, summary
+
+    def val_step(self, input_batch, sensor, i_batch=0, vis_reconstr_idx=-1):
+        """-> (losses, None) as the reference (:235-277); events only (this trainer has no front_sensor_a)."""
+        if sensor != 'sensor_b':
+            raise KeyError('front_' + sensor)  # the reference fails the same way on models_dict (:255)
         s = self.settings
-        data = batch[0].to(self.device)
-        labels = (batch[2] if s.require_paired_data_val_b and len(batch) > 2 else batch[1]).to(self.device)
-        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
-        T, C = s.nr_events_data_b, s.input_channels_b
-        for i in range(T):
-            _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False,
-                                                                    lean_state=i < T - 1)
-        pred = self.models_dict['back_end'](latent)[1]
-        if tuple(pred.shape[2:]) != tuple(labels.shape[1:]):
-            pred = torch.nn.functional.interpolate(pred, size=tuple(labels.shape[1:]), mode='nearest')
-        return self.metrics_semseg_b.update_batch_logits(pred, labels)
+        data = input_batch[0]
+        if getattr(s, 'require_paired_data_val_b', False):
+            labels = input_batch[3] if s.dataset_name_b == 'DDD17_events' else input_batch[2]
+        else:
+            labels = input_batch[1]
+        losses = {}
+        with torch.no_grad():
+            self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+            T, C = s.nr_events_data_b, s.input_channels_b
+            for i in range(T):
+                _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False,
+                                                                        lean_state=i < T - 1)
+            self.valTaskStep(latent, labels, losses, sensor)
+        return losses, None
+
+    def valTaskStep(self, content_first_sensor, labels, losses, sensor):
+        """decoder -> nearest resize to img_size_b -> argmax + confusion, task loss (unweighted, reference :279-292)."""
+        pred = self.models_dict['back_end'](content_first_sensor)[1]
+        pred = hip.resize_nearest(pred, tuple(self.settings.img_size_b))
+        self.metrics_semseg_b.update_batch_logits(pred, labels)
+        losses['semseg_' + sensor + '_loss'] = self.task_loss(pred, target=labels)

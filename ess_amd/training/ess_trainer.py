@@ -4,7 +4,7 @@ ESSModel: the unsupervised-domain-adaptation train step of ESS (reference: train
 Class surface kept: models_dict {'front_sensor_a','front_sensor_b','back_end'}, optimizers_dict
 {'optimizer_front_sensor_a','optimizer_back'}, train_step(batch) -> (losses, outputs, final_loss) with the
 reference's loss-dict keys, img_train_step / trainTaskStep / trainCycleStep / event_train_step /
-TasktrainCycleStep, val_step.
+TasktrainCycleStep, val_step / valTaskStep / valCycleStep / valCycleTask.
 
 What differs from the reference and why the results do not (SURVEY.md 3.1 "redundant work"):
   * the decoder is evaluated on each latent set ONCE per step: `back_end(latent_real)` (with grad, for the task
@@ -21,6 +21,7 @@ import math
 import torch
 
 from .. import functional as Fn
+from .. import hip
 from ..e2vid.image_reconstructor import ImageReconstructor
 from ..e2vid.model.model import E2VIDRecurrent
 from ..e2vid.utils.loading_utils import load_model
@@ -263,32 +264,98 @@ class ESSModel(base_trainer.BaseTrainer):
             t_loss = t_loss + li
         return t_loss
 
-    # ------------------------------------------------------------------ validation (reference :364-493)
+    # ------------------------------------------------------------------ validation (reference :364-548)
+    def resetValidationStatistics(self):
+        self.metrics_semseg_a.reset()
+        if self.settings.semseg_label_val_b:
+            self.metrics_semseg_b.reset()
+            self.metrics_semseg_cycle.reset()
+
     def validationEpoch(self, data_loader, sensor_name):
-        if not self.settings.semseg_label_val_b:
+        """Loss sums stay on the device; the metric summaries are the only host reads of the epoch."""
+        cumulative_losses, n = {}, 0
+        for i_batch, batch in enumerate(data_loader):
+            losses, _ = self.val_step([t.to(self.device) for t in batch], sensor_name, i_batch, -1)
+            for k, v in losses.items():
+                cumulative_losses[k] = cumulative_losses[k] + v if k in cumulative_losses else v
+            n += 1
+        if n == 0:
             return
-        self.metrics_semseg_b.reset()
-        for batch in data_loader:
-            self.val_step(batch, sensor_name)
-        if self.metrics_semseg_b.metrics_acc is not None:
-            m = self.metrics_semseg_b.get_metrics_summary()
-            self.summary_writer.add_scalar('val_{}/mean_iou'.format(sensor_name), float(m['mean_iou']), self.epoch_count)
-            self.summary_writer.add_scalar('val_{}/acc'.format(sensor_name), float(m['acc']), self.epoch_count)
-            self.last_val_metrics = m
+        if sensor_name == 'sensor_a':
+            tracked = [('semseg_sensor_a', self.metrics_semseg_a)]
+        elif self.settings.semseg_label_val_b:
+            tracked = [('semseg_sensor_b', self.metrics_semseg_b), ('semseg_sensor_cycle', self.metrics_semseg_cycle)]
+        else:
+            tracked = []
+        summary = {k: float(v) / n for k, v in cumulative_losses.items()}
+        for name, m in tracked:
+            ms = m.get_metrics_summary()
+            summary[name + '_mean_iou'], summary[name + '_acc'] = float(ms['mean_iou']), float(ms['acc'])
+            self.last_val_metrics = dict(getattr(self, 'last_val_metrics', None) or {}, **{name: ms})
+        for k, v in summary.items():
+            self.summary_writer.add_scalar('val_{}/{}'.format(sensor_name, k), v, self.epoch_count)
+        self.last_val_summary = dict(getattr(self, 'last_val_summary', None) or {}, **{sensor_name: summary})
 
-    def val_step(self, batch, sensor):
+    def val_step(self, input_batch, sensor, i_batch=0, vis_reconstr_idx=-1):
+        """-> (losses, None) as the reference (:424-474); runs under no_grad with the modules in eval mode
+        (validationEpochs).  The tensorboard image dumps behind vis_reconstr_idx are out of scope."""
         s = self.settings
-        data = batch[0].to(self.device)
-        labels = (batch[2] if s.require_paired_data_val_b and len(batch) > 2 else batch[1]).to(self.device)
-        rec = self.reconstructor_valid
-        rec.last_states_for_each_channel = {'grayscale': None}
-        T, C = s.nr_events_data_b, s.input_channels_b
-        for i in range(T):
-            _, _, latent = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False, lean_state=i < T - 1)
-        return self.valTaskStep(latent, labels, self.metrics_semseg_b)
+        data = input_batch[0]
+        if sensor == 'sensor_a':
+            labels = input_batch[2] if getattr(s, 'require_paired_data_val_a', False) else input_batch[1]
+        elif getattr(s, 'require_paired_data_val_b', False):
+            labels = input_batch[3] if s.dataset_name_b == 'DDD17_events' else input_batch[2]
+        else:
+            labels = input_batch[1]
+        losses = {}
+        with torch.no_grad():
+            if sensor == 'sensor_a':
+                content = self.models_dict['front_sensor_a'](data)
+                self.valTaskStep(content, labels, losses, sensor)
+                return losses, None
+            rec = self.reconstructor_valid
+            rec.last_states_for_each_channel = {'grayscale': None}
+            T, C = s.nr_events_data_b, s.input_channels_b
+            for i in range(T):  # only the last slice's image and latents are consumed
+                img_fake, _, content = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=i == T - 1,
+                                                                 lean_state=i < T - 1)
+            preds = self.valTaskStep(content, labels, losses, sensor)
+            self.valCycleStep(content, img_fake, labels, losses, sensor, 'sensor_a', preds)
+        return losses, None
 
-    def valTaskStep(self, content, labels, metrics):
-        pred = self.models_dict['back_end'](content)[1]
-        if tuple(pred.shape[2:]) != tuple(labels.shape[1:]):
-            pred = torch.nn.functional.interpolate(pred, size=tuple(labels.shape[1:]), mode='nearest')
-        return metrics.update_batch_logits(pred, labels)
+    def _val_label_scores(self, pred, labels, metrics):
+        """nearest resize to img_size_b + argmax + confusion + task loss (reference :482-492, :523-530)."""
+        pred = hip.resize_nearest(pred, tuple(self.settings.img_size_b))
+        metrics.update_batch_logits(pred, labels)
+        return self.task_loss(pred, target=labels, weight=self.settings.weight_task_loss)
+
+    def valTaskStep(self, content_first_sensor, labels, losses, sensor):
+        preds = self.models_dict['back_end'](content_first_sensor)
+        if sensor == 'sensor_a':
+            self.metrics_semseg_a.update_batch_logits(preds[1], labels)
+            losses['semseg_sensor_a_loss'] = self.task_loss(preds[1], target=labels, weight=self.settings.weight_task_loss)
+        elif self.settings.semseg_label_val_b:
+            losses['semseg_sensor_b_loss'] = self._val_label_scores(preds[1], labels, self.metrics_semseg_b)
+        return preds
+
+    def valCycleStep(self, content_first_sensor, img_fake, labels, losses, sensor, second_sensor, preds_first_sensor):
+        s = self.settings
+        content_second_sensor = self.models_dict['front_' + second_sensor](img_fake)
+        cycle_name = sensor + '_to_' + second_sensor
+        for k in ((2, 4, 8) if s.skip_connect_encoder else (8,)):
+            losses['cycle_latent_{}x_{}_loss'.format(k, cycle_name)] = self.cycle_content_loss(
+                content_first_sensor[k], content_second_sensor[k], weight=s.weight_cycle_loss)
+        return self.valCycleTask(content_second_sensor, labels, losses, cycle_name, preds_first_sensor)
+
+    def valCycleTask(self, cycle_content_first_second, labels, losses, cycle_name, preds_first_sensor):
+        s = self.settings
+        preds_second_sensor = self.models_dict['back_end'](cycle_content_first_second)
+        if s.semseg_label_val_b:
+            losses['semseg_' + cycle_name + '_loss'] = self._val_label_scores(preds_second_sensor[1], labels,
+                                                                              self.metrics_semseg_cycle)
+        losses['cycle_pred_1x_' + cycle_name + '_loss'] = self.cycle_pred_loss(preds_second_sensor[1], preds_first_sensor[1],
+                                                                               weight=s.weight_KL_loss)
+        for k in (2, 4):
+            losses['cycle_pred_{}x_{}_loss'.format(k, cycle_name)] = self.cycle_content_loss(
+                preds_first_sensor[k], preds_second_sensor[k], weight=s.weight_cycle_task_loss)
+        return preds_second_sensor

@@ -17,11 +17,12 @@ def make_batch(B, T, C, H, W, K, seed, device, sparsity=0.1):
 
 class SyntheticPairedLoader:
     """Iterates `steps` batches of [[img, label_a], [events, label_b]] (the WrapperDataset layout,
-    datasets/wrapper_dataloader.py:53-54) resident on the device; rank-dependent seeds for data parallelism."""
+    datasets/wrapper_dataloader.py:53-54) resident on the device; rank-dependent seeds for data parallelism.
+    events_only / images_only: the single-sensor [data, label] layout of the validation loaders."""
 
-    def __init__(self, steps, B_a, B_b, T, C, H, W, K, device, seed=0, events_only=False):
+    def __init__(self, steps, B_a, B_b, T, C, H, W, K, device, seed=0, events_only=False, images_only=False):
         self.steps, self.args, self.device, self.seed = steps, (T, C, H, W, K), device, seed
-        self.B_a, self.B_b, self.events_only = B_a, B_b, events_only
+        self.B_a, self.B_b, self.events_only, self.images_only = B_a, B_b, events_only, images_only
 
     def __len__(self):
         return self.steps
@@ -35,5 +36,7 @@ class SyntheticPairedLoader:
             ev, img, lab_a, lab_b = make_batch(max(self.B_a, self.B_b), T, C, H, W, K, self.seed + i, self.device)
             if self.events_only:
                 yield [ev[:self.B_b], lab_b[:self.B_b]]
+            elif self.images_only:
+                yield [img[:self.B_a], lab_a[:self.B_a]]
             else:
                 yield [[img[:self.B_a], lab_a[:self.B_a]], [ev[:self.B_b], lab_b[:self.B_b]]]

@@ -221,6 +221,11 @@ int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
                    float beta1, float beta2, float eps, float step_size, int32_t n_sma_ge5,
                    ess_stream_t stream);
 
+/* F.interpolate(x, size=(H_out, W_out), mode='nearest') on fp32 [planes][H_in][W_in] -- the resize of the validation
+ * logits to img_size_b (training/ess_trainer.py:484,525; training/ess_supervised_trainer.py:284).               */
+int ess_resize_nearest(const float* x, float* y, int32_t planes, int32_t H_in, int32_t W_in, int32_t H_out,
+                       int32_t W_out, ess_stream_t stream);
+
 /* argmax over K + confusion-matrix accumulation (training/ess_trainer.py:485; evaluation/metrics.py:4-24)
  * pred_lbl (nullable): int64 [N][H][W]; conf: int64 [K][K], accumulated (conf[label][pred]).         */
 int ess_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred_lbl, int64_t* conf,

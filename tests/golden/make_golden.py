@@ -349,6 +349,79 @@ def gold_train_steps(R, out):
     out['uda_steps'] = dict(K=K, T=T, C=C, H=H, W=W, B=B, wseed=700, fseed=702, runs=uda)
 
 
+def gold_val_steps(R, out):
+    """(f)2 validation path: ESSModel.val_step for sensor_a and sensor_b (valTaskStep, valCycleStep, valCycleTask;
+    training/ess_trainer.py:424-548) and ESSSupervisedModel.val_step (ess_supervised_trainer.py:235-292), models in
+    eval mode under no_grad as BaseTrainer.validationEpochs runs them (base_trainer.py:416-424)."""
+    K, T, C, H, W, B, NB = 6, 3, 2, 24, 40, 2, 2
+    cfg = O.e2vid_config(num_bins=C)
+    e_shapes, d_shapes, f_shapes = O.e2vid_param_shapes(cfg), O.semseg_param_shapes(256, K), O.style_encoder_param_shapes(1)
+    names = [str(i) for i in range(K)]
+
+    def common(tr, st, e2, dec):
+        tr.settings, tr.device = st, torch.device('cpu')
+        tr.task_loss = R.loss.TaskLoss(losses=st.task_loss, gamma=2.0, num_classes=K, ignore_index=255)
+        tr.cycle_content_loss = torch.nn.L1Loss()
+        tr.cycle_pred_loss = R.loss.symJSDivLoss()
+        tr.metrics_semseg_a = R.metrics.MetricsSemseg(K, 255, names)
+        tr.metrics_semseg_b = R.metrics.MetricsSemseg(K, 255, names)
+        tr.metrics_semseg_cycle = R.metrics.MetricsSemseg(K, 255, names)
+        rec = R.recon.ImageReconstructor(e2, H, W, C, torch.device('cpu'), e2vid_options())
+        tr.reconstructor = tr.reconstructor_valid = rec
+
+    def summary(m):
+        s = m.get_metrics_summary()
+        return dict(cm=s['cm'].clone(), miou=s['mean_iou'].clone(), acc=s['acc'].clone())
+
+    runs = {}
+    for name, w in [('DSEC_events', 1.0), ('DDD17_events', 0.01)]:
+        st = _settings(name, K, T, C, w, w, True)
+        st.require_paired_data_val_a = st.require_paired_data_val_b = False
+        st.semseg_label_val_b, st.img_size_b = True, (H, W)
+        e2 = R.model.E2VIDRecurrent(dict(cfg))
+        e2.load_state_dict(O.synth_state_dict(e_shapes, 900))
+        dec = R.style.SemSegE2VID(256, K, skip_connect=True, skip_type='concat')
+        dec.load_state_dict(O.synth_state_dict(d_shapes, 901, decoder_style=True))
+        front = R.style.StyleEncoderE2VID(1, skip_connect=True)
+        front.load_state_dict(O.synth_state_dict(f_shapes, 902))
+        tr = R.trainer.ESSModel.__new__(R.trainer.ESSModel)
+        tr.models_dict = {'front_sensor_a': front, 'front_sensor_b': e2, 'back_end': dec}
+        common(tr, st, e2, dec)
+        for m in tr.models_dict.values():
+            m.eval()
+        batches = []
+        with torch.no_grad():
+            for b in range(NB):
+                ev, img, lab_a, lab_b = O.synth_batch(B, T, C, H, W, K, seed=950 + b)
+                la, _ = tr.val_step([img, lab_a], 'sensor_a', b, -1)
+                lb, _ = tr.val_step([ev, lab_b], 'sensor_b', b, -1)
+                batches.append(dict(dseed=950 + b, a={k: v.detach().clone() for k, v in la.items()},
+                                    b={k: v.detach().clone() for k, v in lb.items()}))
+        runs[name] = dict(batches=batches, settings=vars(st), metrics_a=summary(tr.metrics_semseg_a),
+                          metrics_b=summary(tr.metrics_semseg_b), metrics_cycle=summary(tr.metrics_semseg_cycle))
+
+    # supervised trainer
+    st = _settings('DDD17_events', K, T, C, 1.0, 1.0, True)
+    st.require_paired_data_val_a = st.require_paired_data_val_b = False
+    st.semseg_label_val_b, st.img_size_b = True, (H, W)
+    e2 = R.model.E2VIDRecurrent(dict(cfg))
+    e2.load_state_dict(O.synth_state_dict(e_shapes, 900))
+    dec = R.style.SemSegE2VID(256, K, skip_connect=True, skip_type='concat')
+    dec.load_state_dict(O.synth_state_dict(d_shapes, 901, decoder_style=True))
+    tr = R.sup.ESSSupervisedModel.__new__(R.sup.ESSSupervisedModel)
+    tr.models_dict = {'front_sensor_b': e2, 'back_end': dec}
+    common(tr, st, e2, dec)
+    e2.eval(), dec.eval()
+    batches = []
+    with torch.no_grad():
+        for b in range(NB):
+            ev, _, _, lab_b = O.synth_batch(B, T, C, H, W, K, seed=950 + b)
+            lb, _ = tr.val_step([ev, lab_b], 'sensor_b', b, -1)
+            batches.append(dict(dseed=950 + b, b={k: v.detach().clone() for k, v in lb.items()}))
+    sup = dict(batches=batches, metrics_b=summary(tr.metrics_semseg_b))
+    out['val_steps'] = dict(K=K, T=T, C=C, H=H, W=W, B=B, eseed=900, dseed=901, fseed=902, runs=runs, sup=sup)
+
+
 def _load_by_path(name, rel):
     """datasets/ and DSEC/ have no __init__.py (and `datasets` is shadowed by HuggingFace): load the file itself"""
     import importlib.util
@@ -393,19 +466,32 @@ def gold_voxel(out):
 
 
 def main():
+    """usage: make_golden.py [fixture ...] -- without arguments every fixture is regenerated."""
     torch.manual_seed(6)
     torch.set_num_threads(8)
     R = import_reference()
+    only = set(sys.argv[1:])
+    want = lambda *names: not only or bool(only & set(names))
     out = {}
     with torch.no_grad():
-        gold_normalize(R, out)
-        gold_e2vid(R, out)
-        gold_metrics(R, out)
-    gold_semseg(R, out)
-    gold_losses(R, out)
-    gold_radam(R, out)
-    gold_train_steps(R, out)
-    gold_voxel(out)
+        if want('normalize'):
+            gold_normalize(R, out)
+        if want('e2vid'):
+            gold_e2vid(R, out)
+        if want('metrics'):
+            gold_metrics(R, out)
+    if want('semseg'):
+        gold_semseg(R, out)
+    if want('losses'):
+        gold_losses(R, out)
+    if want('radam'):
+        gold_radam(R, out)
+    if want('sup_steps', 'uda_steps'):
+        gold_train_steps(R, out)
+    if want('voxel'):
+        gold_voxel(out)
+    if want('val_steps'):
+        gold_val_steps(R, out)
     for k, v in out.items():
         path = os.path.join(HERE, f'{k}.pt')
         torch.save(v, path)

@@ -623,3 +623,12 @@ def test_voxel_trilinear_partial_tiles_vs_oracle(H, shape):
         out = H.voxel_grid_trilinear(*args, offs, C, Hh, Ww, binned=binned)
         for i, r in enumerate(refs):
             assert _vox_close(out[i], torch.nan_to_num(r)), (shape, binned, i)
+
+
+@pytest.mark.parametrize('size', [((200, 352), (200, 346)), ((24, 40), (24, 40)), ((7, 9), (15, 20)), ((60, 80), (33, 17))])
+def test_resize_nearest_matches_torch(H, size):
+    """ess_resize_nearest == F.interpolate(mode='nearest') (index arithmetic in fp32), bit-exact."""
+    (h, w), (Ho, Wo) = size
+    x = torch.randn(2, 5, h, w)
+    y = H.resize_nearest(x.cuda(), (Ho, Wo))
+    assert torch.equal(y.cpu(), F.interpolate(x, size=(Ho, Wo), mode='nearest'))

@@ -181,6 +181,105 @@ def test_uda_steps_vs_golden(golden, branch):
             assert int(sdf['encoder_scale_1.1.num_batches_tracked']) == 2
 
 
+def _conf_close(got, ref, max_moved):
+    """Confusion matrices of two fp32 implementations differ only where a pixel's top-2 logits tie to within rounding
+    (random-weight logits are nearly flat): every label row keeps its exact count, at most `max_moved` pixels change
+    their predicted column."""
+    got, ref = got.cpu().long(), ref.cpu().long()
+    return torch.equal(got.sum(1), ref.sum(1)) and int((got - ref).abs().sum()) <= 2 * max_moved
+
+
+@pytest.mark.parametrize('branch', ['DSEC_events', 'DDD17_events'])
+def test_uda_val_steps_vs_golden(golden, branch):
+    """ESSModel.val_step for both sensors (eval-mode BatchNorm in the image encoder, cycle losses, the three
+    metric accumulators) against the reference's own val_step outputs."""
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_trainer import ESSModel
+    g = golden('val_steps')
+    run = g['runs'][branch]
+    rs = run['settings']
+    st = synthetic_settings('ess', branch, (g['H'], g['W']), g['K'], g['B'], g['T'], g['C'],
+                            weight_cycle=rs['weight_cycle_loss'], weight_cycle_task=rs['weight_cycle_task_loss'],
+                            train_on_event_labels=True)
+    tr = ESSModel(st)
+    cfg = O.e2vid_config(num_bins=g['C'])
+    tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), g['eseed']))
+    tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, g['K']), g['dseed'], decoder_style=True))
+    tr.front_end_sensor_a.load_state_dict(O.synth_state_dict(O.style_encoder_param_shapes(1), g['fseed']))
+    for m in tr.models_dict.values():
+        m.eval()
+    tr.resetValidationStatistics()
+    for b, gb in enumerate(run['batches']):
+        ev, img, lab_a, lab_b = O.synth_batch(g['B'], g['T'], g['C'], g['H'], g['W'], g['K'], seed=gb['dseed'])
+        la, none_a = tr.val_step([img.cuda(), lab_a.cuda()], 'sensor_a', b, -1)
+        lb, none_b = tr.val_step([ev.cuda(), lab_b.cuda()], 'sensor_b', b, -1)
+        assert none_a is None and none_b is None
+        for got, ref in ((la, gb['a']), (lb, gb['b'])):
+            assert set(got) == set(ref)
+            for k in got:
+                assert not got[k].requires_grad
+                assert abs(got[k].item() - ref[k].item()) < 2e-4 * max(1.0, abs(ref[k].item())), (k, got[k].item(), ref[k].item())
+    npix = g['B'] * g['H'] * g['W'] * len(run['batches'])
+    for name, m in (('a', tr.metrics_semseg_a), ('b', tr.metrics_semseg_b), ('cycle', tr.metrics_semseg_cycle)):
+        ms, ref = m.get_metrics_summary(), run['metrics_' + name]
+        assert _conf_close(ms['cm'], ref['cm'], max(2, npix // 200)), (name, ms['cm'], ref['cm'])
+        assert abs(float(ms['mean_iou']) - float(ref['miou'])) < 0.5 and abs(float(ms['acc']) - float(ref['acc'])) < 0.5
+    # the BatchNorm running statistics were only read
+    sdf = tr.front_end_sensor_a.state_dict()
+    assert int(sdf['encoder_scale_1.1.num_batches_tracked']) == 0
+    ref_rm = O.synth_state_dict(O.style_encoder_param_shapes(1), g['fseed'])['encoder_scale_1.1.running_mean']
+    assert torch.equal(sdf['encoder_scale_1.1.running_mean'].cpu(), ref_rm)
+
+
+def test_supervised_val_steps_vs_golden_and_validation_epochs(golden):
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
+    g = golden('val_steps')
+    st = synthetic_settings('ess_supervised', 'DDD17_events', (g['H'], g['W']), g['K'], g['B'], g['T'], g['C'],
+                            train_on_event_labels=True)
+    tr = ESSSupervisedModel(st)
+    cfg = O.e2vid_config(num_bins=g['C'])
+    tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), g['eseed']))
+    tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, g['K']), g['dseed'], decoder_style=True))
+    tr.task_backend.eval()
+    tr.resetValidationStatistics()
+    for b, gb in enumerate(g['sup']['batches']):
+        ev, _, _, lab_b = O.synth_batch(g['B'], g['T'], g['C'], g['H'], g['W'], g['K'], seed=gb['dseed'])
+        losses, _ = tr.val_step([ev.cuda(), lab_b.cuda()], 'sensor_b', b, -1)
+        ref = gb['b']['semseg_sensor_b_loss'].item()
+        assert set(losses) == {'semseg_sensor_b_loss'} and abs(losses['semseg_sensor_b_loss'].item() - ref) < 2e-4 * max(1, ref)
+    ms, ref = tr.metrics_semseg_b.get_metrics_summary(), g['sup']['metrics_b']
+    npix = g['B'] * g['H'] * g['W'] * len(g['sup']['batches'])
+    assert _conf_close(ms['cm'], ref['cm'], max(2, npix // 200))
+    with pytest.raises(KeyError):
+        tr.val_step([ev.cuda(), lab_b.cuda()], 'sensor_a', 0, -1)
+    # the epoch driver: eval mode, both accumulators reset, summary holds the loss mean and the metrics
+    tr.validationEpochs()
+    assert not tr.task_backend.training
+    assert set(tr.last_val_summary) == {'semseg_sensor_b_loss', 'semseg_sensor_b_mean_iou', 'semseg_sensor_b_acc'}
+    assert int(tr.last_val_metrics['cm'].sum()) > 0
+
+
+def test_uda_validation_epochs_driver():
+    """BaseTrainer.validationEpochs for the UDA trainer: sensor_a then sensor_b (reference base_trainer.py:416-424)."""
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_trainer import ESSModel
+    tr = ESSModel(synthetic_settings('ess', 'DSEC_events', (32, 48), 6, 2, 2, 2, val_steps=2))
+    tr.validationEpochs()
+    assert all(not m.training for m in tr.models_dict.values())
+    assert set(tr.last_val_summary) == {'sensor_a', 'sensor_b'}
+    sb = tr.last_val_summary['sensor_b']
+    for k in ('semseg_sensor_b_loss', 'cycle_latent_8x_sensor_b_to_sensor_a_loss', 'cycle_pred_1x_sensor_b_to_sensor_a_loss',
+              'semseg_sensor_b_mean_iou', 'semseg_sensor_cycle_mean_iou', 'semseg_sensor_cycle_acc'):
+        assert k in sb and sb[k] == sb[k], k
+    assert 'semseg_sensor_a_mean_iou' in tr.last_val_summary['sensor_a']
+    labelled = 2 * 2 * (32 - 2) * 48  # two batches of B=2; a two-row ignore band per label map
+    assert int(tr.last_val_metrics['semseg_sensor_b']['cm'].sum()) == labelled
+    # a training epoch afterwards flips the trainable modules back to train mode
+    tr.trainEpoch()
+    assert tr.task_backend.training and tr.front_end_sensor_a.training
+
+
 def test_config2_ddd17_shape_parity_vs_oracle():
     """BASELINE config 2: DDD17-shape (B=2, T=5, 2x200x352, K=6) supervised path on the HIP kernels vs the CPU oracle:
     logits within 1e-3 (fp32), per-pixel argmax exact wherever the oracle's own top-2 margin exceeds the logit error,

@@ -177,6 +177,49 @@ def test_uda_steps(golden, branch):
                 assert stats_close(stats(sd_f[k]), gs['front'][k], 1e-4), k
 
 
+# ---- validation steps (eval-mode modules under no_grad)
+@pytest.mark.parametrize('branch', ['DSEC_events', 'DDD17_events'])
+def test_uda_val_steps(golden, branch):
+    g = golden('val_steps')
+    run = g['runs'][branch]
+    st = run['settings']
+    cfg = O.e2vid_config(num_bins=g['C'])
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), g['eseed'])
+    sd_d = O.synth_state_dict(O.semseg_param_shapes(256, g['K']), g['dseed'], decoder_style=True)
+    sd_f = O.synth_state_dict(O.style_encoder_param_shapes(1), g['fseed'])
+    conf = {}
+    kw = dict(img_size_b=tuple(st['img_size_b']), w_task=st['weight_task_loss'], w_cycle=st['weight_cycle_loss'],
+              w_cycle_task=st['weight_cycle_task_loss'], w_kl=st['weight_KL_loss'])
+    for gb in run['batches']:
+        ev, img, lab_a, lab_b = O.synth_batch(g['B'], g['T'], g['C'], g['H'], g['W'], g['K'], seed=gb['dseed'])
+        for sensor, data, lab, ref in (('sensor_a', img, lab_a, gb['a']), ('sensor_b', ev, lab_b, gb['b'])):
+            losses, c = O.uda_val_step(sd_e, cfg, sd_f, sd_d, data, lab, sensor, g['T'], g['K'], **kw)
+            assert set(losses) == set(ref)
+            for k in losses:
+                assert abs(losses[k].item() - ref[k].item()) < 5e-5 * max(1, abs(ref[k].item())), (sensor, k)
+            for k, v in c.items():
+                conf[k] = conf.get(k, 0) + v
+    for k in ('a', 'b', 'cycle'):
+        ref = run['metrics_' + k]
+        assert torch.equal(conf[k], ref['cm'].long()), k
+        miou, _, acc = O.miou_acc(conf[k])
+        assert abs(miou.item() - ref['miou'].item()) < 1e-9 and abs(acc.item() - ref['acc'].item()) < 1e-9
+
+
+def test_supervised_val_steps(golden):
+    g = golden('val_steps')
+    cfg = O.e2vid_config(num_bins=g['C'])
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), g['eseed'])
+    sd_d = O.synth_state_dict(O.semseg_param_shapes(256, g['K']), g['dseed'], decoder_style=True)
+    conf = 0
+    for gb in g['sup']['batches']:
+        ev, _, _, lab_b = O.synth_batch(g['B'], g['T'], g['C'], g['H'], g['W'], g['K'], seed=gb['dseed'])
+        losses, c = O.supervised_val_step(sd_e, cfg, sd_d, ev, lab_b, g['T'], g['K'], img_size_b=(g['H'], g['W']))
+        assert abs(losses['semseg_sensor_b_loss'].item() - gb['b']['semseg_sensor_b_loss'].item()) < 5e-5
+        conf = conf + c['b']
+    assert torch.equal(conf, g['sup']['metrics_b']['cm'].long())
+
+
 # ---- events -> voxel grids (oracle pinned on the reference's VoxelGrid.convert / generate_voxel_grid)
 def _slice_time(t):
     import numpy as np
