@@ -484,10 +484,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
 
 
 // ---- fast variant: rows that are multiples of 8 pixels, direct / nearest-upsampled sources.
-// All global loads of the NEXT pixel tile (13 vectors = 26 x 16 B per thread) are issued before the MFMA phase of the
-// current one and stay in flight across it; conversion to bf16 + LDS write happen afterwards.  Loads are plain,
-// unconditional dwordx4 loads from clamped (always valid) per-lane addresses, zeroed by a 0/1 mask multiply -- no
-// branch, no select on the load, nothing for the compiler to serialize.
+// All global loads of the NEXT pixel tile (14 vectors = 28 x 16 B per thread) are issued at the top of a tile iteration
+// and stay in flight across the first half of its MFMA phase; their conversion to bf16 and the LDS writes (second LDS
+// stage) ride on k-steps 4-7 of that phase.  Loads are plain, unconditional dwordx4 loads from clamped (always valid)
+// per-lane addresses; padding / overhang vectors are zeroed by an AND mask after conversion -- no branch, no select on
+// the load, nothing for the compiler to serialize.
+// Ablation (256->256 @ 60x80, B=8, 142 us with the split-K reduce): fixed part (partial sums out + reduce kernel) 50 us,
+// loads + conversion alone 62 us (573 MB through L2->L1 = 9.2 TB/s: the bound), MFMA phase alone 45 us.
 __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBArgs b) {
   extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
   const WgradArgs& a = b.w;
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   const int Cin = a.C0 + a.C1;
   u32x4w* dy_t = smemv;
   u32x4w* x_t = smemv + 64 * b.pyv;
+  const int stage = 64 * (b.pyv + b.pxv);  // 16-byte vectors per LDS stage
   constexpr int DV = 4, XV = 10;  // vectors per thread: 64*128/8/256 of dY, ceil(64*IH*RV/256) of X (IH*RV = 36 or 40)
   const int nxv = 64 * IH * b.rv;
   const size_t HWo = (size_t)a.Hout * a.Wout;
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   const float* x_base[XV];  // channel plane of this vector's channel in its source (sample 0)
   size_t x_ns[XV];          // sample stride of that source
   int x_w[XV];
-  float x_ok[XV];
+  unsigned x_ok[XV];
 #pragma unroll
   for (int i = 0; i < XV; ++i) {
     const int v = tid + i * 256;
@@ -536,12 +540,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     x_base[i] = (first ? a.src0 : a.src1) + (size_t)cc * Hp * Wp;
     x_ns[i] = (size_t)Cs * Hp * Wp;
     x_w[i] = Wp; x_sh[i] = sh; x_iy[i] = iy; x_xv[i] = xv;
-    x_ok[i] = cok ? 1.f : 0.f;
+    x_ok[i] = cok ? 0xffffffffu : 0u;
     x_lds[i] = v < nxv ? ci * b.pxv + iy * b.rv + xv : -1;
   }
 
   f32x4 dreg[DV][2], xreg[XV][2];
-  float dmask[DV], xmask[XV];
+  unsigned dmask[DV], xmask[XV];  // 0 / all-ones, ANDed onto the converted vector (cheaper than 8 multiplies, NaN-safe)
   auto issue = [&](int tile) {
     const int n = tile / (a.tiles_x * a.tiles_y);
     const int tr = tile - n * a.tiles_x * a.tiles_y;
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
 #pragma unroll
     for (int i = 0; i < DV; ++i) {
       const int y = y0 + d_qy[i], x = x0 + d_xv[i] * 8;
-      dmask[i] = (d_co[i] < a.Cout && y < a.Hout && x < a.Wout) ? 1.f : 0.f;
+      dmask[i] = (d_co[i] < a.Cout && y < a.Hout && x < a.Wout) ? 0xffffffffu : 0u;
       const float* src = a.dy + ((size_t)n * a.Cout + min(d_co[i], a.Cout - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout +
                          min(x, a.Wout - 8);
       dreg[i][0] = *(const f32x4*)src;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
       const int gy = y0 - a.pad + x_iy[i], gx = x0 - 8 + x_xv[i] * 8;
-      xmask[i] = (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? x_ok[i] : 0.f;
+      xmask[i] = (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? x_ok[i] : 0u;
       const int cy = min(max(gy, 0), a.Hin - 1) >> x_sh[i];
       const int cx = min(max(gx, 0), a.Win - 8) >> x_sh[i];
       const float* src = x_base[i] + (size_t)n * x_ns[i] + (size_t)cy * x_w[i] + cx;
@@ -569,26 +573,27 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
       xreg[i][1] = *(const f32x4*)(src + (x_sh[i] ? 0 : 4));
     }
   };
-  auto commit = [&]() {
+  // convert + store ONE staged vector of the next tile into LDS stage `st` (i is a compile-time index after unrolling)
+  auto commit_d = [&](int i, int st) {
+    float f[8];
 #pragma unroll
-    for (int i = 0; i < DV; ++i) {
-      float f[8];
+    for (int j = 0; j < 4; ++j) { f[j] = dreg[i][0][j]; f[4 + j] = dreg[i][1][j]; }
+    u32x4w v = cvt8(f);
+    v[0] &= dmask[i]; v[1] &= dmask[i]; v[2] &= dmask[i]; v[3] &= dmask[i];
+    dy_t[st * stage + d_lds[i]] = v;
+  };
+  auto commit_x = [&](int i, int st) {
+    float f[8];
+    if (x_sh[i]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { f[j] = dreg[i][0][j] * dmask[i]; f[4 + j] = dreg[i][1][j] * dmask[i]; }
-      dy_t[d_lds[i]] = cvt8(f);
+      for (int j = 0; j < 4; ++j) { f[2 * j] = xreg[i][0][j]; f[2 * j + 1] = f[2 * j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { f[j] = xreg[i][0][j]; f[4 + j] = xreg[i][1][j]; }
     }
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-      float f[8];
-      if (x_sh[i]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[2 * j] = xreg[i][0][j] * xmask[i]; f[2 * j + 1] = f[2 * j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f[j] = xreg[i][0][j] * xmask[i]; f[4 + j] = xreg[i][1][j] * xmask[i]; }
-      }
-      if (x_lds[i] >= 0) x_t[x_lds[i]] = cvt8(f);
-    }
+    u32x4w v = cvt8(f);
+    v[0] &= xmask[i]; v[1] &= xmask[i]; v[2] &= xmask[i]; v[3] &= xmask[i];
+    if (x_lds[i] >= 0) x_t[st * stage + x_lds[i]] = v;
   };
 
   f32x16 acc[9];
@@ -598,32 +603,61 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
-  if (split < a.ntiles) issue(split);
-  for (int tile = split; tile < a.ntiles; tile += nsplit) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (tile + nsplit < a.ntiles) issue(tile + nsplit);
-    const u32x4w* ap = dy_t + (cb * 32 + p) * b.pyv + half;
-    const u32x4w* xp = x_t + (ib * 32 + p) * b.pxv + half;
-    for (int qy = 0; qy < THp; ++qy) {
-      for (int xs = 0; xs < TV; xs += 2) {
-        const u32x4w av = ap[qy * TV + xs];
-        const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+  // K loop over this workgroup's pixel tiles.  One tile = 8 k-steps of 16 pixels x 9 taps.  Two LDS stages: while the
+  // MFMAs of tile t read stage t&1, the vectors of tile t+1 (loads issued at the top of the iteration) are converted and
+  // written into the other stage, two per k-step, in the shadow of the matrix pipe; the fragments of k-step k+1 are
+  // read from LDS before the MFMAs of k-step k issue (register double buffer).  One barrier per tile.
+  const int ksh = a.twl - 4, kmask = (1 << ksh) - 1;  // k-step -> (tile row, 16-pixel column) of the pixel tile
+  struct Frag { u32x4w a; u32x4w v[3][3]; };
+  if (split < a.ntiles) {
+    issue(split);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+    for (int i = 0; i < DV; ++i) commit_d(i, 0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const u32x4w* row = xp + (qy + ky) * b.rv + xs;
-          const u32x4w v0 = row[0], v1 = row[1], v2 = row[2];
-          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(v0, v1)),
-                                                                    acc[ky * 3 + 0], 0, 0, 0);
-          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, v1), acc[ky * 3 + 1], 0, 0, 0);
-          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(v1, v2)),
-                                                                    acc[ky * 3 + 2], 0, 0, 0);
-        }
+    for (int i = 0; i < XV; ++i) commit_x(i, 0);
+  }
+  __syncthreads();
+  int st = 0;
+  for (int tile = split; tile < a.ntiles; tile += nsplit, st ^= 1) {
+    const bool more = tile + nsplit < a.ntiles;
+    if (more) issue(tile + nsplit);
+    const u32x4w* ap = dy_t + st * stage + (cb * 32 + p) * b.pyv + half;
+    const u32x4w* xp = x_t + st * stage + (ib * 32 + p) * b.pxv + half;
+    auto read_frag = [&](int ks, Frag& f) {
+      f.a = ap[2 * ks];
+      const u32x4w* row = xp + (ks >> ksh) * b.rv + ((ks & kmask) << 1);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        f.v[ky][0] = row[ky * b.rv]; f.v[ky][1] = row[ky * b.rv + 1]; f.v[ky][2] = row[ky * b.rv + 2];
+      }
+    };
+    auto mma = [&](const Frag& f) {
+      const bf16x8w af = __builtin_bit_cast(bf16x8w, f.a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(f.v[ky][0], f.v[ky][1])),
+                                                                  acc[ky * 3 + 0], 0, 0, 0);
+        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[ky][1]), acc[ky * 3 + 1], 0, 0, 0);
+        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(f.v[ky][1], f.v[ky][2])),
+                                                                  acc[ky * 3 + 2], 0, 0, 0);
+      }
+    };
+    Frag fr[2];
+    read_frag(0, fr[0]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) read_frag(ks + 1, fr[(ks + 1) & 1]);
+      mma(fr[ks & 1]);
+      if (more) {  // wave-uniform; the slice of the next tile's staging that rides on this k-step
+        if (ks == 4) { commit_d(0, st ^ 1); commit_d(1, st ^ 1); commit_d(2, st ^ 1); commit_d(3, st ^ 1); }
+        if (ks == 5) { commit_x(0, st ^ 1); commit_x(1, st ^ 1); commit_x(2, st ^ 1); }
+        if (ks == 6) { commit_x(3, st ^ 1); commit_x(4, st ^ 1); commit_x(5, st ^ 1); }
+        if (ks == 7) { commit_x(6, st ^ 1); commit_x(7, st ^ 1); commit_x(8, st ^ 1); commit_x(9, st ^ 1); }
       }
     }
+    __syncthreads();
   }
   const int ci = cit * 64 + ib * 32 + p;
 #pragma unroll
@@ -913,8 +947,8 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     const bool fast = (d->W_in % 8) == 0 && (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
     if (fast) {
-      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel, w.lds_bytes))) return rc;
-      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel, grid, dim3(256), w.lds_bytes, st, bb);
+      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel, 2 * w.lds_bytes))) return rc;  // two LDS stages
+      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel, grid, dim3(256), 2 * w.lds_bytes, st, bb);
     } else {
       if ((rc = raise_lds(wgrad_bf16_k3s1_kernel, w.lds_bytes))) return rc;
       hipLaunchKernelGGL(wgrad_bf16_k3s1_kernel, grid, dim3(256), w.lds_bytes, st, bb);
