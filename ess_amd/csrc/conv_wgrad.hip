@@ -784,43 +784,66 @@ __global__ __launch_bounds__(256) void wgrad_small1x1_mfma_kernel(const WgradArg
 }
 
 // Deterministic reduction of the split-K slabs: dw[co][ci][tap] (+)= sum_split ws[split][tap][co][ci].
-// One workgroup = 64 consecutive slab elements (coalesced) x 16 waves, wave w summing splits w, w+16, ... with 8
-// independent accumulators, then a fixed-order combine through LDS.  (The first version gave each thread the whole
-// split loop: 256-512 dependent-latency iterations, 30-90 us for a few MB.)  Elements past `total` belong to the bias
-// slabs: element total + co sums ws_b[split][co].
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T,
-                                                            int Cout, int Cin, int accumulate) {
-  __shared__ float part[16][64];
-  const size_t total = (size_t)T * Cout * Cin;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + lane;
-  const bool is_w = i < total;
-  const bool is_b = !is_w && db && ws_b && i < total + (size_t)Cout;
-  const float* src = is_w ? ws + i : ws_b + (i - total);
-  const size_t stride = is_w ? total : (size_t)Cout;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (is_w || is_b) {
-    int k = wave;
-    for (; k + 7 * 16 < nsplit; k += 8 * 16) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(k + 16 * u) * stride];
-    }
-    for (int u = 0; k < nsplit; k += 16, ++u) s[u] += src[(size_t)k * stride];
+// One workgroup = E consecutive (co, ci) elements x NT taps x G = THREADS/E split groups: thread (g, e) sums splits g, g+G, ...
+// of its element, U splits x NT taps = 36 / 8 independent coalesced loads in flight; the groups are combined in a fixed
+// order through LDS.
+//   <64, 9>: 3x3 layers with >= 32k weights.  The E x 9 results leave as ONE contiguous run of dw (the [co][ci][tap] order
+//            makes the taps of an element adjacent); the first version wrote them with a 36-byte stride from nine
+//            workgroups (read-modify-write of partial lines, 1.9 TB/s overall): 256x256x9, 16 splits: 20 -> 9 us.
+//   <64, 1>: everything else (few weights, many splits): one tap per workgroup (blockIdx.y), 16 split groups of 64 lanes
+//            (1024 threads) -- there the slab reads are all that matters and they want as many loads in flight as possible.
+// Blocks past nblk_w (blockIdx.y == 0 only) reduce the bias slabs ws_b[split][co] the same way (one "tap").
+template <int E, int NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T,
+                                                           int CC, int Cout, int nblk_w, int accumulate) {
+  constexpr int G = THREADS / E, PITCH = E * NT + 1, U = NT == 1 ? 8 : 4;
+  __shared__ float part[G * PITCH];
+  int blk = blockIdx.x, t0 = blockIdx.y * NT, nt = min(NT, T - t0);
+  if (blk >= nblk_w) {  // bias blocks (uniform per block)
+    if (blockIdx.y) return;
+    blk -= nblk_w; ws = ws_b; dw = db; T = 1; CC = Cout; nt = 1;
   }
-  part[wave][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  __syncthreads();
-  if (wave == 0 && (is_w || is_b)) {
-    float t = 0.f;
+  const int el = threadIdx.x % E, g = threadIdx.x / E;
+  const int e = blk * E + el;
+  float acc[NT];
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += part[w][lane];
-    if (is_w) {
-      const int tap = i / ((size_t)Cout * Cin);
-      const size_t rem = i - (size_t)tap * Cout * Cin;  // co*Cin + ci
-      float* dst = dw + rem * T + tap;
+  for (int u = 0; u < NT; ++u) acc[u] = 0.f;
+  if (e < CC) {
+    int k = g;
+    for (; k + (U - 1) * G < nsplit; k += U * G) {
+      float v[U][NT];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float* src = ws + ((size_t)(k + j * G) * T + t0) * CC + e;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) v[j][u] = u < nt ? src[(size_t)u * CC] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < U; j += 2) t += v[j][u] + v[j + 1][u];
+        acc[u] += t;
+      }
+    }
+    for (; k < nsplit; k += G) {
+      const float* src = ws + ((size_t)k * T + t0) * CC + e;
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        if (u < nt) acc[u] += src[(size_t)u * CC];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) part[g * PITCH + el * NT + u] = acc[u];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < E * NT; idx += THREADS) {
+    const int l = idx / NT, u = idx - l * NT;
+    if (u < nt && blk * E + l < CC) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < G; ++w) t += part[w * PITCH + idx];
+      float* dst = dw + (size_t)(blk * E + l) * T + t0 + u;
       *dst = accumulate ? *dst + t : t;
-    } else {
-      const size_t co = i - total;
-      db[co] = accumulate ? db[co] + t : t;
     }
   }
 }
@@ -967,8 +990,15 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
   rc = ess_launch_status("conv2d_wgrad");
   if (rc) return rc;
   ESS_CHECK_ARG(!(w.taps_variant && db), "wgrad: the stem variant has no bias gradient");
-  const size_t total = (size_t)T * d->C_out * cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div64(total + d->C_out, 64)), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
-                     w.nsplit, T, d->C_out, cin, accumulate);
+  const int CC = d->C_out * cin;
+  const bool wide = T == 9 && CC >= 32768;
+  const int E = 64;
+  const int nblk_w = ceil_div(CC, E), nblk_b = (db && a.ws_b) ? ceil_div(d->C_out, E) : 0;
+  if (wide)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<64, 9, 256>), dim3((unsigned)(nblk_w + nblk_b)), dim3(256), 0, st, a.ws, a.ws_b, dw, db, w.nsplit, T,
+                       CC, d->C_out, nblk_w, accumulate);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1, 1024>), dim3((unsigned)(nblk_w + nblk_b), (unsigned)T), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
+                       w.nsplit, T, CC, d->C_out, nblk_w, accumulate);
   return ess_launch_status("conv2d_wgrad_reduce");
 }
