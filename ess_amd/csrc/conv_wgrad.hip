@@ -620,7 +620,6 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   int st = 0;
   for (int tile = split; tile < a.ntiles; tile += nsplit, st ^= 1) {
     const bool more = tile + nsplit < a.ntiles;
-    if (more) issue(tile + nsplit);
     const u32x4w* ap = dy_t + st * stage + (cb * 32 + p) * b.pyv + half;
     const u32x4w* xp = x_t + st * stage + (ib * 32 + p) * b.pxv + half;
     auto read_frag = [&](int ks, Frag& f) {
@@ -650,6 +649,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     for (int ks = 0; ks < 8; ++ks) {
       if (ks + 1 < 8) read_frag(ks + 1, fr[(ks + 1) & 1]);
       mma(fr[ks & 1]);
+      if (ks == 0 && more) issue(tile + nsplit);  // address arithmetic + 28 loads, behind the first k-step's MFMAs
       if (more) {  // wave-uniform; the slice of the next tile's staging that rides on this k-step
         if (ks == 4) { commit_d(0, st ^ 1); commit_d(1, st ^ 1); commit_d(2, st ^ 1); commit_d(3, st ^ 1); }
         if (ks == 5) { commit_x(0, st ^ 1); commit_x(1, st ^ 1); commit_x(2, st ^ 1); }
