@@ -61,13 +61,20 @@ __device__ __forceinline__ void ess_store_bf16x4(void* base, size_t sample_blk0,
   *(uint2*)((char*)base + ((sample_blk0 + blk) * HW + pix) * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
 }
 
-template <int MB, int EPI, bool SC, bool IN>
+// FIX pins the wave-uniform run-time options at compile time for the combinations the train step launches most (each
+// one is a branch inside 16 x MB x NBW unrolled rows otherwise -- code size and registers):
+//   0: nothing pinned;  1: no activation, no BF16_C8 copy, one fp32 output;  2: ReLU, one output (copy / fp32 optional);
+//   3: no activation, no copy, split output (the data-gradient of a concat convolution)
+template <int MB, int EPI, bool SC, bool IN, int FIX = 0>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
                                                    const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned plane_b) {
   constexpr int COT = MB * 32;
   const unsigned HW = plane_b / 4u;
   const int c_out = EPI == ESS_EPI_LINEAR ? a.Cout : a.hid;
-  const int split = EPI == ESS_EPI_LINEAR ? a.out_split : 0;
+  const int split = (EPI == ESS_EPI_LINEAR && (FIX == 0 || FIX == 3)) ? a.out_split : 0;
+  const int act = FIX == 1 || FIX == 3 ? (int)ESS_ACT_NONE : FIX == 2 ? (int)ESS_ACT_RELU : a.act;
+  const bool has_bf = (FIX == 1 || FIX == 3) ? false : a.out_bf != nullptr;
+  const bool has_out = FIX == 1 ? true : a.out != nullptr;
   const int c_first = split > 0 ? split : c_out;  // channels of the first output tensor
   const int nblk = (c_out + 7) >> 3;              // 8-channel blocks of the BF16_C8 copy
   const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * c_first * HW, (size_t)c_first * plane_b);
@@ -112,27 +119,57 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
         v += sh[r];
         if constexpr (EPI == ESS_EPI_LINEAR) {
           if constexpr (IN) v += in0v[r];
-          if (a.act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
-          else if (a.act == ESS_ACT_TANH) v = ess_tanh(v);
+          if (act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
+          else if (act == ESS_ACT_TANH) v = ess_tanh(v);
         } else {  // GRU candidate: h' = h (1-u) + tanh(.) u
           v = in0v[r] * (1.f - in1v[r]) + ess_tanh(v) * in1v[r];
         }
         const int co = cu + 4 * half;
-        if (a.out_bf) {  // wave-uniform
+        if (has_bf) {  // wave-uniform
           q[r & 3] = co < c_out ? v : 0.f;  // tail channels of the last block are zero
           if ((r & 3) == 3 && pixi[nb] >= 0 && (rowbase >> 3) + (r >> 2) < nblk)
             ess_store_bf16x4(a.out_bf, (size_t)n * nblk, (rowbase >> 3) + (r >> 2), HW, pixi[nb], half, q[0], q[1], q[2], q[3]);
         }
-        if (split > 0) {  // the two halves of a wave may straddle the split: tensor and channel are chosen per lane
+        if (FIX == 3 || split > 0) {  // the two halves of a wave may straddle the split: tensor and channel are chosen per lane
           const unsigned pixo = voff[nb] == ESS_OOB ? ESS_OOB : voff[nb] - 4u * half * plane_b;
           if (co < split) ess_bstore(v, r_out, pixo + (unsigned)co * plane_b, 0);
           else if (co < c_out) ess_bstore(v, r_out2, pixo + (unsigned)(co - split) * plane_b, 0);
-        } else if (a.out) {  // (NULL: the caller only wants the BF16_C8 copy)
+        } else if (has_out) {  // (NULL: the caller only wants the BF16_C8 copy)
           ess_bstore(v, r_out, co < c_out ? voff[nb] : ESS_OOB, (unsigned)cu * plane_b);
         }
       }
     }
+  }
+}
+
+// The commonest LINEAR epilogue -- y = acc + bias into one fp32 NCHW tensor, nothing else -- without the run-time options
+// of conv_epilogue_rows (activation, residual, scale, split output, BF16_C8 copy).  Those are wave-uniform branches, but
+// inside 16 x MB x NBW unrolled rows they cost registers: the general LINEAR kernel spills ~190 VGPRs in its epilogue.
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_plain(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                    const unsigned (&voff)[NBW], unsigned plane_b) {
+  constexpr int COT = MB * 32;
+  const unsigned HW = plane_b / 4u;
+  const int c_out = a.Cout;
+  const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * c_out * HW, (size_t)c_out * plane_b);
+  const ess_rsrc r_sh = ess_make_rsrc(a.shift ? a.shift : a.out, a.shift ? (size_t)c_out * 4 : 0);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+    float sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = rowbase + (r & 3) + 8 * (r >> 2);
+      sh[r] = ess_bload(r_sh, cu + 4 * half < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cu = rowbase + (r & 3) + 8 * (r >> 2);
+        ess_bstore(acc[mb][nb][r] + sh[r], r_out, cu + 4 * half < c_out ? voff[nb] : ESS_OOB, (unsigned)cu * plane_b);
+      }
   }
 }
 
@@ -155,7 +192,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
     else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
-    if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, pixi, plane_b);
+    const bool bare = a.act == ESS_ACT_NONE && !a.out_bf && a.out;
+    if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
+    else if (bare && !a.scale && a.residual && a.out_split == 0)
+      conv_epilogue_rows<MB, EPI, false, true, 1>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (bare && !a.scale && !a.residual && a.out_split > 0)
+      conv_epilogue_rows<MB, EPI, false, false, 3>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (a.act == ESS_ACT_RELU && a.scale && !a.residual && a.out_split == 0)
+      conv_epilogue_rows<MB, EPI, true, false, 2>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, pixi, plane_b);
     else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
     else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false>(a, acc, ct, n, half, voff, pixi, plane_b);
     else conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
