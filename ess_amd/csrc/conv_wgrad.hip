@@ -491,6 +491,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
 // the load, nothing for the compiler to serialize.
 // Ablation (256->256 @ 60x80, B=8, 142 us with the split-K reduce): fixed part (partial sums out + reduce kernel) 50 us,
 // loads + conversion alone 62 us (573 MB through L2->L1 = 9.2 TB/s: the bound), MFMA phase alone 45 us.
+template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBArgs b) {
   extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
   const WgradArgs& a = b.w;
@@ -596,9 +597,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     if (x_lds[i] >= 0) x_t[st * stage + x_lds[i]] = v;
   };
 
-  f32x16 acc[9];
+  f32x16 acc[TAPS];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
@@ -625,22 +626,30 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     auto read_frag = [&](int ks, Frag& f) {
       f.a = ap[2 * ks];
       const u32x4w* row = xp + (ks >> ksh) * b.rv + ((ks & kmask) << 1);
+      if constexpr (TAPS == 1) {
+        f.v[1][1] = row[b.rv + 1];
+      } else {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        f.v[ky][0] = row[ky * b.rv]; f.v[ky][1] = row[ky * b.rv + 1]; f.v[ky][2] = row[ky * b.rv + 2];
+        for (int ky = 0; ky < 3; ++ky) {
+          f.v[ky][0] = row[ky * b.rv]; f.v[ky][1] = row[ky * b.rv + 1]; f.v[ky][2] = row[ky * b.rv + 2];
+        }
       }
     };
     auto mma = [&](const Frag& f) {
       const bf16x8w af = __builtin_bit_cast(bf16x8w, f.a);
 #pragma unroll
       for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+      if constexpr (TAPS == 1) {  // 1x1 convolution = the centre tap of the same pixel-tile geometry
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[1][1]), acc[0], 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(f.v[ky][0], f.v[ky][1])),
-                                                                  acc[ky * 3 + 0], 0, 0, 0);
-        acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[ky][1]), acc[ky * 3 + 1], 0, 0, 0);
-        acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(f.v[ky][1], f.v[ky][2])),
-                                                                  acc[ky * 3 + 2], 0, 0, 0);
+        for (int ky = 0; ky < 3; ++ky) {
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(f.v[ky][0], f.v[ky][1])),
+                                                                    acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[ky][1]), acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(f.v[ky][1], f.v[ky][2])),
+                                                                    acc[ky * 3 + 2], 0, 0, 0);
+        }
       }
     };
     Frag fr[2];
@@ -661,11 +670,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   }
   const int ci = cit * 64 + ib * 32 + p;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * TAPS + t) * a.Cout + co) * Cin + ci] = acc[t][r];
     }
   if (a.ws_b && cit == 0 && ib == 0) {
     bsum += __shfl_xor(bsum, 32, 64);
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, 
 
 struct WPlan {
   int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
-  bool taps_variant, bf16, small1x1, small1x1_mfma;
+  bool taps_variant, bf16, bf16_1x1, small1x1, small1x1_mfma;
   int pyv, pxv, rv;
   size_t slab_floats;
 };
@@ -871,6 +880,11 @@ WPlan wplan(const EssConvDesc* d) {
   w.taps_variant = (cin == 1 && KS == 7);
   w.small1x1 = KS == 1 && S == 1 && d->pad == 0 && d->C1 == 0 && d->mode0 == ESS_SRC_DIRECT && d->C_out <= 16 && cin <= 64;
   w.bf16 = d->compute == ESS_COMPUTE_BF16 && KS == 3 && S == 1 && d->pad == 1;
+  // 1x1 / stride 1 with at least a tile of channels: the centre tap of the same kernel (the fp32 tile kernel ran the ResNet
+  // downsample gradients at 10 TFLOP/s); needs the fast variant's geometry (rows of 8 pixels, direct / upsampled sources)
+  w.bf16_1x1 = d->compute == ESS_COMPUTE_BF16 && KS == 1 && S == 1 && d->pad == 0 && !w.small1x1 && (d->W_in % 8) == 0 &&
+               (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
+  w.bf16 = w.bf16 || w.bf16_1x1;
   const int npx = w.bf16 ? 128 : 64;
   // pixel tile of 64 (fp32) / 128 (bf16): pick the width that wastes the least
   double best = 1e300;
@@ -969,9 +983,13 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     const bool fast = (d->W_in % 8) == 0 && (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
-    if (fast) {
-      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel, 2 * w.lds_bytes))) return rc;  // two LDS stages
-      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel, grid, dim3(256), 2 * w.lds_bytes, st, bb);
+    if (w.bf16_1x1) {
+      bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile
+      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel<1>, 2 * w.lds_bytes))) return rc;
+      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel<1>, grid, dim3(256), 2 * w.lds_bytes, st, bb);
+    } else if (fast) {
+      if ((rc = raise_lds(wgrad_bf16_k3s1_fast_kernel<9>, 2 * w.lds_bytes))) return rc;  // two LDS stages
+      hipLaunchKernelGGL(wgrad_bf16_k3s1_fast_kernel<9>, grid, dim3(256), 2 * w.lds_bytes, st, bb);
     } else {
       if ((rc = raise_lds(wgrad_bf16_k3s1_kernel, w.lds_bytes))) return rc;
       hipLaunchKernelGGL(wgrad_bf16_k3s1_kernel, grid, dim3(256), w.lds_bytes, st, bb);
