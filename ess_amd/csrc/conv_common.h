@@ -173,6 +173,71 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvKArgs& a, f32x16 (
   }
 }
 
+// ESS_ACT_SUMPOOL2: the first output (channels < out_split, or all of them) leaves as the 2x2 SUM of its pixels at half the
+// resolution -- the data-gradient of a nearest-x2-upsampled source, without the full-resolution tensor in between.  A lane
+// owns one pixel of a 32-pixel block (BW wide, RB = 32/BW rows): the horizontal partner is lane^1, the vertical one lane^BW
+// (RB >= 2) or the same lane's other pixel block (RB == 1: blocks nb = 0/1 are rows 2k / 2k+1).  Shuffles are executed by
+// every lane; which lanes store is decided afterwards.  Channels >= out_split go to out2 at full resolution.
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
+                                                   int y0, const int (&ly)[NBW], unsigned plane_b) {
+  static_assert(NBW == 2, "the RB == 1 pairing assumes two pixel blocks per wave");
+  constexpr int COT = MB * 32;
+  const unsigned HW = plane_b / 4u;
+  const int Wl = a.Wout >> 1, Hl = a.Hout >> 1;
+  const unsigned plane_l = (unsigned)(Hl * Wl) * 4u;
+  const int c_out = a.Cout, split = a.out_split;
+  const int c_first = split > 0 ? split : c_out;
+  const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * c_first * (plane_l / 4u), (size_t)c_first * plane_l);
+  const ess_rsrc r_out2 =
+      ess_make_rsrc(split > 0 ? a.out2 + (size_t)n * (c_out - split) * HW : a.out, (size_t)(split > 0 ? c_out - split : 0) * plane_b);
+  const ess_rsrc r_sh = ess_make_rsrc(a.shift ? a.shift : a.out, a.shift ? (size_t)c_out * 4 : 0);
+  const int BW = 1 << a.bwl;
+  const bool rows1 = a.bwl == 5;  // RB == 1
+  const bool xin = x < a.Wout, xeven = (x & 1) == 0;
+  unsigned pix_h[NBW], pix_l[NBW];  // byte offsets of this lane's pixel (full res) / pooled pixel inside one channel plane
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int y = y0 + ly[nb];
+    const bool inb = xin && y < a.Hout;
+    pix_h[nb] = inb ? (unsigned)(y * a.Wout + x) * 4u : ESS_OOB;
+    const bool st = inb && xeven && (y & 1) == 0 && (!rows1 || nb == 0);
+    pix_l[nb] = st ? (unsigned)((y >> 1) * Wl + (x >> 1)) * 4u : ESS_OOB;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = rowbase + (r & 3) + 8 * (r >> 2);
+      const int co = cu + 4 * half;
+      const float sh = ess_bload(r_sh, co < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u);
+      float v[NBW], t[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) v[nb] = acc[mb][nb][r] + sh;
+      if (rows1) {
+        t[0] = v[0] + v[1];
+        t[0] += __shfl_xor(t[0], 1, 64);
+        t[1] = 0.f;
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          t[nb] = v[nb] + __shfl_xor(v[nb], BW, 64);
+          t[nb] += __shfl_xor(t[nb], 1, 64);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        if (co < c_first) {
+          ess_bstore(t[nb], r_out, pix_l[nb] == ESS_OOB ? ESS_OOB : pix_l[nb] + (unsigned)co * plane_l, 0);
+        } else if (co < c_out) {
+          ess_bstore(v[nb], r_out2, pix_h[nb] == ESS_OOB ? ESS_OOB : pix_h[nb] + (unsigned)(co - split) * plane_b, 0);
+        }
+      }
+    }
+  }
+}
+
 template <int MB, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                               int y0, const int (&ly)[NBW]) {
@@ -193,7 +258,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
     const bool bare = a.act == ESS_ACT_NONE && !a.out_bf && a.out;
-    if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
+    if (a.act == ESS_ACT_SUMPOOL2) conv_epilogue_pool<MB>(a, acc, ct, n, half, x, y0, ly, plane_b);
+    else if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
     else if (bare && !a.scale && a.residual && a.out_split == 0)
       conv_epilogue_rows<MB, EPI, false, true, 1>(a, acc, ct, n, half, voff, pixi, plane_b);
     else if (bare && !a.scale && !a.residual && a.out_split > 0)
@@ -420,6 +486,10 @@ inline int validate(const EssConvDesc* d) {
   if (d->epilogue != ESS_EPI_LINEAR)
     ESS_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->out_split == 0, "conv: recurrent epilogues are 3x3 s1");
   ESS_CHECK_ARG(d->out_split >= 0 && d->out_split < d->C_out, "conv: bad out_split");
+  ESS_CHECK_ARG(d->act >= ESS_ACT_NONE && d->act <= ESS_ACT_SUMPOOL2, "conv: bad act");
+  if (d->act == ESS_ACT_SUMPOOL2)
+    ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && d->stride == 1 && (d->H_out & 1) == 0 && (d->W_out & 1) == 0,
+                  "conv: SUMPOOL2 needs the LINEAR epilogue, stride 1 and even output extents");
   ESS_CHECK_ARG((d->fmt0 == ESS_FMT_F32_NCHW || d->fmt0 == ESS_FMT_BF16_C8) && (d->fmt1 == ESS_FMT_F32_NCHW || d->fmt1 == ESS_FMT_BF16_C8),
                 "conv: bad source format");
   if (d->fmt0 != ESS_FMT_F32_NCHW || d->fmt1 != ESS_FMT_F32_NCHW) {

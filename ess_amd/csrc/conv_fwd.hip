@@ -233,6 +233,8 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   if (out_bf16)
     ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->out_split == 0 && d->epilogue != ESS_EPI_GRU_UR,
                   "conv: the BF16_C8 output copy exists for bf16 compute, LINEAR / LSTM / GRU_OUT epilogues, no out_split");
+  if (d->act == ESS_ACT_SUMPOOL2)
+    ESS_CHECK_ARG(out && !scale && !residual && !out_bf16, "conv: SUMPOOL2 takes no scale / residual / BF16_C8 copy");
   EssConvPlan pl;
   make_plan(d, &pl);
   ESS_CHECK_ARG(pl.lds_bytes <= 160 * 1024, "conv: LDS tile %d B exceeds 160 KiB", pl.lds_bytes);

@@ -98,15 +98,21 @@ class Conv2dFn(torch.autograd.Function):
         d0 = d1 = dw = db = None
         if need0 or need1:
             split = C0 if C1 > 0 else 0
+            # a nearest-upsampled first source: its gradient is the 2x2 sum-pool of the virtual-resolution data-gradient;
+            # the kernel pools in its epilogue (ACT_SUMPOOL2) instead of writing the full-resolution tensor for a pool pass
+            pool0 = s == 1 and need0 and mode0 == hip.SRC_NEAREST_UP2 and (C1 == 0 or mode1 == hip.SRC_DIRECT) and \
+                not (Hv & 1) and not (Wv & 1)
             if s == 1:
-                dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p, out_split=split)
+                dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p, out_split=split,
+                                      act=hip.ACT_SUMPOOL2 if pool0 else hip.ACT_NONE)
             else:
                 if (Hv & 1) or (Wv & 1):
                     raise hip.EssHipError('data-gradient of a stride-2 conv needs even input extents')
                 dspec = hip.conv_spec(N, 2 * spec.H_out, 2 * spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p,
                                       mode0=hip.SRC_ZERO_UP2, out_split=split)
             assert (dspec.H_out, dspec.W_out) == (Hv, Wv), (dspec.H_out, dspec.W_out, Hv, Wv)
-            dv0 = torch.empty(N, C0, Hv, Wv, dtype=torch.float32, device=dy.device)
+            dv0 = torch.empty((N, C0, Hv // 2, Wv // 2) if (s == 1 and pool0) else (N, C0, Hv, Wv), dtype=torch.float32,
+                              device=dy.device)
             dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if C1 > 0 else None
             # the skip-branch gradient (see forward) rides in the epilogue when the data-gradient IS d(x0)
             fuse_skip = d_skip is not None and need0 and C1 == 0 and mode0 == hip.SRC_DIRECT
@@ -115,7 +121,7 @@ class Conv2dFn(torch.autograd.Function):
             if fuse_skip:
                 d_skip = None
             if need0:
-                d0 = hip.sumpool2x2(dv0) if mode0 == hip.SRC_NEAREST_UP2 else dv0
+                d0 = hip.sumpool2x2(dv0) if (mode0 == hip.SRC_NEAREST_UP2 and not (s == 1 and pool0)) else dv0
             if need1:
                 d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
         direct = DIRECT_GRAD_ACCUM and needw and weight.is_leaf and weight.grad is not None and weight.grad.is_contiguous() \

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libess_hip.so')
 
 SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED = 0, 1
 COMPUTE_FP32, COMPUTE_BF16 = 0, 1
 FMT_F32_NCHW, FMT_BF16_C8 = 0, 1

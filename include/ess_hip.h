@@ -38,7 +38,10 @@ enum {
   ESS_EPI_GRU_UR = 2,  /* ConvGRU update/reset -> (u, r*h)      e2vid/model/submodules.py:268-270     */
   ESS_EPI_GRU_OUT = 3  /* ConvGRU candidate -> h'               e2vid/model/submodules.py:270-271     */
 };
-enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3 };
+/* output transform of the LINEAR epilogue.  SUMPOOL2: no activation, and the first output (channels < out_split, or all
+ * of them) is written as the 2x2 sum of its pixels, [N][C][H_out/2][W_out/2] -- the data-gradient of a nearest-x2-upsampled
+ * source (mode ESS_SRC_NEAREST_UP2 of the forward convolution) without the full-resolution tensor in between.        */
+enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3, ESS_ACT_SUMPOOL2 = 4 };
 /* arithmetic of the convolution contraction.  Tensors in HBM are fp32 either way; BF16 rounds the MFMA operands
  * (activations while staging the LDS tile, weights at pack time) to bfloat16 and accumulates in fp32.         */
 enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };

@@ -632,3 +632,37 @@ def test_resize_nearest_matches_torch(H, size):
     x = torch.randn(2, 5, h, w)
     y = H.resize_nearest(x.cuda(), (Ho, Wo))
     assert torch.equal(y.cpu(), F.interpolate(x, size=(Ho, Wo), mode='nearest'))
+
+
+@pytest.mark.parametrize('compute', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 24, 16, 16, 16, 0), (1, 40, 8, 24, 72, 0), (2, 16, 24, 12, 40, 16), (1, 70, 33, 6, 8, 0),
+                                  (1, 64, 64, 60, 80, 0), (1, 48, 96, 20, 136, 64)])
+def test_conv_sumpool2_epilogue(H, compute, case):
+    """ACT_SUMPOOL2: the first output leaves as the 2x2 sum at half resolution (data-gradient of a nearest-upsampled source),
+    channels past out_split at full resolution -- equal to the plain launch followed by a sum-pool."""
+    N, Ci, Co, Hh, Ww, split = case
+    g = torch.Generator().manual_seed(Hh * 131 + Ww)
+    x = torch.randn(N, Ci, Hh, Ww, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.1
+    prev = H.get_compute()
+    H.set_compute(compute)
+    try:
+        plain = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 3, 1, 1, out_split=split)
+        pool = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 3, 1, 1, out_split=split, act=H.ACT_SUMPOOL2)
+        pw = H.pack_weights(plain, w.cuda(), None, H.W_CONV)
+        c1 = split if split else Co
+        o1 = torch.empty(N, c1, Hh, Ww, device='cuda')
+        o2 = torch.empty(N, Co - split, Hh, Ww, device='cuda') if split else None
+        H.conv_forward(plain, x.cuda(), None, pw, out=o1, out2=o2)
+        p1 = torch.full((N, c1, Hh // 2, Ww // 2), float('nan'), device='cuda')
+        p2 = torch.full((N, Co - split, Hh, Ww), float('nan'), device='cuda') if split else None
+        H.conv_forward(pool, x.cuda(), None, pw, out=p1, out2=p2)
+    finally:
+        H.set_compute(prev)
+    ref = F.avg_pool2d(o1.cpu().double(), 2) * 4
+    assert relerr(p1, ref) < 1e-6
+    if split:
+        assert torch.equal(p2, o2)
+    with pytest.raises(H.EssHipError):  # odd extents cannot be pooled
+        H.conv_forward(H.conv_spec(1, 5, 8, 4, 0, 4, 3, 1, 1, act=H.ACT_SUMPOOL2), x[:1, :4, :5, :8].contiguous().cuda(), None, pw,
+                       out=torch.empty(1, 4, 2, 4, device='cuda'))
