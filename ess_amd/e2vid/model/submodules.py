@@ -108,7 +108,18 @@ class ConvLayer(nn.Module):
             self.norm_layer = nl
         self._fold = _Fold()
 
-    def forward(self, x, x1=None, residual=None, want_c8=False, c8_only=False):
+    def forward_of_sum(self, x, skip):
+        """conv(x + skip) without the elementwise pass: W (x + skip) = [W W] [x; skip], i.e. the two tensors are the two
+        concat sources of one convolution whose weight is W repeated along the input channels (sum-skip ahead of the
+        prediction layer, reference unet.py:8-13,178-179).  Sums the same products in a different order."""
+        w = self.conv2d.weight
+        dup = getattr(self, '_dup_w', None)
+        if dup is None or dup[0] != (w._version, w.data_ptr()):
+            with torch.no_grad():
+                dup = self._dup_w = ((w._version, w.data_ptr()), torch.cat([w, w], dim=1).contiguous())
+        return self.forward(x, x1=skip, weight=dup[1])
+
+    def forward(self, x, x1=None, residual=None, want_c8=False, c8_only=False, weight=None):
         """x1: optional second source, channel-concatenated on the fly.
         want_c8: (bf16 arithmetic only) also emit the output as a BF16_C8 staging copy, attached to the returned
         tensor as `.ess_c8`, for a following 3x3 / 5x5 convolution to stage from (see ConvLSTM.forward).
@@ -117,6 +128,7 @@ class ConvLayer(nn.Module):
         _inference_only(x, x1)
         _check_eval(self, self.norm)
         c = self.conv2d
+        wt = c.weight if weight is None else weight  # (forward_of_sum: the weight repeated for the two sources)
         N, C0, H, W = x.shape
         C1 = 0 if x1 is None else x1.shape[1]
         spec = hip.conv_spec(N, H, W, C0, C1, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0],
@@ -131,10 +143,10 @@ class ConvLayer(nn.Module):
         x8 = _c8_of(x) if bf and x1 is None and hip.c8_stageable(k, c.stride[0], c.padding[0]) else None
         skip_fp32 = c8_only and c8 is not None
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
-            hip.conv_forward(spec, x8, None, packed_weight(spec, c.weight), scale, shift, residual,
+            hip.conv_forward(spec, x8, None, packed_weight(spec, wt), scale, shift, residual,
                              out=None if skip_fp32 else out, out_bf=c8, src_fmt=hip.FMT_BF16_C8)
         else:
-            hip.conv_forward(spec, _fp32(x), None if x1 is None else _fp32(x1), packed_weight(spec, c.weight), scale, shift,
+            hip.conv_forward(spec, _fp32(x), None if x1 is None else _fp32(x1), packed_weight(spec, wt), scale, shift,
                              residual, out=None if skip_fp32 else out, out_bf=c8)
         if c8 is not None:
             _attach_c8(out, c8)

@@ -64,7 +64,7 @@ class BaseUNet(nn.Module):
         self.pred.activation = self.activation
         try:
             if self.skip_type == 'sum':
-                img = self.pred(hip.add(x, head))
+                img = self.pred.forward_of_sum(x, head)
             else:
                 img = self.pred(x, x1=head)
         finally:
