@@ -754,6 +754,75 @@ int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_ki
   return ess_launch_status("pack_weights_bf16");
 }
 
+// ---- many weight tensors in one launch (re-packing every trainable convolution after an optimiser step: ~65 tensors of a few
+// hundred KB each, 5 us per single launch).  The job table travels in the kernel arguments; a block finds its job by a scan
+// over the (wave-uniform) block ranges.  LINEAR layouts of pack_weights_bf16_kernel only.
+struct PackJob {
+  const float* w;
+  __bf16* out;
+  long long total;
+  int blk_end;  // exclusive end of this job's block range
+  int cot, ck, n_chunks, ks, cin, cout, w_kind;
+};
+constexpr int PACK_JOBS = 48;
+struct PackJobs { PackJob j[PACK_JOBS]; int count; };
+
+__global__ void pack_weights_bf16_multi_kernel(const PackJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.count && (int)blockIdx.x >= jobs.j[k].blk_end) ++k;
+  const PackJob& jb = jobs.j[k];
+  const int blk0 = k ? jobs.j[k - 1].blk_end : 0;
+  const long long i = (long long)(blockIdx.x - blk0) * blockDim.x + threadIdx.x;
+  if (i >= jb.total) return;
+  long long t = i;
+  const int kp = t & 7; t >>= 3;
+  const int col = t % jb.cot; t /= jb.cot;
+  const int cb8 = jb.ck >> 3;
+  const int cb = t % cb8; t /= cb8;
+  const int tap = t % (jb.ks * jb.ks); t /= jb.ks * jb.ks;
+  const int ch = t % jb.n_chunks;
+  const int ct = t / jb.n_chunks;
+  const int c = ch * jb.ck + cb * 8 + kp;
+  const int row = ct * jb.cot + col;  // LINEAR: packed row = output channel
+  float v = 0.f;
+  if (row < jb.cout && c < jb.cin) {
+    const int ky = tap / jb.ks, kx = tap - ky * jb.ks;
+    if (jb.w_kind == ESS_W_CONV) v = jb.w[(((size_t)row * jb.cin + c) * jb.ks + ky) * jb.ks + kx];
+    else v = jb.w[(((size_t)c * jb.cout + row) * jb.ks + (jb.ks - 1 - ky)) * jb.ks + (jb.ks - 1 - kx)];
+  }
+  jb.out[i] = (__bf16)v;
+}
+
+// returns ESS_EINVAL (nothing launched) when a descriptor is not a plain bf16 LINEAR layout
+int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds, const float* const* w, void* const* packed, int count,
+                                 hipStream_t st) {
+  for (int i = 0; i < count; ++i) {
+    int rc = validate(&descs[i]);
+    if (rc) return rc;
+    ESS_CHECK_ARG(is_bf16(&descs[i]) && descs[i].epilogue == ESS_EPI_LINEAR && !is_paired(&descs[i]) && w[i] && packed[i] &&
+                      (kinds[i] == ESS_W_CONV || kinds[i] == ESS_W_TRANSPOSED),
+                  "pack_weights_multi: job %d is not a plain bf16 LINEAR layout", i);
+  }
+  for (int i0 = 0; i0 < count; i0 += PACK_JOBS) {
+    PackJobs jobs{};
+    int blocks = 0;
+    jobs.count = count - i0 < PACK_JOBS ? count - i0 : PACK_JOBS;
+    for (int k = 0; k < jobs.count; ++k) {
+      const EssConvDesc* d = &descs[i0 + k];
+      EssConvPlan pl;
+      make_plan(d, &pl);
+      PackJob& jb = jobs.j[k];
+      jb.w = w[i0 + k]; jb.out = (__bf16*)packed[i0 + k]; jb.total = pl.packed_elems;
+      jb.cot = pl.cout_tile; jb.ck = pl.ck; jb.n_chunks = pl.n_chunks; jb.ks = d->ksize; jb.cin = d->C0 + d->C1; jb.cout = d->C_out;
+      jb.w_kind = kinds[i0 + k];
+      blocks += (int)ceil_div64(pl.packed_elems, 256);
+      jb.blk_end = blocks;
+    }
+    hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
+  }
+  return ess_launch_status("pack_weights_multi");
+}
+
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st) {
   ESS_CHECK_ARG(g.IH * g.IW <= kpc(d->ksize, d->stride) * 256, "conv(bf16): input tile of %d positions exceeds the staging capacity",
                 g.IH * g.IW);

@@ -594,5 +594,7 @@ static __global__ void pack_rows_kernel(const float* v, const float* v2, float f
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st);
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
                            hipStream_t st);
+int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds, const float* const* w, void* const* packed, int count,
+                                 hipStream_t st);
 
 }  // namespace essconv

@@ -204,6 +204,12 @@ extern "C" int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const f
   return ess_launch_status("pack_weights");
 }
 
+extern "C" int ess_conv2d_pack_weights_multi(const EssConvDesc* descs, const int32_t* w_kinds, const float* const* w,
+                                             void* const* packed, int32_t count, ess_stream_t stream) {
+  ESS_CHECK_ARG(descs && w_kinds && w && packed && count > 0, "pack_weights_multi: bad arguments");
+  return conv_bf16_pack_weights_multi(descs, w_kinds, w, packed, count, (hipStream_t)stream);
+}
+
 extern "C" int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, float fill, float* packed,
                                     ess_stream_t stream) {
   int rc = validate(d);

@@ -51,6 +51,32 @@ def invalidate_packed(params):
         _pack_cache.pop(id(p), None)
 
 
+def repack(params):
+    """After a kernel rewrote `params` through raw pointers (the flat RAdam step): refresh their cached re-layouts IN
+    PLACE with one multi-tensor launch instead of dropping them and re-packing tensor by tensor on next use (2 layouts per
+    trainable convolution: ~65 launches of ~5 us per step).  Layouts the multi-tensor kernel does not cover are dropped."""
+    jobs = []
+    for p in params:
+        ent = _pack_cache.get(id(p))
+        if ent is None or ent[0]() is not p:
+            continue
+        if ent[1] != (p._version, -1, p.data_ptr()):
+            _pack_cache.pop(id(p), None)
+            continue
+        for key in list(ent[2]):
+            if key[-1] == 'rows':  # bias rows: cheap, re-packed lazily
+                del ent[2][key]
+                continue
+            skey, kind = key
+            k, epi, compute = skey[8], skey[11], skey[15]
+            if compute == hip.COMPUTE_BF16 and epi == hip.EPI_LINEAR and k != 5 and p.dim() == 4:
+                jobs.append((hip.spec_of(skey), kind, p.detach(), ent[2][key]))
+            else:
+                del ent[2][key]
+    if jobs:
+        hip.pack_weights_multi(jobs)
+
+
 def _virt(x, mode):
     m = 2 if mode != hip.SRC_DIRECT else 1
     return x.shape[2] * m, x.shape[3] * m

@@ -40,7 +40,7 @@ EXPORTS = [
     'ess_conv2d_forward', 'ess_to_bf16_c8', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
-    'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest',
+    'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
 ]
 
@@ -105,6 +105,7 @@ def lib():
             'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
             'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
             'ess_resize_nearest': [P, P, I, I, I, I, I, P],
+            'ess_conv2d_pack_weights_multi': [P, P, P, P, I, P],
             'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P, c_size_t, I64, P],
             'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
             'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
@@ -181,11 +182,30 @@ def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC
     return sp
 
 
+def spec_of(key):
+    """The cached ConvSpec of a `conv_spec` key tuple."""
+    sp = _desc_cache.get(key)
+    if sp is None:
+        sp = _desc_cache[key] = ConvSpec(key)
+    return sp
+
+
 def pack_weights(spec, w, w2=None, kind=W_CONV):
     out = torch.empty(spec.plan.packed_bytes, dtype=torch.uint8, device=w.device)
     _check(lib().ess_conv2d_pack_weights(byref(spec.desc), kind, ptr(w), ptr(w2), c_void_p(out.data_ptr()), stream()),
            'ess_conv2d_pack_weights')
     return out
+
+
+def pack_weights_multi(jobs):
+    """Re-pack many weights in one launch.  jobs: list of (spec, kind, weight, packed buffer).  Raises EssHipError when a
+    job is not a plain bf16 LINEAR layout (nothing is launched then)."""
+    n = len(jobs)
+    descs = (EssConvDesc * n)(*[j[0].desc for j in jobs])
+    kinds = (c_int32 * n)(*[int(j[1]) for j in jobs])
+    ws = (c_void_p * n)(*[ptr(j[2]).value for j in jobs])
+    outs = (c_void_p * n)(*[j[3].data_ptr() for j in jobs])
+    _check(lib().ess_conv2d_pack_weights_multi(descs, kinds, ws, outs, n, stream()), 'ess_conv2d_pack_weights_multi')
 
 
 def pack_rows(spec, v, v2=None, fill=0.0):

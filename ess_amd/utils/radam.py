@@ -13,7 +13,7 @@ from torch.optim.optimizer import Optimizer
 
 from .. import hip
 from .. import functional as _fn
-from ..functional import invalidate_packed
+from ..functional import repack
 
 
 class RAdam(Optimizer):
@@ -89,7 +89,7 @@ class RAdam(Optimizer):
         n_sma, step_size = self.rectification(self._step, beta1, beta2)
         hip.radam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, group['lr'], beta1, beta2,
                        group['eps'], step_size, n_sma >= 5)
-        invalidate_packed(group['params'])  # the kernel wrote the weights behind autograd's back
+        repack(group['params'])  # the kernel wrote the weights behind autograd's back: refresh their packed copies
         self._bind_grads()
         return loss
 

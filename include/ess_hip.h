@@ -103,6 +103,12 @@ int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
  * For ESS_EPI_GRU_UR pass w = update_gate.weight and w2 = reset_gate.weight.                        */
 int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const float* w, const float* w2,
                             void* packed, ess_stream_t stream);
+/* ess_conv2d_pack_weights for `count` tensors in one launch (the re-pack of every trainable convolution after an optimiser
+ * step).  bf16 compute, LINEAR epilogue, 1x1 / 3x3 / 7x7 layouts only; anything else is refused and nothing is launched.
+ * descs / w_kinds / w / packed: host arrays of `count` entries.                                                      */
+int ess_conv2d_pack_weights_multi(const EssConvDesc* descs, const int32_t* w_kinds, const float* const* w,
+                                  void* const* packed, int32_t count, ess_stream_t stream);
+
 /* Same permutation/padding for a per-output-channel vector (bias, folded BN scale/shift).
  * v2: second vector for GRU_UR (reset gate); fill: value for padded rows.                           */
 int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, float fill,

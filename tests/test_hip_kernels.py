@@ -666,3 +666,38 @@ def test_conv_sumpool2_epilogue(H, compute, case):
     with pytest.raises(H.EssHipError):  # odd extents cannot be pooled
         H.conv_forward(H.conv_spec(1, 5, 8, 4, 0, 4, 3, 1, 1, act=H.ACT_SUMPOOL2), x[:1, :4, :5, :8].contiguous().cuda(), None, pw,
                        out=torch.empty(1, 4, 2, 4, device='cuda'))
+
+
+def test_pack_weights_multi_matches_single(H):
+    """ess_conv2d_pack_weights_multi == ess_conv2d_pack_weights per tensor (bit-exact), incl. transposed layouts, 1x1 / 7x7,
+    more jobs than one launch holds; layouts it does not cover are refused."""
+    prev = H.get_compute()
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(5)
+        jobs, refs = [], []
+        shapes = [(2, 16, 24, 64, 0, 64, 3, 1, 1), (1, 8, 8, 1, 0, 64, 7, 2, 3), (2, 16, 16, 32, 0, 11, 1, 1, 0),
+                  (1, 16, 24, 40, 24, 72, 3, 1, 1), (2, 12, 16, 64, 0, 128, 3, 2, 1)]
+        for rep in range(11):  # 55 jobs > PACK_JOBS
+            for (N, Hh, Ww, C0, C1, Co, k, s_, p_) in shapes:
+                spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, k, s_, p_)
+                w = torch.randn(Co, C0 + C1, k, k, generator=g).cuda()
+                refs.append(H.pack_weights(spec, w, None, H.W_CONV))
+                jobs.append((spec, H.W_CONV, w, torch.zeros_like(refs[-1])))
+                if s_ == 1:  # data-gradient layout of the same weight
+                    dspec = H.conv_spec(N, Hh, Ww, Co, 0, C0 + C1, k, 1, k - 1 - p_, out_split=C0 if C1 else 0)
+                    refs.append(H.pack_weights(dspec, w, None, H.W_TRANSPOSED))
+                    jobs.append((dspec, H.W_TRANSPOSED, w, torch.zeros_like(refs[-1])))
+        H.pack_weights_multi(jobs)
+        for j, r in zip(jobs, refs):
+            assert torch.equal(j[3], r)
+        w5 = torch.randn(32, 16, 5, 5).cuda()
+        s5 = H.conv_spec(1, 16, 16, 16, 0, 32, 5, 1, 2)
+        with pytest.raises(H.EssHipError):
+            H.pack_weights_multi([(s5, H.W_CONV, w5, H.pack_weights(s5, w5, None, H.W_CONV))])
+        sf = H.conv_spec(1, 16, 16, 16, 0, 32, 3, 1, 1, compute=H.COMPUTE_FP32)
+        w3 = torch.randn(32, 16, 3, 3).cuda()
+        with pytest.raises(H.EssHipError):
+            H.pack_weights_multi([(sf, H.W_CONV, w3, H.pack_weights(sf, w3, None, H.W_CONV))])
+    finally:
+        H.set_compute(prev)
