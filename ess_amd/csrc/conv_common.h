@@ -211,25 +211,30 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
     for (int r = 0; r < 16; ++r) {
       const int cu = rowbase + (r & 3) + 8 * (r >> 2);
       const int co = cu + 4 * half;
-      const float sh = ess_bload(r_sh, co < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u);
+      const float sh = a.shift ? ess_bload(r_sh, co < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u) : 0.f;  // (uniform)
       float v[NBW], t[NBW];
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) v[nb] = acc[mb][nb][r] + sh;
-      if (rows1) {
+      // lane^1 through DPP (quad_perm [1,0,3,2]): a register move, not an LDS-crossbar permute
+      auto xor1 = [](float f) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xf, 0xf, true));
+      };
+      if (rows1) {  // (choose_geom picks 32-wide blocks for pooled launches whenever the image allows)
         t[0] = v[0] + v[1];
-        t[0] += __shfl_xor(t[0], 1, 64);
+        t[0] += xor1(t[0]);
         t[1] = 0.f;
       } else {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
           t[nb] = v[nb] + __shfl_xor(v[nb], BW, 64);
-          t[nb] += __shfl_xor(t[nb], 1, 64);
+          t[nb] += xor1(t[nb]);
         }
       }
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         if (co < c_first) {
-          ess_bstore(t[nb], r_out, pix_l[nb] == ESS_OOB ? ESS_OOB : pix_l[nb] + (unsigned)co * plane_l, 0);
+          if (nb == 0 || !rows1)  // (uniform: with one-row blocks the pooled pixel lives in block 0)
+            ess_bstore(t[nb], r_out, pix_l[nb] == ESS_OOB ? ESS_OOB : pix_l[nb] + (unsigned)co * plane_l, 0);
         } else if (co < c_out) {
           ess_bstore(v[nb], r_out2, pix_h[nb] == ESS_OOB ? ESS_OOB : pix_h[nb] + (unsigned)(co - split) * plane_b, 0);
         }
@@ -421,6 +426,8 @@ inline Geom choose_geom(const EssConvDesc* d) {
       const int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
       if (IH * IW > stage_kpc(KS, S) * 256) continue;  // would not fit the staging registers
       { const char* e = getenv("ESS_CONV_GEOM"); if (e && (e[0] - '0' != bwl || e[1] - '0' != wxl)) continue; }  // tuning hook
+      // pooled output: with 32-wide pixel blocks the vertical partner of a pixel is in the same lane (conv_epilogue_pool)
+      if (d->act == ESS_ACT_SUMPOOL2 && d->W_out >= 32 && bwl != 5) continue;
       // padded MACs (dominant) + a small halo/staging term + a coalescing term: a tile row is one contiguous run of the
       // NCHW planes for both the staging loads and the epilogue stores, and the large-plane layers are bound by how
       // HBM traffic is shaped (64->64 @240x320, B=8: 16x16 tiles 131 us, 32x8 121 us, 64x4 114 us); prefer wide blocks on ties
