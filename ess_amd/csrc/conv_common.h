@@ -161,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue_plain(const ConvKArgs& a, f32x16 (
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int cu = rowbase + (r & 3) + 8 * (r >> 2);
-      sh[r] = ess_bload(r_sh, cu + 4 * half < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u);
+      sh[r] = a.shift ? ess_bload(r_sh, cu + 4 * half < c_out ? 16u * half : ESS_OOB, (unsigned)cu * 4u) : 0.f;  // (uniform)
     }
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
