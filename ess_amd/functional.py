@@ -49,6 +49,23 @@ def invalidate_packed(params):
     not bump ``_version``)."""
     for p in params:
         _pack_cache.pop(id(p), None)
+        _first_cache.pop(id(p), None)
+
+
+_first_cache = {}
+
+
+def _first_inputs(weight, c0):
+    """Contiguous copy of weight[:, :c0] (the filters of a concat convolution's FIRST source), cached like the packed
+    layouts: used when only that source needs a data-gradient, so the kernel does not compute the other one's channels."""
+    ent = _first_cache.get(id(weight))
+    ver = (weight._version, weight.data_ptr(), c0)
+    if ent is None or ent[0]() is not weight or ent[1] != ver:
+        with torch.no_grad():
+            sub = weight.detach()[:, :c0].contiguous()
+        ent = (weakref.ref(weight, lambda _, k=id(weight): _first_cache.pop(k, None)), ver, sub)
+        _first_cache[id(weight)] = ent
+    return ent[2]
 
 
 def repack(params):
@@ -57,6 +74,7 @@ def repack(params):
     trainable convolution: ~65 launches of ~5 us per step).  Layouts the multi-tensor kernel does not cover are dropped."""
     jobs = []
     for p in params:
+        _first_cache.pop(id(p), None)  # derived copies: rebuilt on next use
         ent = _pack_cache.get(id(p))
         if ent is None or ent[0]() is not p:
             continue
@@ -124,25 +142,30 @@ class Conv2dFn(torch.autograd.Function):
         d0 = d1 = dw = db = None
         if need0 or need1:
             split = C0 if C1 > 0 else 0
+            wd, c_dg = weight, C0 + C1
+            if C1 > 0 and need0 and not need1:
+                # only the first source wants a gradient (the second is a detached skip latent): contract with its filters
+                # alone instead of computing and discarding the other source's channels
+                wd, c_dg, split = _first_inputs(weight, C0), C0, 0
             # a nearest-upsampled first source: its gradient is the 2x2 sum-pool of the virtual-resolution data-gradient;
             # the kernel pools in its epilogue (ACT_SUMPOOL2) instead of writing the full-resolution tensor for a pool pass
             pool0 = s == 1 and need0 and mode0 == hip.SRC_NEAREST_UP2 and (C1 == 0 or mode1 == hip.SRC_DIRECT) and \
                 not (Hv & 1) and not (Wv & 1)
             if s == 1:
-                dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p, out_split=split,
+                dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, c_dg, k, 1, k - 1 - p, out_split=split,
                                       act=hip.ACT_SUMPOOL2 if pool0 else hip.ACT_NONE)
             else:
                 if (Hv & 1) or (Wv & 1):
                     raise hip.EssHipError('data-gradient of a stride-2 conv needs even input extents')
-                dspec = hip.conv_spec(N, 2 * spec.H_out, 2 * spec.W_out, Cout, 0, C0 + C1, k, 1, k - 1 - p,
+                dspec = hip.conv_spec(N, 2 * spec.H_out, 2 * spec.W_out, Cout, 0, c_dg, k, 1, k - 1 - p,
                                       mode0=hip.SRC_ZERO_UP2, out_split=split)
             assert (dspec.H_out, dspec.W_out) == (Hv, Wv), (dspec.H_out, dspec.W_out, Hv, Wv)
             dv0 = torch.empty((N, C0, Hv // 2, Wv // 2) if (s == 1 and pool0) else (N, C0, Hv, Wv), dtype=torch.float32,
                               device=dy.device)
-            dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if C1 > 0 else None
+            dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if split > 0 else None
             # the skip-branch gradient (see forward) rides in the epilogue when the data-gradient IS d(x0)
             fuse_skip = d_skip is not None and need0 and C1 == 0 and mode0 == hip.SRC_DIRECT
-            hip.conv_forward(dspec, dy, None, packed_weight(dspec, weight, kind=hip.W_TRANSPOSED),
+            hip.conv_forward(dspec, dy, None, packed_weight(dspec, wd, kind=hip.W_TRANSPOSED),
                              residual=d_skip.contiguous() if fuse_skip else None, out=dv0, out2=dv1)
             if fuse_skip:
                 d_skip = None

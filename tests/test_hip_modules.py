@@ -491,3 +491,33 @@ def test_events_to_latents_pipeline_vs_oracle():
         _, _, lat = rec.update_reconstruction(ev[:, t * C:(t + 1) * C], need_image=False, lean_state=t < T - 1)
     for k in (1, 2, 4, 8):
         assert relerr(lat[k], lat_ref[k]) < 1e-4, k
+
+
+def test_concat_conv_first_source_only_gradient():
+    """Data-gradient of a concat convolution whose second source is detached (the decoder's skip latents in the decoder-
+    training passes): computed from the first source's filters alone, equal to the full data-gradient's first part; the
+    cached filter slice follows an optimiser step that rewrites the weight through raw pointers."""
+    from ess_amd import functional as Fn, hip
+    from ess_amd.utils import radam
+    torch.manual_seed(3)
+    w = torch.nn.Parameter((torch.randn(24, 16 + 8, 3, 3) * 0.1).cuda())
+    b = torch.nn.Parameter(torch.zeros(24).cuda())
+    opt = radam.RAdam([w, b], lr=1e-2, betas=(0., 0.999))
+    x0 = torch.randn(2, 16, 6, 10).cuda()
+    x1 = torch.randn(2, 8, 12, 20).cuda()
+    for it in range(2):
+        opt.zero_grad()
+        a = x0.clone().requires_grad_(True)
+        y = Fn.conv2d(a, w, b, 1, 1, x1=x1, mode0=hip.SRC_NEAREST_UP2)          # x1 detached: first-source-only path
+        y.square().sum().backward()
+        a2, c2 = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+        gw = w.grad.clone()
+        y2 = Fn.conv2d(a2, w, b, 1, 1, x1=c2, mode0=hip.SRC_NEAREST_UP2)         # both sources: full data-gradient
+        y2.square().sum().backward()
+        assert relerr(a.grad, a2.grad) < 1e-5, it
+        up = torch.nn.functional.interpolate(x0.cpu(), scale_factor=2, mode='nearest').requires_grad_(True)
+        ref = torch.nn.functional.conv2d(torch.cat([up, x1.cpu()], 1), w.detach().cpu(), b.detach().cpu(), padding=1)
+        ref.square().sum().backward()
+        assert relerr(a.grad, torch.nn.functional.avg_pool2d(up.grad, 2) * 4) < 1e-4, it
+        w.grad.copy_(gw)
+        opt.step()  # rewrites w behind autograd's back: the cached slice and packed layouts must follow
