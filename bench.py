@@ -160,6 +160,25 @@ def cpu_baseline(args):
                       f'), mean of 2 steps after 1 warm-up; {t:.2f} s/step'}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves through torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0:
+        raise SystemExit(proc.returncode)
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -167,8 +186,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+        return self_launch(args)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
     dev_index = local_rank % torch.cuda.device_count()  # (a CPU-side `gloo` smoke run may stack ranks on one GPU)
