@@ -1,0 +1,32 @@
+// Shared bits of the bf16-MFMA convolution kernels (conv_bf16*.hip): fragment types, staging helpers, and the launchers each
+// translation unit exports to the dispatcher in conv_bf16.hip.  The three kernel families live in separate files so that the
+// in-tree build compiles them in parallel.
+#pragma once
+#include "conv_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace essconv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+  return __builtin_bit_cast(u32x4, b);
+}
+
+// pixel positions a thread stages per 8-channel block (compile-time bound of the register prefetch), by filter geometry
+constexpr int kpc(int ks, int s) { return stage_kpc(ks, s); }
+constexpr unsigned OOB = 0x80000000u;  // beyond any buffer: the bounds-checked load returns 0
+
+// conv_bf16_generic.hip
+void conv_bf16_launch_generic(int key, int mb, int cb8, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
+// conv_bf16_ws.hip
+void conv_bf16_launch_ws(int mb, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
+// conv_bf16_pair.hip
+void conv_bf16_launch_pair(int stride, int mb, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
+
+}  // namespace essconv

@@ -1,0 +1,262 @@
+// Wave-specialised 3x3 / stride-1 convolution on the bf16 matrix cores (see conv_bf16.hip for the dispatcher).
+#include "conv_bf16_common.h"
+
+namespace {
+
+using namespace essconv;
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant for 3x3 / stride 1 (the bulk of the FLOPs).  512 threads: waves 0-3 only issue LDS reads
+// and MFMAs (consumers), waves 4-7 only stage (producers: bounds-checked loads -> bf16 -> LDS).  The dispatcher places
+// wave w on SIMD w % 4, so every SIMD hosts one consumer and one producer: the staging VALU/LDS-write work runs in the
+// shadow of the matrix pipe instead of in front of it.  LDS is double-buffered; ONE barrier per channel chunk:
+//   iteration ch: consumers read buffer ch&1 | producers convert+write chunk ch+1 into buffer (ch+1)&1 (its last
+//   readers passed the previous barrier) and then issue the loads of chunk ch+2, which land during iteration ch+1.
+template <int MB, int EPI, bool SRCBF>
+__global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
+  constexpr int KS = 3, CB8 = 2, CK = 16;
+  constexpr int COT = MB * 32;
+  constexpr int KPC = kpc(3, 1);
+  constexpr int WSZ = KS * KS * CB8 * COT;
+  constexpr int WV = (WSZ + 255) / 256;
+  const int role = threadIdx.x >> 8;  // 0: consumer (MFMA), 1: producer (staging) -- wave-uniform
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
+  const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = logical % a.n_cout_tiles;
+  const int sp = logical / a.n_cout_tiles;
+  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int bufsz = CB8 * a.plane + WSZ;  // one stage: input tile + weight slab (16-byte units)
+
+  if (role == 1 && SRCBF) {
+    // ------------------------------------------------------------------ producer, BF16_C8 sources
+    // The sources are already bf16 pixel vectors ([N][C/8][H][W][8]): staging one is ONE 16-byte load and ONE
+    // ds_write_b128, no conversion.  A halo row of the tile is 34 x 16 B contiguous, so an 8-channel block costs ~5
+    // cache lines per row instead of 8 x 3 with fp32 NCHW planes -- the L1 line rate, not HBM, bounded the fp32 staging.
+    // Padding / overhang positions read a clamped address and are zeroed by a mask; tail channels are zero in memory.
+    // A source may be read nearest-x2-upsampled (the decoder's upsample + concat) or zero-inserted (data-gradient of a
+    // stride-2 convolution): the position arithmetic is per source, the holes of ZERO_UP2 are masked like the padding.
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+    const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
+    const size_t hw0 = (size_t)(a.Hin >> sh0) * Wp0, hw1 = (size_t)(a.Hin >> sh1) * Wp1;
+    const int nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
+    const u32x4* s0 = (const u32x4*)a.src0 + (size_t)n * nb0 * hw0;
+    const u32x4* s1 = a.C1 ? (const u32x4*)a.src1 + (size_t)n * nb1 * hw1 : s0;
+    unsigned v_pos0[KPC], v_pos1[KPC], v_keep0[KPC], v_keep1[KPC];
+    int v_lds[KPC];
+    const int npos = a.IH * a.IW;
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) {
+      const int vi = tid + k * 256;
+      const int iy = vi / a.IW, ix = vi - iy * a.IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool in = vi < npos && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+      const bool odd = ((gy | gx) & 1) != 0;
+      const bool in0 = in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd), in1 = in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd);
+      v_lds[k] = vi < npos ? iy * a.row_pitch + ix : -1;
+      v_pos0[k] = in0 ? (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0)) : 0u;
+      v_pos1[k] = in1 ? (unsigned)((gy >> sh1) * Wp1 + (gx >> sh1)) : 0u;
+      v_keep0[k] = in0 ? 0xffffffffu : 0u;
+      v_keep1[k] = in1 ? 0xffffffffu : 0u;
+    }
+    u32x4 pre[CB8][KPC];
+    u32x4 wpre[WV];
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb) {
+        const int c0 = ch * CK + cb * 8;                 // wave-uniform
+        const bool first = c0 < a.C0 || a.C1 == 0;       // a block never straddles the sources (C0 % 8 == 0)
+        const int bi = (first ? c0 : c0 - a.C0) >> 3, nbs = first ? nb0 : nb1;
+        const u32x4* sp = (first ? s0 : s1) + (size_t)(bi < nbs ? bi : 0) * (first ? hw0 : hw1);  // blocks past the end: clamped, masked
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) pre[cb][k] = sp[first ? v_pos0[k] : v_pos1[k]];
+      }
+      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+    };
+    auto commit = [&](int ch, int buf) {
+      u32x4* in_t = smem16 + buf * bufsz;
+      u32x4* w_t = in_t + CB8 * a.plane;
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb) {
+        const int c0 = ch * CK + cb * 8;
+        const bool first = c0 < a.C0 || a.C1 == 0;
+        const unsigned blk_ok = ((first ? c0 : c0 - a.C0) >> 3) < (first ? nb0 : nb1) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) {
+          const unsigned m = (first ? v_keep0[k] : v_keep1[k]) & blk_ok;
+          u32x4 v = pre[cb][k];
+          v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+          if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = v;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+    };
+    load_chunk(0);
+    commit(0, 0);
+    if (a.n_chunks > 1) load_chunk(1);
+    __syncthreads();  // stage 0 is ready
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+      if (ch + 1 < a.n_chunks) {
+        commit(ch + 1, (ch + 1) & 1);
+        if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (role == 1) {
+    // ------------------------------------------------------------------------------------------- producer
+    const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
+    const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+    const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
+    const unsigned pl0 = (unsigned)((a.Hin >> sh0) * Wp0) * 4u, pl1 = (unsigned)((a.Hin >> sh1) * Wp1) * 4u;
+    const __amdgpu_buffer_rsrc_t r0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.src0 + (size_t)n * a.C0 * (pl0 / 4)), 0, a.C0 * pl0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.C1 ? a.src1 + (size_t)n * a.C1 * (pl1 / 4) : a.src0), 0, a.C1 * pl1, 0x00020000);
+    unsigned v_o0[KPC], v_o1[KPC];
+    int v_lds[KPC];
+    const int npos = a.IH * a.IW;
+#pragma unroll
+    for (int k = 0; k < KPC; ++k) {
+      const int vi = tid + k * 256;
+      const int iy = vi / a.IW, ix = vi - iy * a.IW;
+      const int gy = iy0 + iy, gx = ix0 + ix;
+      const bool in = vi < npos && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+      const bool odd = ((gy | gx) & 1) != 0;
+      v_lds[k] = vi < npos ? iy * a.row_pitch + ix : -1;
+      v_o0[k] = (in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0)) * 4u : OOB;
+      v_o1[k] = (in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd)) ? (unsigned)((gy >> sh1) * Wp1 + (gx >> sh1)) * 4u : OOB;
+    }
+    struct Raw8 { float v[8]; };
+    Raw8 pre[CB8][KPC];
+    u32x4 wpre[WV];
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb) {
+        const int c0 = ch * CK + cb * 8;
+        const bool first = c0 < a.C0 || a.C1 == 0;
+        const unsigned pls = first ? pl0 : pl1;
+        const unsigned cbase = (unsigned)(first ? c0 : c0 - a.C0) * pls;
+#pragma unroll
+        for (int k = 0; k < KPC; ++k) {
+          const unsigned off = (first ? v_o0[k] : v_o1[k]) + cbase;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            pre[cb][k].v[j] =
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
+        }
+      }
+      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+    };
+    auto commit = [&](int buf) {
+      u32x4* in_t = smem16 + buf * bufsz;
+      u32x4* w_t = in_t + CB8 * a.plane;
+#pragma unroll
+      for (int cb = 0; cb < CB8; ++cb)
+#pragma unroll
+        for (int k = 0; k < KPC; ++k)
+          if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = pack8(pre[cb][k].v);
+#pragma unroll
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+    };
+    load_chunk(0);
+    commit(0);
+    if (a.n_chunks > 1) load_chunk(1);
+    __syncthreads();  // stage 0 is ready
+    for (int ch = 0; ch < a.n_chunks; ++ch) {
+      if (ch + 1 < a.n_chunks) {
+        commit((ch + 1) & 1);
+        if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // --------------------------------------------------------------------------------------------- consumer
+  const int ox = p & (BW - 1), oy = p >> a.bwl;
+  const int wx = wave & (WX - 1), wy = wave >> a.wxl;
+  const int lx = wx * BW + ox;
+  int ly[NBW], boff[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    ly[nb] = (wy * NBW + nb) * RB + oy;
+    boff[nb] = half * a.plane + ly[nb] * a.row_pitch + lx;
+  }
+  f32x16 acc[MB][NBW];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  __syncthreads();  // stage 0 is ready
+  for (int ch = 0; ch < a.n_chunks; ++ch) {
+    const u32x4* in_t = smem16 + (ch & 1) * bufsz;
+    const u32x4* w_t = in_t + CB8 * a.plane;
+    // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (register double buffer, fully unrolled)
+    bf16x8 af[2][MB], bfr[2][NBW];
+    auto read_tap = [&](int tap, int slot) {
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const u32x4* wp = w_t + (tap * CB8 + half) * COT + p;
+      const u32x4* ip = in_t + ky * a.row_pitch + kx;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[slot][mb] = __builtin_bit_cast(bf16x8, wp[mb * 32]);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) bfr[slot][nb] = __builtin_bit_cast(bf16x8, ip[boff[nb]]);
+    };
+    read_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      if (tap + 1 < KS * KS) read_tap(tap + 1, (tap + 1) & 1);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][mb], bfr[tap & 1][nb], acc[mb][nb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
+}
+
+
+template <int MB, bool SRCBF>
+void launch_ws(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+#define ESS_WS(E_) { ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>, lds); hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>), grid, dim3(512), lds, st, a); }
+  switch (epi) {
+    case ESS_EPI_LSTM: ESS_WS(ESS_EPI_LSTM) break;
+    case ESS_EPI_GRU_UR: ESS_WS(ESS_EPI_GRU_UR) break;
+    case ESS_EPI_GRU_OUT: ESS_WS(ESS_EPI_GRU_OUT) break;
+    default: ESS_WS(ESS_EPI_LINEAR) break;
+  }
+#undef ESS_WS
+}
+template <bool SRCBF>
+void launch_ws_mb(int mb, int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if (mb == 4) launch_ws<4, SRCBF>(epi, grid, lds, st, a);
+  else if (mb == 2) launch_ws<2, SRCBF>(epi, grid, lds, st, a);
+  else launch_ws<1, SRCBF>(epi, grid, lds, st, a);
+}
+}  // namespace
+
+namespace essconv {
+
+void conv_bf16_launch_ws(int mb, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if (c8) launch_ws_mb<true>(mb, epi, grid, lds, st, a);
+  else launch_ws_mb<false>(mb, epi, grid, lds, st, a);
+}
+
+}  // namespace essconv

@@ -27,6 +27,8 @@ struct ConvKArgs {
   int act, hid, out_split;
   void* out_bf;   // optional BF16_C8 copy of `out`
   int fmt0, fmt1;  // ESS_FMT_* of the sources
+  int fmt_out;     // ESS_FMT_BF16_C8: `out` / `out2` ARE BF16_C8 tensors (LINEAR epilogue), nothing is written in fp32
+  int fmt_res;     // format of `residual`
 };
 
 
@@ -243,6 +245,114 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
   }
 }
 
+// LINEAR epilogue with BF16_C8 OUTPUT(S) (fmt_out): the stored form of the trainable networks' activations and activation
+// gradients in the bf16 configuration.  A lane owns 4 consecutive channels (4*half .. +3 of 8-channel block rowbase/8 + j) of
+// its pixel = one 8-byte store; the two half-waves complete the 16-byte pixel vector, 32 lanes = 512 contiguous bytes.
+// Options (all wave-uniform): per-channel scale / shift, a BF16_C8 residual (the skip gradient riding on a data-gradient),
+// ReLU, out_split (channels >= out_split go to out2: the data-gradient of a concat convolution; out_split % 8 == 0),
+// SUMPOOL2 (the first output leaves as the 2x2 pixel sum at half resolution: gradient of a nearest-x2-upsampled source).
+// Channels past C_out inside the last block are written as zeros (the BF16_C8 contract).
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
+                                                 int y0, const int (&ly)[NBW]) {
+  static_assert(NBW == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  constexpr int COT = MB * 32;
+  const size_t HW = (size_t)a.Hout * a.Wout;
+  const int c_out = a.Cout, split = a.out_split;
+  const int c_first = split > 0 ? split : c_out;
+  const int nb_first = (c_first + 7) >> 3, nb_all = nb_first + (split > 0 ? (c_out - split + 7) >> 3 : 0);
+  const bool pool = a.act == ESS_ACT_SUMPOOL2, relu = a.act == ESS_ACT_RELU;
+  const int Wl = a.Wout >> 1;
+  const size_t HWl = (size_t)(a.Hout >> 1) * Wl;
+  char* o1 = (char*)a.out + (size_t)n * nb_first * (pool ? HWl : HW) * 16;
+  char* o2 = (char*)a.out2 + (size_t)n * (nb_all - nb_first) * HW * 16;
+  const char* rs = (const char*)a.residual + (size_t)n * nb_all * HW * 16;
+  const int BW = 1 << a.bwl;
+  const bool rows1 = a.bwl == 5;
+  bool inb[NBW], own[NBW];
+  size_t pix[NBW], pixl[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int y = y0 + ly[nb];
+    inb[nb] = y < a.Hout && x < a.Wout;
+    pix[nb] = inb[nb] ? (size_t)y * a.Wout + x : 0;  // clamped: loads are unconditional, stores predicated
+    own[nb] = inb[nb] && !(x & 1) && !(y & 1) && (!rows1 || nb == 0);
+    pixl[nb] = (size_t)(y >> 1) * Wl + (x >> 1);
+  }
+  auto xor1 = [](float f) {  // lane^1 through DPP (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xf, 0xf, true));
+  };
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int blk = (rowbase >> 3) + j, c0 = blk * 8 + 4 * half;
+      const bool blk_ok = blk < nb_all;  // wave-uniform
+      float sc[4], sh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ci = c0 + i < c_out ? c0 + i : c_out - 1;
+        sc[i] = a.scale ? a.scale[ci] : 1.f;
+        sh[i] = a.shift ? a.shift[ci] : 0.f;
+      }
+      float v[NBW][4];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[nb][i] = acc[mb][nb][4 * j + i] * sc[i] + sh[i];
+        if (a.residual) {  // (uniform)
+          const uint2 rr = *(const uint2*)(rs + ((size_t)(blk_ok ? blk : 0) * HW + pix[nb]) * 16 + 8 * half);
+          const bf16x4 rb = __builtin_bit_cast(bf16x4, rr);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[nb][i] += (float)rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (relu) v[nb][i] = fmaxf(v[nb][i], 0.f);
+          if (c0 + i >= c_out) v[nb][i] = 0.f;
+        }
+      }
+      if (pool && blk < nb_first) {  // (uniform)
+        float t[NBW][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rows1) {
+            t[0][i] = v[0][i] + v[1][i];
+            t[0][i] += xor1(t[0][i]);
+            t[1][i] = 0.f;
+          } else {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+              t[nb][i] = v[nb][i] + __shfl_xor(v[nb][i], BW, 64);
+              t[nb][i] += xor1(t[nb][i]);
+            }
+          }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          if (own[nb]) {
+            bf16x4 b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = (__bf16)t[nb][i];
+            *(uint2*)(o1 + ((size_t)blk * HWl + pixl[nb]) * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
+          }
+      } else if (blk_ok) {
+        char* dst = blk < nb_first ? o1 + (size_t)blk * HW * 16 : o2 + (size_t)(blk - nb_first) * HW * 16;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          if (inb[nb]) {
+            bf16x4 b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
+            *(uint2*)(dst + pix[nb] * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
+          }
+      }
+    }
+  }
+}
+
 template <int MB, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                               int y0, const int (&ly)[NBW]) {
@@ -262,6 +372,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
     else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
+    if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB>(a, acc, ct, n, half, x, y0, ly); return; }
     const bool bare = a.act == ESS_ACT_NONE && !a.out_bf && a.out;
     if (a.act == ESS_ACT_SUMPOOL2) conv_epilogue_pool<MB>(a, acc, ct, n, half, x, y0, ly, plane_b);
     else if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
@@ -500,12 +611,22 @@ inline int validate(const EssConvDesc* d) {
   ESS_CHECK_ARG((d->fmt0 == ESS_FMT_F32_NCHW || d->fmt0 == ESS_FMT_BF16_C8) && (d->fmt1 == ESS_FMT_F32_NCHW || d->fmt1 == ESS_FMT_BF16_C8),
                 "conv: bad source format");
   if (d->fmt0 != ESS_FMT_F32_NCHW || d->fmt1 != ESS_FMT_F32_NCHW) {
-    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->mode0 == ESS_SRC_DIRECT && (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT) &&
-                      ((d->ksize == 3 && d->stride == 1 && d->pad == 1) || (d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR)),
-                  "conv: BF16_C8 sources need bf16 compute, DIRECT sources and a 3x3 stride-1 pad-1 or a 5x5 convolution");
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16, "conv: BF16_C8 sources need bf16 compute");
+    if (d->ksize == 5)
+      ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && d->mode0 == ESS_SRC_DIRECT && (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT),
+                    "conv: 5x5 BF16_C8 sources must be DIRECT (LINEAR epilogue)");
+    else
+      ESS_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "conv: BF16_C8 sources are staged by the 1x1, 3x3 and 5x5 kernels");
     ESS_CHECK_ARG(d->C1 == 0 || d->fmt0 == d->fmt1, "conv: both sources of a concat must use the same format");
     ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "conv: the first BF16_C8 source of a concat must have a multiple of 8 channels");
   }
+  ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_BF16_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),
+                "conv: bad output / residual format");
+  if (d->fmt_out == ESS_FMT_BF16_C8)
+    ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && (d->out_split % 8) == 0 &&
+                      (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU || d->act == ESS_ACT_SUMPOOL2),
+                  "conv: BF16_C8 outputs need the LINEAR epilogue, out_split %% 8 == 0 and act in {none, relu, sumpool2}");
+  ESS_CHECK_ARG(d->fmt_res == d->fmt_out || d->fmt_res == ESS_FMT_F32_NCHW, "conv: a BF16_C8 residual needs a BF16_C8 output");
   ESS_CHECK_ARG((int64_t)d->C_out * d->H_out * d->W_out * 4 < (int64_t)1 << 31,
                 "conv: one output sample must stay below 2 GiB (32-bit buffer offsets in the epilogue)");
   return ESS_OK;

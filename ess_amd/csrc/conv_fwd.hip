@@ -224,8 +224,8 @@ extern "C" int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const 
 }
 
 extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
-                                  const float* scale, const float* shift, const float* residual, const float* aux0,
-                                  const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream) {
+                                  const float* scale, const float* shift, const void* residual, const float* aux0,
+                                  const float* aux1, void* out, void* out2, void* out_bf16, ess_stream_t stream) {
   int rc = validate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
@@ -241,14 +241,19 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
                   "conv: the BF16_C8 output copy exists for bf16 compute, LINEAR / LSTM / GRU_OUT epilogues, no out_split");
   if (d->act == ESS_ACT_SUMPOOL2)
     ESS_CHECK_ARG(out && !scale && !residual && !out_bf16, "conv: SUMPOOL2 takes no scale / residual / BF16_C8 copy");
+  if (d->fmt_out == ESS_FMT_BF16_C8) {
+    ESS_CHECK_ARG(out && !out_bf16, "conv: a BF16_C8 output goes to `out` (no separate copy)");
+    ESS_CHECK_ARG(((((uintptr_t)out) | ((uintptr_t)out2) | ((uintptr_t)residual)) & 15) == 0, "conv: BF16_C8 tensors must be 16-byte aligned");
+  }
+  ESS_CHECK_ARG(!residual || d->fmt_res == d->fmt_out, "conv: the residual must come in the output's format");
   EssConvPlan pl;
   make_plan(d, &pl);
   ESS_CHECK_ARG(pl.lds_bytes <= 160 * 1024, "conv: LDS tile %d B exceeds 160 KiB", pl.lds_bytes);
   const Geom g = choose_geom(d);
   ConvKArgs a{};
   a.src0 = (const float*)src0; a.src1 = (const float*)src1; a.wpk = packed_w;
-  a.out_bf = out_bf16; a.fmt0 = d->fmt0; a.fmt1 = d->C1 ? d->fmt1 : d->fmt0; a.scale = scale; a.shift = shift; a.residual = residual;
-  a.aux0 = aux0; a.aux1 = aux1; a.out = out; a.out2 = out2;
+  a.out_bf = out_bf16; a.fmt0 = d->fmt0; a.fmt1 = d->C1 ? d->fmt1 : d->fmt0; a.scale = scale; a.shift = shift; a.residual = (const float*)residual;
+  a.aux0 = aux0; a.aux1 = aux1; a.out = (float*)out; a.out2 = (float*)out2; a.fmt_out = d->fmt_out; a.fmt_res = d->fmt_res;
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;

@@ -48,7 +48,7 @@ EXPORTS = [
 class EssConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         'N', 'H_in', 'W_in', 'C0', 'C1', 'mode0', 'mode1', 'C_out', 'H_out', 'W_out', 'ksize', 'stride', 'pad',
-        'epilogue', 'act', 'hidden', 'out_split', 'compute', 'fmt0', 'fmt1')]
+        'epilogue', 'act', 'hidden', 'out_split', 'compute', 'fmt0', 'fmt1', 'fmt_out', 'fmt_res')]
 
 
 class EssConvPlan(Structure):
@@ -154,21 +154,29 @@ class ConvSpec:
         H_out = (H_in + 2 * p - k) // s + 1
         W_out = (W_in + 2 * p - k) // s + 1
         self.desc = EssConvDesc(N, H_in, W_in, C0, C1, mode0, mode1, C_out, H_out, W_out, k, s, p, epi, act, hidden,
-                                out_split, compute, FMT_F32_NCHW, FMT_F32_NCHW)
-        self._desc_c8 = None
+                                out_split, compute, FMT_F32_NCHW, FMT_F32_NCHW, FMT_F32_NCHW, FMT_F32_NCHW)
+        self._desc_fmt = {}
         self.plan = EssConvPlan()
         _check(lib().ess_conv2d_plan(byref(self.desc), byref(self.plan)), 'ess_conv2d_plan')
         self.key = key
         self.H_out, self.W_out = H_out, W_out
         self.wgrad_ws = None
 
-    def desc_c8(self):
-        """The same convolution reading BF16_C8 sources (same plan, same packed weights)."""
-        if self._desc_c8 is None:
+    def desc_fmt(self, src_fmt=FMT_F32_NCHW, out_fmt=FMT_F32_NCHW, res_fmt=FMT_F32_NCHW):
+        """The same convolution (same plan, same packed weights) with the given storage formats of the sources, of the
+        output(s) and of the residual."""
+        key = (src_fmt, out_fmt, res_fmt)
+        d = self._desc_fmt.get(key)
+        if d is None:
             d = EssConvDesc.from_buffer_copy(self.desc)
-            d.fmt0 = d.fmt1 = FMT_BF16_C8
-            self._desc_c8 = d
-        return self._desc_c8
+            d.fmt0 = d.fmt1 = src_fmt
+            d.fmt_out, d.fmt_res = out_fmt, res_fmt
+            self._desc_fmt[key] = d
+        return d
+
+    def desc_c8(self):
+        """The same convolution reading BF16_C8 sources."""
+        return self.desc_fmt(FMT_BF16_C8)
 
 
 def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC_DIRECT, epi=EPI_LINEAR, act=ACT_NONE,
@@ -216,23 +224,26 @@ def pack_rows(spec, v, v2=None, fill=0.0):
 
 
 def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None,
-                 out2=None, out_bf=None, src_fmt=FMT_F32_NCHW):
-    """src_fmt FMT_BF16_C8: src0/src1 are bf16 [N][C/8][H][W][8] staging copies (see bf16_c8_empty);
-    out_bf: receives `out` in that format for the next convolution."""
-    c8 = src_fmt == FMT_BF16_C8
-    sdt = torch.bfloat16 if c8 else torch.float32
-    _check(lib().ess_conv2d_forward(byref(spec.desc_c8() if c8 else spec.desc), ptr(src0, sdt), ptr(src1, sdt),
-                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual), ptr(aux0), ptr(aux1),
-                                    ptr(out), ptr(out2), ptr(out_bf, torch.bfloat16), stream()),
+                 out2=None, out_bf=None, src_fmt=FMT_F32_NCHW, out_fmt=FMT_F32_NCHW):
+    """src_fmt FMT_BF16_C8: src0/src1 are bf16 [N][C/8][H][W][8] tensors (see bf16_c8_empty);
+    out_bf: additionally receives `out` in that format (the frozen encoder's staging copies);
+    out_fmt FMT_BF16_C8: `out` / `out2` (and `residual`, if any) ARE BF16_C8 tensors, no fp32 tensor is written."""
+    sdt = torch.bfloat16 if src_fmt == FMT_BF16_C8 else torch.float32
+    odt = torch.bfloat16 if out_fmt == FMT_BF16_C8 else torch.float32
+    res_fmt = out_fmt if residual is not None else FMT_F32_NCHW
+    desc = spec.desc if (src_fmt, out_fmt, res_fmt) == (FMT_F32_NCHW,) * 3 else spec.desc_fmt(src_fmt, out_fmt, res_fmt)
+    _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt),
+                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, odt), ptr(aux0), ptr(aux1),
+                                    ptr(out, odt), ptr(out2, odt), ptr(out_bf, torch.bfloat16), stream()),
            'ess_conv2d_forward')
     return out
 
 
 def c8_stageable(ksize, stride, pad):
-    """Can a bf16 convolution of this geometry stage BF16_C8 sources?  Only the wave-specialised 3x3 and the tap-paired 5x5
-    kernels do; both can be switched off for diagnostics (ESS_CONV_WS=0 / ESS_CONV_PAIR=0, read by the library as well)."""
-    if ksize == 3:
-        return stride == 1 and pad == 1 and os.environ.get('ESS_CONV_WS', '1')[:1] != '0'
+    """Can a bf16 convolution of this geometry stage BF16_C8 sources?  1x1 and 3x3 always (wave-specialised or generic tile
+    kernel); 5x5 on the tap-paired kernel only, which can be switched off for diagnostics (ESS_CONV_PAIR=0)."""
+    if ksize in (1, 3):
+        return True
     if ksize == 5:
         return os.environ.get('ESS_CONV_PAIR', '1')[:1] != '0'
     return False

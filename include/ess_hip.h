@@ -79,8 +79,13 @@ typedef struct EssConvDesc {
   int32_t out_split;    /* LINEAR: >0 writes channels [0,out_split) to `out` and the rest to `out2`
                            (data-gradient of a two-source conv)                                      */
   int32_t compute;      /* ESS_COMPUTE_*                                                             */
-  int32_t fmt0, fmt1;   /* ESS_FMT_* of source 0 / 1.  BF16_C8 needs: bf16 compute, 3x3, stride 1, DIRECT
-                           sources, and the same format for both sources of a concat                     */
+  int32_t fmt0, fmt1;   /* ESS_FMT_* of source 0 / 1.  BF16_C8 needs bf16 compute, a 1x1 / 3x3 (any source mode) or a
+                           5x5 (DIRECT sources) filter, and the same format for both sources of a concat        */
+  int32_t fmt_out;      /* ESS_FMT_BF16_C8 (LINEAR epilogue, bf16 compute): `out` -- and `out2` of an out_split --
+                           ARE BF16_C8 tensors and no fp32 tensor is written: the stored form of the trainable
+                           networks' activations and activation gradients in the bf16 configuration.  With
+                           ESS_ACT_SUMPOOL2 the first output is the pooled BF16_C8 tensor.  out_split % 8 == 0.       */
+  int32_t fmt_res;      /* format of `residual` (BF16_C8 only together with a BF16_C8 output)                         */
 } EssConvDesc;
 
 typedef struct EssConvPlan {
@@ -119,8 +124,9 @@ int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, 
  * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev ; aux1: GRU_OUT u.
  * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h | LINEAR split.  */
 int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
-                       const float* scale, const float* shift, const float* residual, const float* aux0,
-                       const float* aux1, float* out, float* out2, void* out_bf16, ess_stream_t stream);
+                       const float* scale, const float* shift, const void* residual, const float* aux0,
+                       const float* aux1, void* out, void* out2, void* out_bf16, ess_stream_t stream);
+/* out / out2 / residual: fp32 NCHW, or BF16_C8 tensors when d->fmt_out (d->fmt_res) says so.                    */
 /* src0/src1: fp32 NCHW or bf16 C8 per d->fmt0/fmt1.  out_bf16 (nullable): additionally receives `out` (LINEAR y,
  * LSTM h', GRU_OUT h') as a BF16_C8 tensor [N][ceil(C/8)][H_out][W_out][8] for the next convolution to stage from
  * (bf16 compute only; not with out_split).  With out_bf16 given, `out` may be NULL for the LINEAR and LSTM epilogues:
