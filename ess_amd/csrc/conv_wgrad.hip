@@ -7,22 +7,10 @@
 // blocks per wave.  The pixel range is split over blockIdx.y; partial slabs go to the workspace and a
 // second kernel reduces them in a fixed order (deterministic, no float atomics).
 // The 7x7 / C_in = 1 stem of the image encoder uses the "taps as N" variant instead.
-#include "common.h"
+#include "conv_wgrad_common.h"
 
 namespace {
 
-struct WgradArgs {
-  const float* src0;
-  const float* src1;
-  const float* dy;
-  float* ws;      // [nsplit][taps][Cout][Cin]
-  float* ws_b;    // [nsplit][Cout] or null
-  int N, Hin, Win, C0, C1, mode0, mode1, Cout, Hout, Wout, pad;
-  int twl;        // pixel tile = (64>>twl) rows x (1<<twl) cols
-  int tiles_x, tiles_y, ntiles;
-  int IH, IW, plx;  // X tile rows/cols, per-channel pitch (odd)
-  int ci_tiles, npairs, nsplit;
-};
 
 // Value of the (virtually upsampled, concatenated) conv input at channel c (< C0+C1), position (gy, gx).  Branch-free in
 // the per-lane quantities: the load is unconditional from a clamped address and the result selected afterwards (a load
@@ -207,6 +195,23 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
     {
       const int qx = tid & (TWp - 1);
       const int rows_per_it = 256 >> a.twl;
+      if (a.dy_c8) {  // BF16_C8 dY: 8 blocks x 64 pixel vectors of this channel tile, two per thread
+        const int nbo = (a.Cout + 7) >> 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int v = tid + i * 256;
+          const int vx = v & (TWp - 1), vy = (v >> a.twl) % THp, cbk = v / 64;
+          const int blk = cot * 8 + cbk, y = y0 + vy, x = x0 + vx;
+          const bool ok = blk < nbo && y < a.Hout && x < a.Wout;
+          const u32x4w q = ((const u32x4w*)a.dy)[((size_t)n * nbo + min(blk, nbo - 1)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout + min(x, a.Wout - 1)];
+          const unsigned m = ok ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dy_t[(cbk * 8 + 2 * e) * PY + vy * TWp + vx] = __builtin_bit_cast(float, (q[e] << 16) & m);
+            dy_t[(cbk * 8 + 2 * e + 1) * PY + vy * TWp + vx] = __builtin_bit_cast(float, q[e] & 0xffff0000u & m);
+          }
+        }
+      } else
       for (int r = tid >> a.twl; r < 64 * THp; r += rows_per_it) {
         const int co = r / THp, qy = r - co * THp;
         const int cg = cot * 64 + co, y = y0 + qy, x = x0 + qx;
@@ -247,10 +252,6 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(const WgradArgs a) {
 // left / right) are produced from two neighbouring vectors with v_alignbyte (4 VALU per fragment) instead of keeping
 // three shifted copies in LDS.  Per-channel pitches are odd multiples of 16 B: lanes run over channels, so the
 // ds_read_b128 groups hit 16 distinct slots.
-constexpr unsigned OOBW = 0x80000000u;  // beyond any buffer: bounds-checked loads return 0
-typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
-
 // 16-byte bounds-checked buffer loads.  hipcc (ROCm 7.2) mis-lowers __builtin_amdgcn_raw_buffer_load_b64/_b128 to a
 // single buffer_load_dword, so the wide form is inline asm.  A whole batch is ONE statement -- loads and their
 // s_waitcnt together, early-clobber outputs (cdna_hip_programming.md 5.7 form i) -- so the compiler never sees a
@@ -286,35 +287,6 @@ __device__ __forceinline__ void ldb128x12(u32x4w (&d)[12], __amdgpu_buffer_rsrc_
         "v"(o[10]), "v"(o[11]), "s"(ra), "s"(rb)
       : "memory");
 }
-__device__ __forceinline__ u32x4w cvt8(const float (&v)[8]) {
-  bf16x8w b;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
-  return __builtin_bit_cast(u32x4w, b);
-}
-// bytes [off, off+16) of the 32-byte concatenation lo|hi
-__device__ __forceinline__ u32x4w shift_left1(u32x4w lo, u32x4w hi) {  // window starting 14 bytes into lo (one pixel earlier than hi)
-  u32x4w r;
-  r[0] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
-  r[1] = __builtin_amdgcn_alignbyte(hi[1], hi[0], 2);
-  r[2] = __builtin_amdgcn_alignbyte(hi[2], hi[1], 2);
-  r[3] = __builtin_amdgcn_alignbyte(hi[3], hi[2], 2);
-  return r;
-}
-__device__ __forceinline__ u32x4w shift_right1(u32x4w lo, u32x4w hi) {  // window starting 2 bytes into lo (one pixel later)
-  u32x4w r;
-  r[0] = __builtin_amdgcn_alignbyte(lo[1], lo[0], 2);
-  r[1] = __builtin_amdgcn_alignbyte(lo[2], lo[1], 2);
-  r[2] = __builtin_amdgcn_alignbyte(lo[3], lo[2], 2);
-  r[3] = __builtin_amdgcn_alignbyte(hi[0], lo[3], 2);
-  return r;
-}
-
-struct WgradBArgs {
-  WgradArgs w;
-  int thl;     // pixel tile = (128 >> twl) rows x (1 << twl) cols, twl in {4,5}
-  int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
-};
 
 __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b) {
   extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
@@ -859,7 +831,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, 
 
 struct WPlan {
   int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
-  bool taps_variant, bf16, bf16_1x1, small1x1, small1x1_mfma;
+  bool taps_variant, bf16, bf16_1x1, small1x1, small1x1_mfma, c8, small1x1_c8;
   int pyv, pxv, rv;
   size_t slab_floats;
 };
@@ -871,6 +843,21 @@ int wvalidate(const EssConvDesc* d) {
   const bool taps = cin == 1 && d->ksize == 7;
   ESS_CHECK_ARG(taps || d->ksize == 1 || d->ksize == 3, "wgrad: k=%d with C_in=%d unsupported", d->ksize, cin);
   ESS_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride %d unsupported", d->stride);
+  // storage formats: fmt0 (= fmt1) is X's, fmt_out is dY's
+  const bool xc8 = d->fmt0 == ESS_FMT_BF16_C8, dc8 = d->fmt_out == ESS_FMT_BF16_C8;
+  if (xc8 || dc8) {
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16, "wgrad: BF16_C8 tensors need bf16 compute");
+    ESS_CHECK_ARG(d->C1 == 0 || d->fmt1 == d->fmt0, "wgrad: both sources of a concat must use the same format");
+    ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "wgrad: the first BF16_C8 source of a concat must have a multiple of 8 channels");
+    if (xc8 && dc8)
+      ESS_CHECK_ARG((d->ksize == 3 && d->stride == 1 && d->pad == 1) || (d->ksize == 1 && d->pad == 0 && d->mode0 == ESS_SRC_DIRECT && d->C1 == 0),
+                    "wgrad(BF16_C8): 3x3 / stride 1 / pad 1 and 1x1 / pad 0 convolutions only");
+    else if (xc8)
+      ESS_CHECK_ARG(d->ksize == 1 && d->stride == 1 && d->pad == 0 && d->C1 == 0 && d->mode0 == ESS_SRC_DIRECT && d->C_out <= 32 && cin <= 32,
+                    "wgrad(BF16_C8 X, fp32 dY): the 1x1 head only (C_in, C_out <= 32)");
+    else
+      ESS_CHECK_ARG(taps, "wgrad(fp32 X, BF16_C8 dY): the 7x7 single-channel stem only");
+  }
   return ESS_OK;
 }
 
@@ -885,6 +872,10 @@ WPlan wplan(const EssConvDesc* d) {
   w.bf16_1x1 = d->compute == ESS_COMPUTE_BF16 && KS == 1 && S == 1 && d->pad == 0 && !w.small1x1 && (d->W_in % 8) == 0 &&
                (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
   w.bf16 = w.bf16 || w.bf16_1x1;
+  w.c8 = d->fmt0 == ESS_FMT_BF16_C8 && d->fmt_out == ESS_FMT_BF16_C8;  // both operands BF16_C8: conv_wgrad_c8.hip
+  w.small1x1_c8 = d->fmt0 == ESS_FMT_BF16_C8 && d->fmt_out != ESS_FMT_BF16_C8;
+  if (w.c8) { w.bf16 = true; w.bf16_1x1 = KS == 1; w.small1x1 = false; }
+  if (w.small1x1_c8) { w.bf16 = w.bf16_1x1 = false; w.small1x1 = true; }
   const int npx = w.bf16 ? 128 : 64;
   // pixel tile of 64 (fp32) / 128 (bf16): pick the width that wastes the least
   double best = 1e300;
@@ -913,6 +904,10 @@ WPlan wplan(const EssConvDesc* d) {
     const int chunks = d->N * ceil_div(d->H_out * d->W_out, 128);
     w.nsplit = chunks < 1024 ? chunks : 1024;
     w.small1x1_mfma = cin <= 32 && ((d->H_out * d->W_out) % 64) == 0;
+    if (w.small1x1_c8) {
+      w.small1x1_mfma = false;
+      if (w.nsplit > 512) w.nsplit = 512;
+    }
     if (w.small1x1_mfma) {  // one slab per workgroup of 4 waves, two workgroups per CU
       const int groups = d->N * (d->H_out * d->W_out / 64);
       w.nsplit = groups < 4 * 512 ? ceil_div(groups, 4) : 512;
@@ -948,8 +943,9 @@ extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   return (size_t)w.nsplit * w.slab_floats * 4;
 }
 
-extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1, const float* dy, float* dw,
+extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const void* src1_, const void* dy_, float* dw,
                                 float* db, int accumulate, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
+  const float* src0 = (const float*)src0_; const float* src1 = (const float*)src1_; const float* dy = (const float*)dy_;
   int rc = wvalidate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && dy && dw && workspace, "wgrad: null pointer");
@@ -973,7 +969,17 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const f
     if ((rc = raise_lds(wgrad_f32_kernel<KS_, S_>, w.lds_bytes))) return rc;                         \
     hipLaunchKernelGGL((wgrad_f32_kernel<KS_, S_>), grid, dim3(256), w.lds_bytes, st, a);             \
   } while (0)
-  if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {
+  a.dy_c8 = d->fmt_out == ESS_FMT_BF16_C8;
+  if (d->fmt0 == ESS_FMT_BF16_C8 || a.dy_c8)
+    ESS_CHECK_ARG(((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)dy)) & 15) == 0, "wgrad: BF16_C8 tensors must be 16-byte aligned");
+  if (w.small1x1_c8) {
+    if ((rc = wgrad_small1x1_c8_launch(a, w.nsplit, st))) return rc;
+  } else if (w.c8) {
+    WgradBArgs bb{};
+    bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
+    if (w.bf16_1x1) bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile
+    if ((rc = wgrad_c8_launch(bb, w.bf16_1x1 ? 1 : 9, d->stride, 2 * w.lds_bytes, grid, st))) return rc;
+  } else if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {
     const int per_img = d->H_out * d->W_out / 64;
     hipLaunchKernelGGL(wgrad_small1x1_mfma_kernel, dim3(w.nsplit), dim3(256), 0, st, a, per_img, d->N * per_img);
   } else if (w.small1x1) {

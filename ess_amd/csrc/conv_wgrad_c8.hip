@@ -1,0 +1,299 @@
+// Weight gradients from BF16_C8 tensors (the stored form of the trainable networks' activations X and output gradients dY in
+// the bf16 configuration: bfloat16 [N][C/8][H][W][8]).
+//
+// GEMM view as in conv_wgrad.hip:  dW[tap][co][ci] = sum_px dY[co][px] * X[ci][px (+) tap], contraction over PIXELS on
+// v_mfma_f32_32x32x16_bf16 -- both operands want 8 consecutive pixels of ONE channel per lane, while BF16_C8 keeps the 8
+// channels of one pixel together.  The transposition happens in registers while a tile is staged: a thread loads a "quad" =
+// 4 consecutive pixel vectors of one 8-channel block (64 contiguous bytes), regroups the 16-bit elements with 16 v_perm_b32
+// into 8 half-vectors (4 pixels of one channel each) and writes them to the channel-major LDS tile the MFMA loop reads
+// (ds_write_b64).  No conversion (the tensors already hold the bf16 operands), no alignment constraints (every pixel is its own
+// 16-byte vector: any width / height works, masks are per pixel), half the bytes and half the staging registers of the
+// fp32-NCHW kernel.  The MFMA loop, the LDS tile layout, the split-K slabs and the reduce kernel are those of
+// wgrad_bf16_k3s1_fast_kernel.
+//   TAPS = 9: 3x3 / stride 1 / pad 1 (sources direct or nearest-x2-upsampled, one or two concat sources);
+//   TAPS = 1: 1x1 convolutions as the centre tap of the same tile geometry, input stride SX = 1 or 2 (ResNet downsample).
+#include "conv_wgrad_common.h"
+
+namespace {
+
+struct Quad { u32x4w v[4]; };
+
+// 4 pixel vectors (8 channels each) -> for channel 2d / 2d+1: the 4 pixels as two dwords
+__device__ __forceinline__ void quad_transpose(const Quad& q, uint2 (&out)[8]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    out[2 * d].x = __builtin_amdgcn_perm(q.v[1][d], q.v[0][d], 0x05040100u);
+    out[2 * d].y = __builtin_amdgcn_perm(q.v[3][d], q.v[2][d], 0x05040100u);
+    out[2 * d + 1].x = __builtin_amdgcn_perm(q.v[1][d], q.v[0][d], 0x07060302u);
+    out[2 * d + 1].y = __builtin_amdgcn_perm(q.v[3][d], q.v[2][d], 0x07060302u);
+  }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int sx) {
+  extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
+  const WgradArgs& a = b.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
+  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
+  const int cb = wave >> 1, ib = wave & 1;
+  const int TWp = 1 << a.twl, THp = 128 >> a.twl;
+  const int TV = TWp >> 3;
+  const int IH = THp + 2;
+  const int Cin = a.C0 + a.C1;
+  u32x4w* dy_t = smemv;
+  u32x4w* x_t = smemv + 64 * b.pyv;
+  const int stage = 64 * (b.pyv + b.pxv);  // 16-byte vectors per LDS stage
+  constexpr int XQ = 3;                    // X quads per thread: 8 blocks x IH x 2*rv quads = 576 (twl 5) / 640 (twl 4) <= 768
+  const int QW = TWp >> 2;                 // dY quads per tile row
+  const int XW = 2 * b.rv;                 // X quads per tile row
+  const int nxq = 8 * IH * XW;
+  const size_t HWo = (size_t)a.Hout * a.Wout;
+  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+  const int nbo = (a.Cout + 7) >> 3, nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
+
+  // ---- tile-independent staging plan
+  // dY: quad = (block cbk of this 64-channel tile, tile row qy, quad column xq): one per thread
+  const int d_xq = tid % QW, d_r = tid / QW;
+  const int d_qy = d_r % THp, d_cbk = d_r / THp;
+  const int d_blk = cot * 8 + d_cbk;
+  const bool d_ok = d_blk < nbo;
+  const int d_lds2 = 2 * ((d_cbk * 8) * b.pyv + d_qy * TV + (d_xq >> 1)) + (d_xq & 1);  // 8-byte units, channel j adds 2 * pyv * j
+  int x_lds2[XQ], x_iy[XQ], x_xq[XQ], x_sh[XQ], x_w[XQ], x_zero[XQ];
+  const u32x4w* x_base[XQ];
+  size_t x_ns[XQ];
+  bool x_ok[XQ];
+#pragma unroll
+  for (int i = 0; i < XQ; ++i) {
+    const int q = tid + i * 256;
+    const int xq = q % XW, r = q / XW;
+    const int iy = r % IH, cbk = r / IH;
+    const int c0 = (cit * 8 + cbk) * 8;            // first channel of the block in the concatenated input
+    const bool first = c0 < a.C0 || a.C1 == 0;
+    const int bi = (first ? c0 : c0 - a.C0) >> 3, nbs = first ? nb0 : nb1;
+    const int sh = first ? sh0 : sh1;
+    const int Hp = a.Hin >> sh, Wp = a.Win >> sh;
+    x_ok[i] = q < nxq && c0 < Cin && bi < nbs;
+    x_base[i] = (const u32x4w*)(first ? a.src0 : a.src1) + (size_t)(bi < nbs ? bi : 0) * Hp * Wp;
+    x_ns[i] = (size_t)nbs * Hp * Wp;
+    x_w[i] = Wp; x_sh[i] = sh; x_iy[i] = iy; x_xq[i] = xq;
+    x_zero[i] = (first ? a.mode0 : a.mode1) == ESS_SRC_ZERO_UP2;
+    x_lds2[i] = q < nxq ? 2 * ((cbk * 8) * b.pxv + iy * b.rv + (xq >> 1)) + (xq & 1) : -1;
+  }
+
+  Quad dq, xq_[XQ];
+  unsigned dmask, xmask[XQ];  // bit i: pixel i of the quad is real data
+  auto issue = [&](int tile) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * THp, x0 = tx * TWp;
+    {
+      const int y = y0 + d_qy, x = x0 + 4 * d_xq;
+      const u32x4w* src = (const u32x4w*)a.dy + ((size_t)n * nbo + (d_ok ? d_blk : 0)) * HWo + (size_t)min(y, a.Hout - 1) * a.Wout;
+      dmask = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (d_ok && y < a.Hout && x + i < a.Wout) dmask |= 1u << i;
+        dq.v[i] = src[min(x + i, a.Wout - 1)];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) {
+      const int gy = (y0 - a.pad + x_iy[k]) * sx;
+      const int cy = min(max(gy, 0), a.Hin - 1) >> x_sh[k];
+      const u32x4w* src = x_base[k] + (size_t)n * x_ns[k] + (size_t)cy * x_w[k];
+      const bool rok = x_ok[k] && gy >= 0 && gy < a.Hin && !(x_zero[k] && (gy & 1));
+      xmask[k] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gx = (x0 - 8 + 4 * x_xq[k] + i) * sx;
+        if (rok && gx >= 0 && gx < a.Win && !(x_zero[k] && (gx & 1))) xmask[k] |= 1u << i;
+        xq_[k].v[i] = src[min(max(gx, 0), a.Win - 1) >> x_sh[k]];
+      }
+    }
+  };
+  auto commit = [&](const Quad& qin, unsigned mask, uint2* base2, int lds2, int pitch2) {
+    Quad q = qin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned m = (mask >> i) & 1u ? 0xffffffffu : 0u;
+      q.v[i][0] &= m; q.v[i][1] &= m; q.v[i][2] &= m; q.v[i][3] &= m;
+    }
+    uint2 o[8];
+    quad_transpose(q, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) base2[lds2 + j * pitch2] = o[j];
+  };
+  auto commit_d = [&](int st) { commit(dq, dmask, (uint2*)(dy_t + st * stage), d_lds2, 2 * b.pyv); };
+  auto commit_x = [&](int k, int st) {
+    if (x_lds2[k] >= 0) commit(xq_[k], xmask[k], (uint2*)(x_t + st * stage), x_lds2[k], 2 * b.pxv);
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  // K loop over this workgroup's pixel tiles: 8 k-steps of 16 pixels x TAPS taps per tile, two LDS stages; the quads of tile
+  // t+1 (loads issued behind the first k-step) are transposed and written into the other stage on k-steps 4-7
+  const int ksh = a.twl - 4, kmask = (1 << ksh) - 1;
+  struct Frag { u32x4w a; u32x4w v[3][3]; };
+  if (split < a.ntiles) {
+    issue(split);
+    commit_d(0);
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) commit_x(k, 0);
+  }
+  __syncthreads();
+  int st = 0;
+  for (int tile = split; tile < a.ntiles; tile += nsplit, st ^= 1) {
+    const bool more = tile + nsplit < a.ntiles;
+    const u32x4w* ap = dy_t + st * stage + (cb * 32 + p) * b.pyv + half;
+    const u32x4w* xp = x_t + st * stage + (ib * 32 + p) * b.pxv + half;
+    auto read_frag = [&](int ks, Frag& f) {
+      f.a = ap[2 * ks];
+      const u32x4w* row = xp + (ks >> ksh) * b.rv + ((ks & kmask) << 1);
+      if constexpr (TAPS == 1) {
+        f.v[1][1] = row[b.rv + 1];
+      } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          f.v[ky][0] = row[ky * b.rv]; f.v[ky][1] = row[ky * b.rv + 1]; f.v[ky][2] = row[ky * b.rv + 2];
+        }
+      }
+    };
+    auto mma = [&](const Frag& f) {
+      const bf16x8w af = __builtin_bit_cast(bf16x8w, f.a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+      if constexpr (TAPS == 1) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[1][1]), acc[0], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_left1(f.v[ky][0], f.v[ky][1])),
+                                                                    acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[ky][1]), acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, shift_right1(f.v[ky][1], f.v[ky][2])),
+                                                                    acc[ky * 3 + 2], 0, 0, 0);
+        }
+      }
+    };
+    Frag fr[2];
+    read_frag(0, fr[0]);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) read_frag(ks + 1, fr[(ks + 1) & 1]);
+      mma(fr[ks & 1]);
+      if (ks == 0 && more) issue(tile + nsplit);
+      if (more) {  // wave-uniform
+        if (ks == 4) commit_d(st ^ 1);
+        if (ks == 5) commit_x(0, st ^ 1);
+        if (ks == 6) commit_x(1, st ^ 1);
+        if (ks == 7) commit_x(2, st ^ 1);
+      }
+    }
+    __syncthreads();
+  }
+  const int ci = cit * 64 + ib * 32 + p;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * TAPS + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+    }
+  if (a.ws_b && cit == 0 && ib == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int co = cot * 64 + cb * 32 + p;
+    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
+  }
+}
+
+// ---- the K-class 1x1 head (32 -> K at full resolution): X is BF16_C8 (C_in <= 32), dY fp32 NCHW (the loss kernels' logit
+// gradients, C_out <= 32).  HBM-bound.  A workgroup walks chunks of 128 pixels: X and dY are staged to LDS as fp32
+// [channel][pixel] rows, each wave contracts its 32 pixels of the chunk on the exact-fp32 matrix core
+// (v_mfma_f32_32x32x2_f32, one 32x32 (co, ci) tile), the four waves are combined at the end; one slab per workgroup.
+__global__ __launch_bounds__(256) void wgrad_small1x1_c8_kernel(const WgradArgs a, int chunks_per_img, int total_chunks) {
+  constexpr int P = 128, PP = P + 1;
+  __shared__ float dy_s[32 * PP];
+  __shared__ float x_s[32 * PP];
+  float* red = dy_s;  // reused after the loop: [4][16 * 64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int Cin = a.C0, Cout = a.Cout, nbi = (Cin + 7) >> 3;
+  const size_t HW = (size_t)a.Hout * a.Wout;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int i = tid; i < 32 * PP; i += 256) { dy_s[i] = 0.f; x_s[i] = 0.f; }  // rows of absent channels stay zero
+  for (int chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    const int n = chunk / chunks_per_img;
+    const size_t px0 = (size_t)(chunk - n * chunks_per_img) * P;
+    __syncthreads();
+    // X: nbi blocks x 128 pixel vectors
+    for (int i = tid; i < nbi * P; i += 256) {
+      const int blk = i / P, j = i - blk * P;
+      const size_t px = px0 + j;
+      const u32x4w v = ((const u32x4w*)a.src0)[((size_t)n * nbi + blk) * HW + (px < HW ? px : HW - 1)];
+      const unsigned m = px < HW ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        x_s[(blk * 8 + 2 * q) * PP + j] = __builtin_bit_cast(float, (v[q] << 16) & m);
+        x_s[(blk * 8 + 2 * q + 1) * PP + j] = __builtin_bit_cast(float, v[q] & 0xffff0000u & m);
+      }
+    }
+    for (int i = tid; i < Cout * P; i += 256) {
+      const int r = i / P, j = i - r * P;
+      const size_t px = px0 + j;
+      const float t = a.dy[((size_t)n * Cout + r) * HW + (px < HW ? px : HW - 1)];
+      dy_s[r * PP + j] = px < HW ? t : 0.f;
+    }
+    __syncthreads();
+    const float* dp = dy_s + p * PP + wave * 32 + half;
+    const float* xp = x_s + p * PP + wave * 32 + half;
+#pragma unroll 8
+    for (int kk = 0; kk < 16; ++kk) {
+      const float d1 = dp[2 * kk], x1 = xp[2 * kk];
+      bsum += d1;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, x1, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* redb = x_s;  // [4][32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (half == 0) redb[wave * 32 + p] = bsum;
+  __syncthreads();
+  for (int i = tid; i < 16 * 64; i += 256) {
+    const int r = i >> 6, l = i & 63;
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31;
+    if (co < Cout && ci < Cin)
+      a.ws[(size_t)blockIdx.x * Cout * Cin + co * Cin + ci] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+  }
+  if (a.ws_b && tid < Cout) a.ws_b[(size_t)blockIdx.x * Cout + tid] = (redb[tid] + redb[32 + tid]) + (redb[64 + tid] + redb[96 + tid]);
+}
+
+}  // namespace
+
+int wgrad_c8_launch(const WgradBArgs& b, int taps, int sx, int lds_bytes, dim3 grid, hipStream_t st) {
+  if (taps == 1) {
+    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_c8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(wgrad_c8_kernel<1>, grid, dim3(256), lds_bytes, st, b, sx);
+  } else {
+    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_c8_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(wgrad_c8_kernel<9>, grid, dim3(256), lds_bytes, st, b, sx);
+  }
+  return ess_launch_status("conv2d_wgrad(BF16_C8)");
+}
+
+int wgrad_small1x1_c8_launch(const WgradArgs& a, int nsplit, hipStream_t st) {
+  const int per_img = ceil_div(a.Hout * a.Wout, 128);
+  hipLaunchKernelGGL(wgrad_small1x1_c8_kernel, dim3(nsplit), dim3(256), 0, st, a, per_img, a.N * per_img);
+  return ess_launch_status("conv2d_wgrad(1x1 head, BF16_C8)");
+}

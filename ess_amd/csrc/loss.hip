@@ -232,6 +232,35 @@ __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a,
   if (threadIdx.x == 0) atomicAdd(ws, acc);
 }
 
+// L1 over BF16_C8 tensors (the latent / intermediate-prediction cycle losses of the bf16 configuration): 8 elements per 16-byte
+// vector, fp32 differences, the gradient sign(a - b) * scale / n written as BF16_C8.  Padded tail channels are zero in both
+// operands: they add nothing to the sum and get a zero gradient; `n` is the number of REAL elements.
+__global__ __launch_bounds__(256) void l1_c8_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, double* ws,
+                                                    uint4* __restrict__ da, float scale, int64_t nvec, int64_t n) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  __shared__ double red[16];
+  const float gs = scale / (float)n;
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 va = a[i], vb = b[i];
+    const unsigned ua[4] = {va.x, va.y, va.z, va.w}, ub[4] = {vb.x, vb.y, vb.z, vb.w};
+    bf16x8 g;
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float d0 = __builtin_bit_cast(float, ua[q] << 16) - __builtin_bit_cast(float, ub[q] << 16);
+      const float d1 = __builtin_bit_cast(float, ua[q] & 0xffff0000u) - __builtin_bit_cast(float, ub[q] & 0xffff0000u);
+      part += fabsf(d0) + fabsf(d1);
+      g[2 * q] = (__bf16)(d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f));
+      g[2 * q + 1] = (__bf16)(d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f));
+    }
+    acc += part;
+    if (da) da[i] = __builtin_bit_cast(uint4, g);
+  }
+  acc = block_sum_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(ws, acc);
+}
+
 __global__ void mean_finalize_kernel(const double* ws, float* loss, double denom, float scale) {
   *loss = (float)(ws[0] / denom * scale);
 }
@@ -345,6 +374,18 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
                        loss_scale, n);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
   return ess_launch_status("l1_loss");
+}
+
+extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* da, float loss_scale, int64_t n_vectors, int64_t n,
+                              void* workspace, ess_stream_t stream) {
+  ESS_CHECK_ARG(a && b && loss && workspace && n_vectors > 0 && n > 0 && n <= 8 * n_vectors, "l1_loss_c8: bad arguments");
+  ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0, "l1_loss_c8: BF16_C8 tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("l1_loss_c8: memset failed"); return ESS_ELAUNCH; }
+  hipLaunchKernelGGL(l1_c8_kernel, dim3(wave_uniform_grid((size_t)n_vectors, 2048)), dim3(256), 0, st, (const uint4*)a, (const uint4*)b,
+                     (double*)workspace, (uint4*)da, loss_scale, n_vectors, n);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
+  return ess_launch_status("l1_loss_c8");
 }
 
 extern "C" int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

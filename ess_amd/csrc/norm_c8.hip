@@ -1,0 +1,528 @@
+// InstanceNorm2d / train-mode BatchNorm2d on BF16_C8 tensors: bfloat16 [N][ceil(C/8)][H*W][8] -- the stored form of the
+// trainable networks' activations and activation gradients in the bf16 configuration (reference layers:
+// models/style_networks.py:163-164,180-182,192 and the torchvision BasicBlock BatchNorm behind :116-121).
+//
+// A 16-byte load is one pixel of EIGHT channel planes, so every kernel works on an 8-channel block at a time: a lane keeps 8
+// running sums, a workgroup reduces 8 planes at once.  All arithmetic is fp32 (statistics: fp64 partial sums in the split
+// variants, a register-resident two-pass mean / centred variance in the fused ones); only the tensors are bf16.  Channels
+// past C inside the last block are zeros in memory and are written back as zeros.
+//   * planes of <= 20 vectors per thread (60x80 with 256 threads, 120x160 with 1024): ONE kernel, x read once and kept in
+//     registers between the reduction and the map (2 B read + 2 B written per element);
+//   * larger planes and BatchNorm (few channel blocks, reduction over N x H x W): pass 1 writes one fp64 partial per
+//     (group, slice, channel) -- no atomics, fixed summation order --, pass 2 totals them and applies the map.
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8n __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void unpack8(u32x4n v, float (&f)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f[2 * q] = __builtin_bit_cast(float, v[q] << 16);
+    f[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4n pack8n(const float (&f)[8]) {
+  bf16x8n b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)f[j];
+  return __builtin_bit_cast(u32x4n, b);
+}
+
+// block-wide sums of 8 floats (blockDim.x a multiple of 64, <= 1024); red: 16 x 8 floats of LDS.  Fixed order.
+__device__ __forceinline__ void block_sum8(float (&v)[8], float* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = wave_sum(v[j]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[w * 8 + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i * 8 + j];
+    v[j] = t;
+  }
+}
+
+constexpr int MAXV = 20;  // 16-byte vectors a thread of the fused kernels keeps in registers
+
+// The fused kernels keep a plane PACKED (4 VGPRs per 8 elements) between their passes.  Left alone, the compiler hoists the
+// bf16 -> fp32 unpacking out of the later passes and keeps all 8 floats per vector alive (2x the registers: spills with 1024
+// threads); an opaque copy per use makes every pass unpack again.
+__device__ __forceinline__ u32x4n opaque(u32x4n v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// ---- InstanceNorm forward, fused: one workgroup per (n, channel block)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
+                                                            u32x4n* __restrict__ y, float* __restrict__ stats, int CB, int C,
+                                                            int hw, float eps, int relu) {
+  __shared__ float red[16 * 8];
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  const size_t base = (size_t)g * hw;
+  constexpr int MV = THREADS == 1024 ? 19 : MAXV;  // (16 waves per CU: 128 registers per thread)
+  u32x4n xv[MV];
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    if (i < hw) {
+      xv[k] = x[base + i];
+      float f[8];
+      unpack8(xv[k], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+  }
+  block_sum8(s, red);
+  float mean[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mean[j] = s[j] / hw; q[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    if (i < hw) {
+      float f[8];
+      unpack8(opaque(xv[k]), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[j] - mean[j]; q[j] += d * d; }
+    }
+  }
+  block_sum8(q, red);
+  float rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(q[j] / hw + eps);
+  if (threadIdx.x < 8 && cb * 8 + (int)threadIdx.x < C) {
+    float m = 0.f, r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == (int)threadIdx.x) { m = mean[j]; r = rstd[j]; }
+    stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x)] = m;
+    stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x) + 1] = r;
+  }
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    if (i < hw) {
+      float f[8], rf[8];
+      unpack8(opaque(xv[k]), f);
+      if (res) unpack8(res[base + i], rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (f[j] - mean[j]) * rstd[j];
+        if (relu) t = fmaxf(t, 0.f);
+        if (res) t += rf[j];
+        f[j] = cb * 8 + j < C ? t : 0.f;
+      }
+      y[base + i] = pack8n(f);
+    }
+  }
+}
+
+// ---- InstanceNorm backward, fused (256 threads: x and dy of a 60x80 block stay in registers)
+__global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
+                                                        const float* __restrict__ stats, u32x4n* __restrict__ dx, int CB, int C,
+                                                        int hw, int relu) {
+  __shared__ float red[16 * 8];
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  const size_t base = (size_t)g * hw;
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
+    mean[j] = stats[2 * ((size_t)n * C + c)];
+    rstd[j] = stats[2 * ((size_t)n * C + c) + 1];
+  }
+  u32x4n xv[MAXV], gv[MAXV];
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < hw) {
+      xv[k] = x[base + i];
+      gv[k] = dy[base + i];
+      float f[8], gg[8];
+      unpack8(xv[k], f);
+      unpack8(gv[k], gg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (f[j] - mean[j]) * rstd[j];
+        const float gr = (relu && xh <= 0.f) ? 0.f : gg[j];
+        s1[j] += gr;
+        s2[j] += gr * xh;
+      }
+    }
+  }
+  block_sum8(s1, red);
+  block_sum8(s2, red);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] /= hw; s2[j] /= hw; }
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < hw) {
+      float f[8], gg[8];
+      unpack8(opaque(xv[k]), f);
+      unpack8(opaque(gv[k]), gg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (f[j] - mean[j]) * rstd[j];
+        const float gr = (relu && xh <= 0.f) ? 0.f : gg[j];
+        f[j] = cb * 8 + j < C ? rstd[j] * (gr - s1[j] - xh * s2[j]) : 0.f;
+      }
+      dx[base + i] = pack8n(f);
+    }
+  }
+}
+
+// ---- split variants.  Group g = (n, cb) [InstanceNorm: nseg = 1] or cb [BatchNorm: nseg = N, seg_stride = CB];
+// segment j of group g = hw vectors at ((j * seg_stride) + g) * hw.
+// sums[((g * nsl + sl) * 8 + ch) * 2 + {0, 1}] = (sum f0, sum f1) of the slice, (f0, f1) = (x, x^2) [MODE 0] or (g, g * xhat)
+// [MODE 1: backward; the ReLU mask comes from xhat (InstanceNorm: relu(IN(x))) or from the saved output y (BatchNorm)]
+template <int MODE>
+__global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ y,
+                                                        const u32x4n* __restrict__ dy, const float* __restrict__ stats,
+                                                        double* sums, int hw, int nseg, int seg_stride, int CB, int C,
+                                                        int per_sample_stats, int relu, int relu_from_y) {
+  __shared__ double redd[16];
+  const int g = blockIdx.x, nsl = gridDim.y, sl = blockIdx.y;
+  const int len = (hw + nsl - 1) / nsl;
+  const int i0 = sl * len, i1 = min(hw, i0 + len);
+  const int cb = g % CB;
+  float mean[8], rstd[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
+      const size_t p = per_sample_stats ? (size_t)(g / CB) * C + c : (size_t)c;
+      mean[j] = stats[2 * p];
+      rstd[j] = stats[2 * p + 1];
+    }
+  }
+  double s0[8], s1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0; s1[j] = 0; }
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    const size_t base = ((size_t)sgm * seg_stride + g) * hw;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      float f[8];
+      unpack8(x[base + i], f);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += (double)f[j] * f[j]; }
+      } else {
+        float gg[8], yy[8];
+        unpack8(dy[base + i], gg);
+        if (relu && relu_from_y) unpack8(y[base + i], yy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (f[j] - mean[j]) * rstd[j];
+          const bool off = relu && (relu_from_y ? yy[j] <= 0.f : xh <= 0.f);
+          const float gr = off ? 0.f : gg[j];
+          s0[j] += gr;
+          s1[j] += (double)gr * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double a = block_sum_d(s0[j], redd), b = block_sum_d(s1[j], redd);
+    if (threadIdx.x == 0) {
+      sums[(((size_t)g * nsl + sl) * 8 + j) * 2] = a;
+      sums[(((size_t)g * nsl + sl) * 8 + j) * 2 + 1] = b;
+    }
+  }
+}
+
+// totals of a group's partials for its 8 channels (wave-uniform addresses: scalar loads), in slice order
+__device__ __forceinline__ void group_total8(const double* sums, int g, int nsl, double (&t0)[8], double (&t1)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { t0[j] = 0; t1[j] = 0; }
+  for (int k = 0; k < nsl; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      t0[j] += sums[(((size_t)g * nsl + k) * 8 + j) * 2];
+      t1[j] += sums[(((size_t)g * nsl + k) * 8 + j) * 2 + 1];
+    }
+  }
+}
+
+// InstanceNorm forward map (grid: (N*CB, chunks))
+__global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
+                                                          u32x4n* __restrict__ y, float* __restrict__ stats, const double* sums,
+                                                          int nsl, int CB, int C, int hw, float eps, int relu) {
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  double t0[8], t1[8];
+  group_total8(sums, g, nsl, t0, t1);
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double m = t0[j] / hw;
+    double var = t1[j] / hw - m * m;
+    if (var < 0) var = 0;
+    mean[j] = (float)m;
+    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) { stats[2 * ((size_t)n * C + cb * 8 + j)] = mean[j]; stats[2 * ((size_t)n * C + cb * 8 + j) + 1] = rstd[j]; }
+  }
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float f[8], rf[8];
+    unpack8(x[base + i], f);
+    if (res) unpack8(res[base + i], rf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = (f[j] - mean[j]) * rstd[j];
+      if (relu) t = fmaxf(t, 0.f);
+      if (res) t += rf[j];
+      f[j] = cb * 8 + j < C ? t : 0.f;
+    }
+    y[base + i] = pack8n(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
+                                                              const float* __restrict__ stats, const double* sums, int nsl,
+                                                              u32x4n* __restrict__ dx, int CB, int C, int hw, int relu) {
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  double t0[8], t1[8];
+  group_total8(sums, g, nsl, t0, t1);
+  float mean[8], rstd[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
+    mean[j] = stats[2 * ((size_t)n * C + c)];
+    rstd[j] = stats[2 * ((size_t)n * C + c) + 1];
+    m1[j] = (float)(t0[j] / hw);
+    m2[j] = (float)(t1[j] / hw);
+  }
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float f[8], gg[8];
+    unpack8(x[base + i], f);
+    unpack8(dy[base + i], gg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (f[j] - mean[j]) * rstd[j];
+      const float gr = (relu && xh <= 0.f) ? 0.f : gg[j];
+      f[j] = cb * 8 + j < C ? rstd[j] * (gr - m1[j] - xh * m2[j]) : 0.f;
+    }
+    dx[base + i] = pack8n(f);
+  }
+}
+
+// BatchNorm(train) forward map over (n, cb) = blockIdx.x; the n == 0 / chunk 0 block also writes stats and running stats
+__global__ __launch_bounds__(256) void bn_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          u32x4n* __restrict__ y, float* __restrict__ stats, const double* sums,
+                                                          int nsl, int N, int CB, int C, int hw, int relu) {
+  const int g = blockIdx.x, cb = g % CB;
+  const double cnt = (double)N * hw;
+  double t0[8], t1[8];
+  group_total8(sums, cb, nsl, t0, t1);
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
+    const double m = t0[j] / cnt;
+    double var = t1[j] / cnt - m * m;
+    if (var < 0) var = 0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (g < CB && blockIdx.y == 0 && threadIdx.x == 0 && cb * 8 + j < C) {
+      stats[2 * c] = mean; stats[2 * c + 1] = rstd;
+      if (running_mean) {
+        const double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    }
+    a[j] = rstd * gamma[c];
+    b[j] = beta[c] - mean * a[j];
+  }
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float f[8], rf[8];
+    unpack8(x[base + i], f);
+    if (res) unpack8(res[base + i], rf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = f[j] * a[j] + b[j];
+      if (res) t += rf[j];
+      if (relu) t = fmaxf(t, 0.f);
+      f[j] = cb * 8 + j < C ? t : 0.f;
+    }
+    y[base + i] = pack8n(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ y,
+                                                              const u32x4n* __restrict__ dy, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stats, const double* sums, int nsl,
+                                                              u32x4n* __restrict__ dx, u32x4n* __restrict__ dres, float* dgamma,
+                                                              float* dbeta, int accumulate, int N, int CB, int C, int hw, int relu) {
+  const int g = blockIdx.x, cb = g % CB;
+  const double cnt = (double)N * hw;
+  double t0[8], t1[8];
+  group_total8(sums, cb, nsl, t0, t1);
+  float mean[8], rstd[8], m1[8], m2[8], gr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
+    mean[j] = stats[2 * c];
+    rstd[j] = stats[2 * c + 1];
+    if (g < CB && blockIdx.y == 0 && threadIdx.x == 0 && cb * 8 + j < C) {
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)t0[j] : (float)t0[j];
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)t1[j] : (float)t1[j];
+    }
+    m1[j] = (float)(t0[j] / cnt);
+    m2[j] = (float)(t1[j] / cnt);
+    gr[j] = gamma[c] * rstd[j];
+  }
+  const size_t base = (size_t)g * hw;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
+    float gg[8], yy[8], f[8];
+    unpack8(dy[base + i], gg);
+    if (relu) {
+      unpack8(y[base + i], yy);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (yy[j] <= 0.f) gg[j] = 0.f;
+    }
+    if (dres) dres[base + i] = pack8n(gg);
+    if (dx) {
+      unpack8(x[base + i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? gr[j] * (gg[j] - m1[j] - (f[j] - mean[j]) * rstd[j] * m2[j]) : 0.f;
+      dx[base + i] = pack8n(f);
+    }
+  }
+}
+
+inline int split_for8(int groups, int hw) {
+  int s = (1024 + groups - 1) / groups;
+  const int maxs = (hw + 1023) / 1024;  // at least 1024 pixel vectors per slice
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+inline int chunks_for8(int groups, int hw) {
+  int c = (2048 + groups - 1) / groups;
+  const int maxc = (hw + 511) / 512;
+  if (c > maxc) c = maxc;
+  return c < 1 ? 1 : c;
+}
+inline int need_ws(void* ws, size_t need, size_t have, const char* what) {
+  if (!ws || have < need) { ess_set_error("%s: workspace too small (%zu < %zu)", what, have, need); return ESS_EINVAL; }
+  return ESS_OK;
+}
+inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr, const void* e = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)e)) & 15) == 0;
+}
+
+}  // namespace
+
+// (sum, sum) pairs of doubles per group, slice and channel of the block; split_for8() keeps groups * slices <= 1024 + groups
+extern "C" size_t ess_norm_workspace_c8(int32_t groups) { return (size_t)(groups > 0 ? groups + 1024 : 0) * 8 * 16; }
+
+extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C,
+                                       int32_t hw, float eps, int32_t relu, void* workspace, size_t workspace_bytes,
+                                       ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && stats && N > 0 && C > 0 && hw > 0, "instnorm_forward_c8: bad arguments");
+  ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_forward_c8: relu must be 0 or 1");
+  ESS_CHECK_ARG(al16(x, residual, y), "instnorm_forward_c8: BF16_C8 tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int CB = (C + 7) / 8, groups = N * CB;
+  const u32x4n* xs = (const u32x4n*)x; const u32x4n* rs = (const u32x4n*)residual; u32x4n* ys = (u32x4n*)y;
+  if (hw <= 256 * MAXV) {
+    hipLaunchKernelGGL(in_fwd_c8_kernel<256>, dim3(groups), dim3(256), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
+    return ess_launch_status("instnorm_forward_c8");
+  }
+  if (hw <= 1024 * 19 && groups >= 64) {
+    hipLaunchKernelGGL(in_fwd_c8_kernel<1024>, dim3(groups), dim3(1024), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
+    return ess_launch_status("instnorm_forward_c8");
+  }
+  int rc = need_ws(workspace, ess_norm_workspace_c8(groups), workspace_bytes, "instnorm_forward_c8");
+  if (rc) return rc;
+  const int nsl = split_for8(groups, hw);
+  hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, nullptr, nullptr, (double*)workspace, hw, 1,
+                     0, CB, C, 1, 0, 0);
+  hipLaunchKernelGGL(in_apply_c8_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, rs, ys, stats,
+                     (const double*)workspace, nsl, CB, C, hw, eps, relu);
+  return ess_launch_status("instnorm_forward_c8(split)");
+}
+
+extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C,
+                                        int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && dy && stats && dx && N > 0 && C > 0 && hw > 0, "instnorm_backward_c8: bad arguments");
+  ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_backward_c8: relu must be 0 or 1");
+  ESS_CHECK_ARG(al16(x, dy, dx), "instnorm_backward_c8: BF16_C8 tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int CB = (C + 7) / 8, groups = N * CB;
+  const u32x4n* xs = (const u32x4n*)x; const u32x4n* gs = (const u32x4n*)dy; u32x4n* ds = (u32x4n*)dx;
+  if (hw <= 256 * MAXV) {
+    hipLaunchKernelGGL(in_bwd_c8_kernel, dim3(groups), dim3(256), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
+    return ess_launch_status("instnorm_backward_c8");
+  }
+  int rc = need_ws(workspace, ess_norm_workspace_c8(groups), workspace_bytes, "instnorm_backward_c8");
+  if (rc) return rc;
+  const int nsl = split_for8(groups, hw);
+  hipLaunchKernelGGL((c8_reduce_kernel<1>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, gs, stats, (double*)workspace, hw, 1, 0, CB,
+                     C, 1, relu, 0);
+  hipLaunchKernelGGL(in_bwd_apply_c8_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, gs, stats,
+                     (const double*)workspace, nsl, ds, CB, C, hw, relu);
+  return ess_launch_status("instnorm_backward_c8(split)");
+}
+
+extern "C" int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const float* gamma, const float* beta,
+                                              float* running_mean, float* running_var, float momentum, float eps, void* y,
+                                              float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace,
+                                              size_t workspace_bytes, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && gamma && beta && y && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_forward_c8: bad arguments");
+  ESS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_forward_c8: running stats come in pairs");
+  ESS_CHECK_ARG(al16(x, residual, y), "batchnorm_train_forward_c8: BF16_C8 tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int CB = (C + 7) / 8;
+  int rc = need_ws(workspace, ess_norm_workspace_c8(CB), workspace_bytes, "batchnorm_train_forward_c8");
+  if (rc) return rc;
+  const int nsl = split_for8(CB, hw);
+  hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(CB, nsl), dim3(256), 0, st, (const u32x4n*)x, nullptr, nullptr, nullptr,
+                     (double*)workspace, hw, N, CB, CB, C, 0, 0, 0);
+  hipLaunchKernelGGL(bn_apply_c8_kernel, dim3(N * CB, chunks_for8(N * CB, hw)), dim3(256), 0, st, (const u32x4n*)x,
+                     (const u32x4n*)residual, gamma, beta, running_mean, running_var, momentum, eps, (u32x4n*)y, stats,
+                     (const double*)workspace, nsl, N, CB, C, hw, relu);
+  return ess_launch_status("batchnorm_train_forward_c8");
+}
+
+extern "C" int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma,
+                                               const float* stats, void* dx, void* d_residual, float* dgamma, float* dbeta,
+                                               int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu,
+                                               void* workspace, size_t workspace_bytes, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && dy && gamma && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_backward_c8: bad arguments");
+  ESS_CHECK_ARG(al16(x, y, dy, dx, d_residual), "batchnorm_train_backward_c8: BF16_C8 tensors must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int CB = (C + 7) / 8;
+  int rc = need_ws(workspace, ess_norm_workspace_c8(CB), workspace_bytes, "batchnorm_train_backward_c8");
+  if (rc) return rc;
+  const int nsl = split_for8(CB, hw);
+  hipLaunchKernelGGL((c8_reduce_kernel<1>), dim3(CB, nsl), dim3(256), 0, st, (const u32x4n*)x, (const u32x4n*)y, (const u32x4n*)dy,
+                     stats, (double*)workspace, hw, N, CB, CB, C, 0, relu, 1);
+  hipLaunchKernelGGL(bn_bwd_apply_c8_kernel, dim3(N * CB, chunks_for8(N * CB, hw)), dim3(256), 0, st, (const u32x4n*)x,
+                     (const u32x4n*)y, (const u32x4n*)dy, gamma, stats, (const double*)workspace, nsl, (u32x4n*)dx,
+                     (u32x4n*)d_residual, dgamma, dbeta, accumulate, N, CB, C, hw, relu);
+  return ess_launch_status("batchnorm_train_backward_c8");
+}

@@ -255,3 +255,34 @@ extern "C" int ess_to_bf16_c8(const float* x, void* y, int N, int C, int H, int 
   hipLaunchKernelGGL(to_bf16_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y, C, hw, total);
   return ess_launch_status("to_bf16_c8");
 }
+
+// BF16_C8 -> fp32 NCHW (exact: every bf16 is an fp32).  The bridge out of the bf16 configuration's stored form, e.g. for a
+// caller that wants the decoder's intermediate predictions as the reference's fp32 NCHW tensors.
+namespace {
+__global__ __launch_bounds__(256) void from_bf16_c8_kernel(const uint4* __restrict__ x, float* __restrict__ y, int C, int64_t hw,
+                                                           int64_t total) {
+  const int nblk = (C + 7) >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % hw, nb = i / hw;
+    const int blk = (int)(nb % nblk);
+    const int64_t n = nb / nblk;
+    const uint4 v = x[i];
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+    float* p = y + ((size_t)n * C + (size_t)blk * 8) * hw + pix;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (blk * 8 + 2 * q < C) p[(size_t)(2 * q) * hw] = __builtin_bit_cast(float, u[q] << 16);
+      if (blk * 8 + 2 * q + 1 < C) p[(size_t)(2 * q + 1) * hw] = __builtin_bit_cast(float, u[q] & 0xffff0000u);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ess_from_bf16_c8(const void* x, float* y, int N, int C, int H, int W, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "from_bf16_c8: bad arguments");
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * ((C + 7) / 8) * hw;
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(from_bf16_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, y, C, hw, total);
+  return ess_launch_status("from_bf16_c8");
+}

@@ -67,6 +67,8 @@ class MetricsSemseg:
         return pred
 
     def get_metrics_summary(self):
+        from ..training import distributed as D
+        D.all_reduce_sum_([self.metrics_acc])  # data parallel: every rank validated its own shard; the matrix is the sum
         self.metrics_acc = self.metrics_acc.cpu()  # the one host read; the reference keeps the accumulator on the CPU
         iou_mean, iou_per_class = semseg_accum_confusion_to_iou(self.metrics_acc)
         out = {self.class_names[i]: iou for i, iou in enumerate(iou_per_class)}

@@ -14,6 +14,10 @@ _pack_cache = {}
 # (a view of the optimiser's flat gradient buffer) instead of materialising dW and letting AccumulateGrad add it.
 DIRECT_GRAD_ACCUM = False
 
+# Set by training.distributed.GradAllReducer.arm(): called with a parameter as soon as the launch that completes its gradient
+# in the running backward pass has been issued (bucketed gradient all-reduce overlapped with the rest of the backward).
+GRAD_READY_HOOK = None
+
 
 def packed_weight(spec, w, w2=None, kind=hip.W_CONV):
     """Tile-major re-layout of a weight tensor, cached until the tensor is modified in place
@@ -97,7 +101,81 @@ def repack(params):
 
 def _virt(x, mode):
     m = 2 if mode != hip.SRC_DIRECT else 1
-    return x.shape[2] * m, x.shape[3] * m
+    return x.shape[2] * m, x.shape[3] * m  # (dims 2, 3 are H, W in both layouts)
+
+
+def _channels(x):
+    """Channel count of an activation: fp32 NCHW, or BF16_C8 [N, C/8, H, W, 8] (whole blocks: every activation of the
+    trainable networks that is stored as BF16_C8 has a multiple of 8 channels)."""
+    return x.shape[1] * 8 if hip.is_c8(x) else x.shape[1]
+
+
+def _fmt(x):
+    return hip.FMT_BF16_C8 if hip.is_c8(x) else hip.FMT_F32_NCHW
+
+
+def _empty_act(N, C, H, W, device, c8):
+    if c8:
+        if C % 8:
+            raise hip.EssHipError(f'a BF16_C8 activation needs a multiple of 8 channels, got {C}')
+        return hip.bf16_c8_empty(N, C, H, W, device)
+    return torch.empty(N, C, H, W, dtype=torch.float32, device=device)
+
+
+def c8_mode():
+    """bf16 configuration: the trainable networks keep activations and activation gradients as BF16_C8 tensors only."""
+    return hip.get_compute() == 'bf16'
+
+
+class ToC8Fn(torch.autograd.Function):
+    """fp32 NCHW -> BF16_C8 (entry into the bf16 configuration's stored form); the gradient comes back as fp32 NCHW."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.C = x.shape[1]
+        return hip.to_bf16_c8(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.from_bf16_c8(dy.contiguous(), ctx.C)
+
+
+class FromC8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C):
+        return hip.from_bf16_c8(x.contiguous(), C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return hip.to_bf16_c8(dy.contiguous()), None
+
+
+def as_c8(x):
+    """`x` as a BF16_C8 tensor: itself, the staging copy its producer left next to an fp32 tensor (frozen encoder latents:
+    `.ess_c8`, valid while the tensor is unmodified and needs no gradient), or a converted copy (autograd-aware)."""
+    if hip.is_c8(x):
+        return x
+    if x.shape[1] % 8:
+        raise hip.EssHipError(f'as_c8: {x.shape[1]} channels are not a whole number of 8-channel blocks')
+    c8 = getattr(x, 'ess_c8', None)
+    if c8 is not None and c8[1] == x._version and not x.requires_grad:
+        return c8[0]
+    return ToC8Fn.apply(x)
+
+
+def from_c8(x, C=None):
+    return FromC8Fn.apply(x, x.shape[1] * 8 if C is None else C) if hip.is_c8(x) else x
+
+
+def detach_keep_c8(x):
+    """x.detach() that does not lose the producer's BF16_C8 staging copy (python attributes do not survive detach())."""
+    d = x.detach()
+    c8 = getattr(x, 'ess_c8', None)
+    if c8 is not None and c8[1] == x._version:
+        d.ess_c8 = (c8[0], d._version)
+    if getattr(x, 'ess_fp32_unwritten', False):
+        d.ess_fp32_unwritten = True
+    return d
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -107,13 +185,19 @@ class Conv2dFn(torch.autograd.Function):
     transposed weights) + weight gradient kernel, each only when needed."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1, passthrough=False):
+    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1, passthrough=False, out_c8=None):
         """passthrough=True additionally returns x0 itself as a second output.  A residual block uses THAT as its
         skip operand (y = f(conv(x)) + x_passthrough), so the gradient of the skip branch arrives in this function's
         backward next to the conv's own and is added inside the data-gradient kernel's epilogue (`residual`), instead
-        of by a separate elementwise add that autograd would launch for a tensor with two consumers."""
-        N, C0 = x0.shape[0], x0.shape[1]
-        C1 = x1.shape[1] if x1 is not None else 0
+        of by a separate elementwise add that autograd would launch for a tensor with two consumers.
+        Formats: the sources are fp32 NCHW or BF16_C8 (both alike); out_c8 picks the output's (default: like the sources)."""
+        c8in = hip.is_c8(x0)
+        if x1 is not None and hip.is_c8(x1) != c8in:
+            raise hip.EssHipError('Conv2dFn: the two sources must use the same storage format')
+        if out_c8 is None:
+            out_c8 = c8in
+        N, C0 = x0.shape[0], _channels(x0)
+        C1 = _channels(x1) if x1 is not None else 0
         Hv, Wv = _virt(x0, mode0)
         if x1 is not None and _virt(x1, mode1) != (Hv, Wv):
             raise hip.EssHipError('Conv2dFn: the two sources disagree on the (virtual) extent')
@@ -121,9 +205,9 @@ class Conv2dFn(torch.autograd.Function):
         if weight.shape[1] != C0 + C1:
             raise hip.EssHipError(f'Conv2dFn: weight expects {weight.shape[1]} input channels, got {C0}+{C1}')
         spec = hip.conv_spec(N, Hv, Wv, C0, C1, Cout, k, stride, pad, mode0, mode1)
-        out = torch.empty(N, Cout, spec.H_out, spec.W_out, dtype=torch.float32, device=x0.device)
+        out = _empty_act(N, Cout, spec.H_out, spec.W_out, x0.device, out_c8)
         shift = packed_rows(spec, bias) if bias is not None else None
-        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out)
+        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out, src_fmt=_fmt(x0), out_fmt=_fmt(out))
         ctx.spec = spec
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
@@ -137,6 +221,7 @@ class Conv2dFn(torch.autograd.Function):
         spec = ctx.spec
         (N, Hv, Wv, C0, C1, mode0, mode1, Cout, k, s, p, _, _, _, _, _) = spec.key
         dy = dy.contiguous()
+        c8in = hip.is_c8(x0)
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.has_x1, \
             ctx.needs_input_grad[2], ctx.needs_input_grad[3] and ctx.has_bias
         d0 = d1 = dw = db = None
@@ -151,6 +236,8 @@ class Conv2dFn(torch.autograd.Function):
             # the kernel pools in its epilogue (ACT_SUMPOOL2) instead of writing the full-resolution tensor for a pool pass
             pool0 = s == 1 and need0 and mode0 == hip.SRC_NEAREST_UP2 and (C1 == 0 or mode1 == hip.SRC_DIRECT) and \
                 not (Hv & 1) and not (Wv & 1)
+            if c8in and ((mode0 == hip.SRC_NEAREST_UP2 and need0 and not pool0) or (mode1 == hip.SRC_NEAREST_UP2 and need1)):
+                raise hip.EssHipError('Conv2dFn(BF16_C8): only the first source may be nearest-upsampled (pooled data-gradient)')
             if s == 1:
                 dspec = hip.conv_spec(N, spec.H_out, spec.W_out, Cout, 0, c_dg, k, 1, k - 1 - p, out_split=split,
                                       act=hip.ACT_SUMPOOL2 if pool0 else hip.ACT_NONE)
@@ -160,19 +247,20 @@ class Conv2dFn(torch.autograd.Function):
                 dspec = hip.conv_spec(N, 2 * spec.H_out, 2 * spec.W_out, Cout, 0, c_dg, k, 1, k - 1 - p,
                                       mode0=hip.SRC_ZERO_UP2, out_split=split)
             assert (dspec.H_out, dspec.W_out) == (Hv, Wv), (dspec.H_out, dspec.W_out, Hv, Wv)
-            dv0 = torch.empty((N, C0, Hv // 2, Wv // 2) if (s == 1 and pool0) else (N, C0, Hv, Wv), dtype=torch.float32,
-                              device=dy.device)
-            dv1 = torch.empty(N, C1, Hv, Wv, dtype=torch.float32, device=dy.device) if split > 0 else None
+            dv0 = _empty_act(N, C0, Hv // 2 if (s == 1 and pool0) else Hv, Wv // 2 if (s == 1 and pool0) else Wv, dy.device, c8in)
+            dv1 = _empty_act(N, C1, Hv, Wv, dy.device, c8in) if split > 0 else None
             # the skip-branch gradient (see forward) rides in the epilogue when the data-gradient IS d(x0)
             fuse_skip = d_skip is not None and need0 and C1 == 0 and mode0 == hip.SRC_DIRECT
             hip.conv_forward(dspec, dy, None, packed_weight(dspec, wd, kind=hip.W_TRANSPOSED),
-                             residual=d_skip.contiguous() if fuse_skip else None, out=dv0, out2=dv1)
+                             residual=d_skip.contiguous() if fuse_skip else None, out=dv0, out2=dv1, src_fmt=_fmt(dy),
+                             out_fmt=_fmt(dv0))
             if fuse_skip:
                 d_skip = None
             if need0:
                 d0 = hip.sumpool2x2(dv0) if (mode0 == hip.SRC_NEAREST_UP2 and not (s == 1 and pool0)) else dv0
             if need1:
                 d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
+        s2_1x1 = s == 2 and k == 1 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1)
         direct = DIRECT_GRAD_ACCUM and needw and weight.is_leaf and weight.grad is not None and weight.grad.is_contiguous() \
             and not (s == 2 and k == 3)
         if direct:
@@ -181,17 +269,19 @@ class Conv2dFn(torch.autograd.Function):
             if needb and db_t is None:
                 direct = False
         if direct:
-            if s == 2 and k == 1 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1):
+            if s2_1x1 and not c8in:
                 sp1 = hip.conv_spec(N, Hv // 2, Wv // 2, C0, 0, Cout, 1, 1, 0)
                 hip.conv_wgrad(sp1, x0[:, :, ::2, ::2].contiguous(), None, dy, weight.grad, db_t, accumulate=True)
-            else:
+            else:  # (BF16_C8: the 1x1 kernel samples the stride-2 grid itself)
                 hip.conv_wgrad(spec, x0, x1, dy, weight.grad, db_t, accumulate=True)
             dw = db = None
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK(weight)
         elif needw or needb:
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
             if s == 2 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1) and \
-                    ((k == 3 and p == 1) or (k == 1 and p == 0)):
+                    ((k == 3 and p == 1) or (k == 1 and p == 0 and not c8in)):
                 _wgrad_stride2_by_phases(x0, dy, dw, db, k)
             else:
                 hip.conv_wgrad(spec, x0, x1, dy, dw, db)
@@ -200,8 +290,8 @@ class Conv2dFn(torch.autograd.Function):
             if not needb:
                 db = None
         if d_skip is not None and need0:  # not fusable (or no data-gradient was computed): plain sum
-            d0 = d_skip if d0 is None else hip.add(d0, d_skip.contiguous())
-        return d0, d1, dw, db, None, None, None, None, None
+            d0 = d_skip if d0 is None else (d0 + d_skip if c8in else hip.add(d0, d_skip.contiguous()))
+        return d0, d1, dw, db, None, None, None, None, None, None
 
 
 def _wgrad_stride2_by_phases(x, dy, dw, db, k):
@@ -209,8 +299,8 @@ def _wgrad_stride2_by_phases(x, dy, dw, db, k):
     into its 4 pixel-parity phases X_pq[y][x] = X[2y+p][2x+q] (each at output resolution) and tap (ky, kx) of the stride-2
     filter is tap (ky', kx') of a stride-1 3x3 correlation of dY with one phase:  p = 0 if ky == 1 else 1,
     ky' = 0 if ky == 0 else 1 (same in x).  Exact; the direct stride-2 tile kernel stages 5x more input than it uses."""
-    N, C, H, W = x.shape
-    Cout = dy.shape[1]
+    N, C, H, W = x.shape[0], _channels(x), x.shape[2], x.shape[3]
+    Cout = _channels(dy)
     Ho, Wo = H // 2, W // 2
     if k == 1:
         spec = hip.conv_spec(N, Ho, Wo, C, 0, Cout, 1, 1, 0)
@@ -228,8 +318,8 @@ def _wgrad_stride2_by_phases(x, dy, dw, db, k):
                     dw[:, :, ky, kx] = tmp[:, :, 0 if ky == 0 else 1, 0 if kx == 0 else 1]
 
 
-def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT):
-    return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1)
+def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT, out_c8=None):
+    return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1, False, out_c8)
 
 
 def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0):
@@ -238,11 +328,14 @@ def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0):
 
 
 class InstanceNormFn(torch.autograd.Function):
-    """y = act(InstanceNorm(x)) + residual   (models/style_networks.py:163-164,180-182,192)."""
+    """y = act(InstanceNorm(x)) + residual   (models/style_networks.py:163-164,180-182,192); fp32 NCHW or BF16_C8 tensors."""
 
     @staticmethod
     def forward(ctx, x, residual, relu, eps):
-        y, stats = hip.instnorm_forward(x, residual, relu, eps)
+        if hip.is_c8(x):
+            y, stats = hip.instnorm_forward_c8(x, _channels(x), residual, relu, eps)
+        else:
+            y, stats = hip.instnorm_forward(x, residual, relu, eps)
         ctx.relu = relu
         ctx.save_for_backward(x, stats)
         return y
@@ -251,7 +344,10 @@ class InstanceNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = hip.instnorm_backward(x, dy, stats, ctx.relu) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.instnorm_backward_c8(x, _channels(x), dy, stats, ctx.relu) if hip.is_c8(x) else \
+                hip.instnorm_backward(x, dy, stats, ctx.relu)
         dres = dy if ctx.needs_input_grad[1] else None
         return dx, dres, None, None
 
@@ -262,12 +358,16 @@ def instance_norm(x, residual=None, relu=False, eps=1e-5):
 
 class BatchNormTrainFn(torch.autograd.Function):
     """y = act(BatchNorm_train(x) + residual), running stats updated in place (torchvision BasicBlock
-    as used by StyleEncoderE2VID, models/style_networks.py:116-121)."""
+    as used by StyleEncoderE2VID, models/style_networks.py:116-121); fp32 NCHW or BF16_C8 tensors."""
 
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
-        y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
-                                               momentum, eps, relu)
+        if hip.is_c8(x):
+            y, stats = hip.batchnorm_train_forward_c8(x, _channels(x), residual, gamma.detach(), beta.detach(), running_mean,
+                                                      running_var, momentum, eps, relu)
+        else:
+            y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
+                                                   momentum, eps, relu)
         ctx.relu = relu
         ctx.beta_ref = weakref.ref(beta)
         ctx.save_for_backward(x, y, gamma, stats)
@@ -279,17 +379,21 @@ class BatchNormTrainFn(torch.autograd.Function):
         dy = dy.contiguous()
         need_dx, need_dres, need_g, need_b = ctx.needs_input_grad[0:4]
         beta = ctx.beta_ref()
+        if hip.is_c8(x):
+            C = _channels(x)
+            bwd = lambda *a, **k: hip.batchnorm_train_backward_c8(x, C, *a, **k)  # noqa: E731
+        else:
+            bwd = lambda *a, **k: hip.batchnorm_train_backward(x, *a, **k)  # noqa: E731
         # like the conv weight gradients: add straight into the leaves' .grad (views of the optimiser's flat buffer)
         # instead of returning two C-element tensors for AccumulateGrad to add with one tiny launch each
         direct = DIRECT_GRAD_ACCUM and need_g and need_b and beta is not None and gamma.is_leaf and beta.is_leaf and \
             gamma.grad is not None and beta.grad is not None and gamma.grad.is_contiguous() and beta.grad.is_contiguous()
         if direct:
-            dx, dres = hip.batchnorm_train_backward(x, y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, gamma.grad,
-                                                    beta.grad, accumulate=True)
+            dx, dres = bwd(y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, gamma.grad, beta.grad, accumulate=True)
             return dx, dres, None, None, None, None, None, None, None
         dgamma = torch.empty_like(gamma) if (need_g or need_b) else None
         dbeta = torch.empty_like(gamma) if (need_g or need_b) else None
-        dx, dres = hip.batchnorm_train_backward(x, y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, dgamma, dbeta)
+        dx, dres = bwd(y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, dgamma, dbeta)
         return dx, dres, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None
 
 
@@ -354,7 +458,10 @@ class SymJSFn(torch.autograd.Function):
 class L1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, weight=1.0):
-        loss, da = hip.l1_loss(a, b, ctx.needs_input_grad[0], float(weight))
+        if hip.is_c8(a):
+            loss, da = hip.l1_loss_c8(a, b, a.numel(), ctx.needs_input_grad[0], float(weight))
+        else:
+            loss, da = hip.l1_loss(a, b, ctx.needs_input_grad[0], float(weight))
         ctx.save_for_backward(da)
         return loss
 
@@ -378,4 +485,6 @@ def sym_js_div(a, b, weight=1.0):
 def l1_loss(a, b, weight=1.0):
     if b.requires_grad:
         raise hip.EssHipError('l1_loss: the second argument must not require grad')
+    if hip.is_c8(a) != hip.is_c8(b):  # one side already lives in the bf16 configuration's stored form: compare there
+        a, b = as_c8(a), as_c8(b)
     return L1Fn.apply(a.contiguous(), b.contiguous(), weight)

@@ -42,6 +42,8 @@ EXPORTS = [
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
+    'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
+    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8',
 ]
 
 
@@ -78,6 +80,8 @@ def lib():
         L.ess_task_loss_workspace.argtypes = [c_int32]
         L.ess_norm_workspace.restype = c_size_t
         L.ess_norm_workspace.argtypes = [c_int32]
+        L.ess_norm_workspace_c8.restype = c_size_t
+        L.ess_norm_workspace_c8.argtypes = [c_int32]
         L.ess_voxel_normalize_workspace.restype = c_size_t
         L.ess_voxel_normalize_workspace.argtypes = [c_int32]
         L.ess_voxel_grid_trilinear_workspace.restype = c_size_t
@@ -109,6 +113,12 @@ def lib():
             'ess_voxel_grid_trilinear': [P, P, P, P, P, I64, I, I, I, I, P, P, c_size_t, I64, P],
             'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
             'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
+            'ess_from_bf16_c8': [P, P, I, I, I, I, P],
+            'ess_instnorm_forward_c8': [P, P, P, P, I, I, I, F, I, P, c_size_t, P],
+            'ess_instnorm_backward_c8': [P, P, P, P, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P],
+            'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -263,9 +273,18 @@ def to_bf16_c8(x):
 
 
 def from_bf16_c8(y, C):
-    """BF16_C8 -> fp32 NCHW (plain torch; test/debug helper, not on the product path)."""
+    """BF16_C8 -> fp32 NCHW on the device (exact)."""
     N, nb, H, W, _ = y.shape
-    return y.permute(0, 1, 4, 2, 3).reshape(N, nb * 8, H, W)[:, :C].float().contiguous()
+    if not 0 < C <= nb * 8:
+        raise EssHipError(f'from_bf16_c8: {C} channels do not fit {nb} blocks')
+    x = torch.empty(N, C, H, W, dtype=torch.float32, device=y.device)
+    _check(lib().ess_from_bf16_c8(ptr(y, torch.bfloat16), ptr(x), N, C, H, W, stream()), 'ess_from_bf16_c8')
+    return x
+
+
+def is_c8(t):
+    """Is `t` a BF16_C8 tensor (bfloat16 [N][C/8][H][W][8])?"""
+    return t is not None and t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[-1] == 8
 
 
 _ws_cache = {}
@@ -282,11 +301,17 @@ def workspace(nbytes, device, tag='ws'):
 
 
 def conv_wgrad(spec, src0, src1, dy, dw, db=None, accumulate=False):
-    nbytes = lib().ess_conv2d_wgrad_workspace(byref(spec.desc))
+    """The storage formats are taken from the tensors: BF16_C8 (bfloat16, 5-D) or fp32 NCHW for the sources and for dy."""
+    sfmt = FMT_BF16_C8 if is_c8(src0) else FMT_F32_NCHW
+    dfmt = FMT_BF16_C8 if is_c8(dy) else FMT_F32_NCHW
+    desc = spec.desc if (sfmt, dfmt) == (FMT_F32_NCHW, FMT_F32_NCHW) else spec.desc_fmt(sfmt, dfmt)
+    sdt = torch.bfloat16 if sfmt == FMT_BF16_C8 else torch.float32
+    ddt = torch.bfloat16 if dfmt == FMT_BF16_C8 else torch.float32
+    nbytes = lib().ess_conv2d_wgrad_workspace(byref(desc))
     if nbytes == 0:
         raise EssHipError('ess_conv2d_wgrad_workspace: ' + lib().ess_last_error().decode())
     ws = workspace(nbytes, dy.device, 'wgrad')
-    _check(lib().ess_conv2d_wgrad(byref(spec.desc), ptr(src0), ptr(src1), ptr(dy), ptr(dw), ptr(db), int(accumulate),
+    _check(lib().ess_conv2d_wgrad(byref(desc), ptr(src0, sdt), ptr(src1, sdt), ptr(dy, ddt), ptr(dw), ptr(db), int(accumulate),
                                   c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_conv2d_wgrad')
 
 
@@ -332,6 +357,56 @@ def batchnorm_train_backward(x, y, dy, gamma, stats, relu, need_dx=True, need_dr
                                               ptr(dgamma), ptr(dbeta), int(accumulate), N, C, H * W, int(relu),
                                               c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
            'ess_batchnorm_train_backward')
+    return dx, dres
+
+
+# ---- the same norms on BF16_C8 tensors [N, ceil(C/8), H, W, 8] (C = real channel count)
+def instnorm_forward_c8(x, C, residual, relu, eps=1e-5):
+    N, CB, H, W, _ = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
+    _check(L.ess_instnorm_forward_c8(ptr(x, torch.bfloat16), ptr(residual, torch.bfloat16), ptr(y, torch.bfloat16), ptr(stats), N, C,
+                                     H * W, c_float(eps), int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
+           'ess_instnorm_forward_c8')
+    return y, stats
+
+
+def instnorm_backward_c8(x, C, dy, stats, relu):
+    N, CB, H, W, _ = x.shape
+    dx = torch.empty_like(x)
+    L = lib()
+    ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
+    _check(L.ess_instnorm_backward_c8(ptr(x, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(stats), ptr(dx, torch.bfloat16), N, C, H * W,
+                                      int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward_c8')
+    return dx
+
+
+def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    N, CB, H, W, _ = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
+    _check(L.ess_batchnorm_train_forward_c8(ptr(x, torch.bfloat16), ptr(residual, torch.bfloat16), ptr(gamma), ptr(beta),
+                                            ptr(running_mean), ptr(running_var), c_float(momentum), c_float(eps),
+                                            ptr(y, torch.bfloat16), ptr(stats), N, C, H * W, int(relu), c_void_p(ws.data_ptr()),
+                                            c_size_t(ws.numel()), stream()), 'ess_batchnorm_train_forward_c8')
+    return y, stats
+
+
+def batchnorm_train_backward_c8(x, C, y, dy, gamma, stats, relu, need_dx=True, need_dres=False, dgamma=None, dbeta=None,
+                                accumulate=False):
+    N, CB, H, W, _ = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dres = torch.empty_like(x) if need_dres else None
+    L = lib()
+    ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
+    _check(L.ess_batchnorm_train_backward_c8(ptr(x, torch.bfloat16), ptr(y, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(gamma),
+                                             ptr(stats), ptr(dx, torch.bfloat16), ptr(dres, torch.bfloat16), ptr(dgamma), ptr(dbeta),
+                                             int(accumulate), N, C, H * W, int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
+                                             stream()), 'ess_batchnorm_train_backward_c8')
     return dx, dres
 
 
@@ -450,6 +525,18 @@ def l1_loss(a, b, want_grad, scale=1.0):
     ws = workspace(64, a.device, 'loss')
     _check(lib().ess_l1_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), a.numel(), c_void_p(ws.data_ptr()),
                              stream()), 'ess_l1_loss')
+    return loss, da
+
+
+def l1_loss_c8(a, b, n_real, want_grad, scale=1.0):
+    """L1 mean over two BF16_C8 tensors; n_real = N*C*H*W real elements (the mean's denominator)."""
+    if a.shape != b.shape:
+        raise EssHipError('l1_loss_c8: shape mismatch')
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    ws = workspace(64, a.device, 'loss')
+    _check(lib().ess_l1_loss_c8(ptr(a, torch.bfloat16), ptr(b, torch.bfloat16), ptr(loss), ptr(da, torch.bfloat16), c_float(scale),
+                                a.numel() // 8, int(n_real), c_void_p(ws.data_ptr()), stream()), 'ess_l1_loss_c8')
     return loss, da
 
 

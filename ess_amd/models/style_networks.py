@@ -104,16 +104,22 @@ class SemSegE2VID(nn.Module):
         skips[scale] = x
 
     def forward(self, input_dict):
+        """bf16 configuration (hip.set_compute('bf16')): every activation between the latents and the logits is a BF16_C8
+        tensor (bfloat16 [N, C/8, H, W, 8]) -- the latents are taken as they come (BF16_C8 from the image encoder, the
+        frozen encoder's staging copies, or converted), out[2] / out[4] are returned in that form (hip.from_bf16_c8 gives
+        the reference's fp32 NCHW view), out[1] (the logits) is fp32 NCHW in either configuration."""
         sz_in = input_dict[1].shape[3]
         x = input_dict[8]
         out = {8: x}
-        x = x.contiguous()
+        c8 = Fn.c8_mode()
+        lat = (lambda t: Fn.as_c8(t).contiguous()) if c8 else (lambda t: t.contiguous())
+        x = lat(x)
         if self.skip_connect:
             x = self.decoder_scale_1(x)
-            x = self.decoder_scale_2[0].forward_fused(x, input_dict[4].contiguous(), up=True)
+            x = self.decoder_scale_2[0].forward_fused(x, lat(input_dict[4]), up=True)
             x = self.decoder_scale_2[1](x)
             self.update_skip_dict(out, x, sz_in)
-            x = self.decoder_scale_3[0].forward_fused(x, input_dict[2].contiguous(), up=True)
+            x = self.decoder_scale_3[0].forward_fused(x, lat(input_dict[2]), up=True)
             x = self.decoder_scale_3[1](x)
             self.update_skip_dict(out, x, sz_in)
             x = self.decoder_scale_4[0].forward_fused(x, None, up=True)
@@ -125,7 +131,7 @@ class SemSegE2VID(nn.Module):
             self.update_skip_dict(out, x, sz_in)
             x = self.decoder_scale_4[1].forward_fused(x, None, up=True)
         c5 = self.decoder_scale_5[0]
-        x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0)
+        x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0, out_c8=False)  # the logits: fp32 NCHW for the loss / metric kernels
         self.update_skip_dict(out, x, sz_in)
         return out
 
@@ -148,12 +154,16 @@ class _ConvBN(nn.Module):
 
     @staticmethod
     def run(conv, bn, x, residual=None, relu=True, passthrough=False):
-        """passthrough (train mode): -> (out, x handed through conv's autograd node) for an identity skip."""
+        """passthrough (train mode): -> (out, x handed through conv's autograd node) for an identity skip.
+        bf16 configuration: the output (and a residual) is a BF16_C8 tensor whatever the input's format (the stem reads the
+        fp32 image)."""
+        out_c8 = Fn.c8_mode()
         if bn.training:
             if passthrough:
-                y, skip = Fn.conv2d_passthrough(x, conv.weight, None, conv.stride[0], conv.padding[0])
+                y, skip = Fn.Conv2dFn.apply(x, None, conv.weight, None, conv.stride[0], conv.padding[0], hip.SRC_DIRECT,
+                                            hip.SRC_DIRECT, True, out_c8)
             else:
-                y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0])
+                y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], out_c8=out_c8)
             out = Fn.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu,
                                       bn.momentum, bn.eps)
             _PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # incremented together (flush_bn_counters): 1 launch, not 15
@@ -163,16 +173,16 @@ class _ConvBN(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
             raise NotImplementedError('eval-mode BatchNorm is forward-only here (validation runs under no_grad, '
                                       'training/base_trainer.py:419)')
-        N, C, H, W = x.shape
+        N, C, H, W = x.shape[0], Fn._channels(x), x.shape[2], x.shape[3]
         spec = hip.conv_spec(N, H, W, C, 0, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0],
                              act=hip.ACT_RELU if relu else hip.ACT_NONE)
         with torch.no_grad():
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
-        out = torch.empty(N, conv.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
+        out = Fn._empty_act(N, conv.out_channels, spec.H_out, spec.W_out, x.device, out_c8)
         return hip.conv_forward(spec, x.contiguous(), None, Fn.packed_weight(spec, conv.weight),
                                 hip.pack_rows(spec, scale.contiguous(), fill=1.0), hip.pack_rows(spec, shift.contiguous()),
-                                residual, out=out)
+                                residual, out=out, src_fmt=Fn._fmt(x), out_fmt=Fn._fmt(out))
 
 
 class BasicBlock(nn.Module):
@@ -265,6 +275,7 @@ class StyleEncoderE2VID(nn.Module):
         skips[scale] = x
 
     def forward(self, x):
+        """bf16 configuration: out[2] / out[4] / out[8] are BF16_C8 tensors (see SemSegE2VID.forward); out[1] is the image."""
         out = {1: x}
         sz_in = x.shape[3]
         x = self.encoder_scale_1(x.contiguous())

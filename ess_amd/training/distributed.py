@@ -33,22 +33,78 @@ def rank():
 
 
 class GradAllReducer:
-    """Asynchronous averaged all-reduce of flat gradient buffers."""
+    """Asynchronous averaged all-reduce of flat gradient buffers.
+
+    launch(flat): one collective over a whole buffer, issued by the trainer right after the backward that completes it.
+    arm(opt, n) ... flush(): BUCKETED reduce of `opt.flat_grad` overlapped with the backward pass that is about to run: the
+    buffer is cut at parameter boundaries into `n` contiguous buckets of about equal size; the weight-gradient launches report
+    each finished parameter (functional.GRAD_READY_HOOK), and a bucket's all-reduce is issued the moment its last parameter
+    is done -- from inside the backward, so on RCCL's stream it runs under the remaining data-/weight-gradient kernels
+    (parameters are laid out in forward order, the backward finishes them back to front: the tail bucket goes first).
+    flush() issues whatever has not been reported (correctness never depends on the hook firing)."""
 
     def __init__(self):
         self.pending = []
+        self._armed = None
+
+    def _reduce(self, t):
+        if dist.get_backend() == 'nccl':
+            self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:  # gloo has no AVG
+            self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
 
     def launch(self, flat_grad):
         if world_size() <= 1:
             return
-        if dist.get_backend() == 'nccl':
-            work = dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, async_op=True)
-            self.pending.append((work, None))
-        else:  # gloo has no AVG
-            work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
-            self.pending.append((work, flat_grad))
+        self._reduce(flat_grad)
+
+    def arm(self, opt, n_buckets=2):
+        if world_size() <= 1:
+            return
+        from .. import functional as Fn
+        params = list(opt.param_groups[0]['params'])
+        sizes = [p.numel() for p in params]
+        total = sum(sizes)
+        buckets, by_id, lo, acc, cur = [], {}, 0, 0, []
+        for i, (p, k) in enumerate(zip(params, sizes)):
+            cur.append(p)
+            acc += k
+            last = i == len(params) - 1
+            if last or (len(buckets) < n_buckets - 1 and acc - lo >= total / n_buckets):
+                need = {id(q) for q in cur if q.dim() == 4 and q.requires_grad}
+                b = {'lo': lo, 'hi': acc, 'need': need, 'done': False}
+                for q in cur:
+                    by_id[id(q)] = b
+                buckets.append(b)
+                lo, cur = acc, []
+        self._armed = {'flat': opt.flat_grad, 'buckets': buckets, 'by_id': by_id}
+        Fn.GRAD_READY_HOOK = self._ready
+
+    def _ready(self, param):
+        a = self._armed
+        if a is None:
+            return
+        b = a['by_id'].get(id(param))
+        if b is None or b['done']:
+            return
+        b['need'].discard(id(param))
+        if not b['need']:
+            b['done'] = True
+            self._reduce(a['flat'][b['lo']:b['hi']])
+
+    def flush(self):
+        from .. import functional as Fn
+        a, self._armed = self._armed, None
+        Fn.GRAD_READY_HOOK = None
+        if a is None:
+            return
+        for b in a['buckets']:
+            if not b['done']:
+                b['done'] = True
+                self._reduce(a['flat'][b['lo']:b['hi']])
 
     def wait(self):
+        self.flush()
         for work, t in self.pending:
             work.wait()
             if t is not None:
@@ -56,9 +112,31 @@ class GradAllReducer:
         self.pending = []
 
 
+def all_reduce_sum_(tensors):
+    """In-place SUM over ranks of a list of tensors (validation confusion matrices / loss sums); no-op on one rank."""
+    if world_size() <= 1:
+        return
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def reduce_validation_sums(cumulative_losses, n):
+    """Loss sums and batch count of a validation epoch, summed over the ranks (each validates its own shard)."""
+    if world_size() <= 1 or not cumulative_losses:
+        return cumulative_losses, n
+    keys = sorted(cumulative_losses)
+    vals = [cumulative_losses[k].detach().float().reshape(()) for k in keys]
+    t = torch.stack(vals + [torch.tensor(float(n), device=vals[0].device)])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {k: t[i] for i, k in enumerate(keys)}, float(t[-1])
+
+
 def broadcast_module(module, src=0):
     """Make every rank start from rank `src`'s weights/buffers."""
     if world_size() <= 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+    from .. import functional as Fn
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src)  # (detach() shares storage AND version counter, unlike .data)
+    Fn.invalidate_packed(module.parameters())  # cached tile-major copies of the old weights

@@ -16,6 +16,7 @@ from ..models.style_networks import SemSegE2VID
 from ..utils import radam
 from ..utils.loss_functions import L1Loss, TaskLoss
 from . import base_trainer
+from . import distributed as D
 from .ess_trainer import build_event_encoder
 
 
@@ -62,8 +63,8 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         opt = self.optimizers_dict['optimizer_back']
         opt.zero_grad()
         d_final_loss, d_losses, d_outputs = self.task_train_step(input_batch)
+        self.grad_reducer.arm(opt, n_buckets=3)  # data parallel: bucketed all-reduce issued from inside the backward
         Fn.unit_backward([d_final_loss])  # == d_final_loss.backward(), without the gradient-times-one pass
-        self.grad_reducer.launch(opt.flat_grad)
         self.grad_reducer.wait()
         opt.step()
         return d_losses, d_outputs, d_final_loss
@@ -87,7 +88,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         return loss, losses, outputs
 
     def trainTaskStep(self, sensor_name, content_features, labels, losses):
-        content_features = {k: v.detach() for k, v in content_features.items()}
+        content_features = {k: Fn.detach_keep_c8(v) for k, v in content_features.items()}  # (keeps the BF16_C8 staging copies)
         pred = self.models_dict['back_end'](content_features)
         loss_pred = self.task_loss(pred[1], labels, weight=self.settings.weight_task_loss)  # weight folded into the kernel
         losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()
@@ -106,6 +107,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
             n += 1
         if n == 0:
             return
+        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n)
         m = self.metrics_semseg_b.get_metrics_summary()
         summary = {k: float(v) / n for k, v in cumulative_losses.items()}
         summary['semseg_sensor_b_mean_iou'], summary['semseg_sensor_b_acc'] = float(m['mean_iou']), float(m['acc'])

@@ -30,6 +30,7 @@ from ..models.style_networks import SemSegE2VID, StyleEncoderE2VID
 from ..utils import radam
 from ..utils.loss_functions import L1Loss, TaskLoss, symJSDivLoss
 from . import base_trainer
+from . import distributed as D
 
 
 def build_event_encoder(settings):
@@ -131,8 +132,9 @@ class ESSModel(base_trainer.BaseTrainer):
         e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch)
         Fn.unit_backward(self._e_terms)  # image encoder only: the decoder was frozen while this graph was recorded
         self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
+        self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
         Fn.unit_backward(self._t_terms)  # decoder only
-        self.grad_reducer.launch(opt_back.flat_grad)
+        self.grad_reducer.flush()
         final_loss = final_loss + e_loss.detach() + t_loss.detach()
         losses.update(event_losses)
         outputs.update(event_outputs)
@@ -220,7 +222,7 @@ class ESSModel(base_trainer.BaseTrainer):
                 img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
                     data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1), lean_state=i < T - 1)
         latent_fake = gen_model_sensor_a(img_fake.detach())
-        latent_real = {k: v.detach() for k, v in latent_real.items()}
+        latent_real = {k: Fn.detach_keep_c8(v) for k, v in latent_real.items()}  # (keeps the encoder's BF16_C8 staging copies)
 
         # decoder on the event latents: ONE forward, with grad (task cycle loss), shared as no-grad target
         back_end.train()
@@ -281,6 +283,7 @@ class ESSModel(base_trainer.BaseTrainer):
             n += 1
         if n == 0:
             return
+        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n)
         if sensor_name == 'sensor_a':
             tracked = [('semseg_sensor_a', self.metrics_semseg_a)]
         elif self.settings.semseg_label_val_b:

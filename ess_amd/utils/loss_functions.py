@@ -52,4 +52,4 @@ class L1Loss(torch.nn.Module):
     """torch.nn.L1Loss() as used for the cycle losses (training/ess_trainer.py:28,217-253)."""
 
     def forward(self, predict, target, weight=1.0):
-        return Fn.l1_loss(predict, target.detach(), weight)
+        return Fn.l1_loss(predict, Fn.detach_keep_c8(target), weight)

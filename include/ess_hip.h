@@ -134,13 +134,19 @@ int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1,
 
 /* fp32 NCHW -> BF16_C8 (round to nearest even; tail channels zero).  y: N*ceil(C/8)*H*W*8 bfloat16.        */
 int ess_to_bf16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
+/* BF16_C8 -> fp32 NCHW (exact).                                                                                  */
+int ess_from_bf16_c8(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
 
 /* Weight gradient of the same convolution (replaces cuDNN wgrad under autograd for
  * models/style_networks.py:158-193 and the ResNet prefix :116-121).
  * dy: [N][C_out][H_out][W_out].  dw: [C_out][C0+C1][k][k] (overwritten, or accumulated when
  * accumulate != 0).  db: [C_out] or NULL.  workspace: ess_conv2d_wgrad_workspace() bytes.          */
+/* Storage formats (bf16 compute): d->fmt0 (= fmt1) is the sources' format, d->fmt_out that of dy.  Both BF16_C8: 3x3 / stride 1 /
+ * pad 1 (direct or nearest-upsampled, one or two sources) and 1x1 / pad 0 (stride 1 or 2) convolutions -- the tiles are
+ * transposed to channel-major in registers while they are staged; X BF16_C8 + dy fp32: the 1x1 head (C_in, C_out <= 32);
+ * X fp32 + dy BF16_C8: the single-channel 7x7 stem.                                                          */
 size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d);
-int ess_conv2d_wgrad(const EssConvDesc* d, const float* src0, const float* src1, const float* dy,
+int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0, const void* src1, const void* dy,
                      float* dw, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                      ess_stream_t stream);
 
@@ -155,6 +161,24 @@ int ess_instnorm_forward(const float* x, const float* residual, float* y, float*
 /* dx from dy (gradient w.r.t. y; the residual branch gradient is dy itself, handled by the caller). */
 int ess_instnorm_backward(const float* x, const float* dy, const float* stats, float* dx, int32_t planes,
                           int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+
+/* ---- the same norms on BF16_C8 tensors (bfloat16 [N][ceil(C/8)][hw][8]; bf16 configuration: the stored form of the trainable
+ * networks' activations and activation gradients).  fp32 arithmetic and statistics; stats: fp32 [N*C][2] (InstanceNorm) /
+ * [C][2] (BatchNorm) = (mean, rstd).  relu: 0 / 1 as above.  workspace: ess_norm_workspace_c8(N*ceil(C/8)) (InstanceNorm) /
+ * ess_norm_workspace_c8(ceil(C/8)) (BatchNorm) bytes.                                                          */
+size_t ess_norm_workspace_c8(int32_t groups);
+int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C, int32_t hw,
+                            float eps, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C, int32_t hw,
+                             int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, void* y, float* stats,
+                                   int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes,
+                                   ess_stream_t stream);
+int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma, const float* stats,
+                                    void* dx, void* d_residual, float* dgamma, float* dbeta, int32_t accumulate, int32_t N,
+                                    int32_t C, int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes,
+                                    ess_stream_t stream);
 
 /* BatchNorm2d, training mode (ResNet prefix of StyleEncoderE2VID, models/style_networks.py:116-121):
  * batch statistics, running-stat update with momentum (unbiased var), y = act(bn(x) + residual).
@@ -229,6 +253,12 @@ int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, floa
 /* L1Loss mean (training/ess_trainer.py:217-229): loss and gradient w.r.t. a.                        */
 int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n,
                 void* workspace, ess_stream_t stream);
+
+/* L1Loss mean over BF16_C8 operands (bf16 configuration: the latents / intermediate predictions the cycle losses compare are
+ * stored as BF16_C8); da (nullable): BF16_C8 gradient.  n_vectors 16-byte pixel vectors, n REAL elements (the mean's
+ * denominator; padded tail channels are zero in both operands).                                                   */
+int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* da, float loss_scale, int64_t n_vectors, int64_t n,
+                   void* workspace, ess_stream_t stream);
 
 /* RAdam.step over ONE flat parameter buffer (utils/radam.py:15-80, weight_decay = 0).
  * step_size / n_sma_ge5 are computed by the host exactly as radam.py:49-64.                         */

@@ -1,0 +1,319 @@
+"""GPU tier: the BF16_C8 forms of the kernels under the trainable networks (bf16 configuration: activations and activation
+gradients are stored ONLY as bfloat16 [N][C/8][H][W][8]).  Two kinds of checks:
+  * against the fp32-NCHW form of the same kernel on bf16-pre-rounded inputs -- the MFMA operands are then identical, so the
+    BF16_C8 result must be the bf16 rounding of the fp32 result (one bf16 ulp allowed where an FMA contraction differs);
+  * against plain fp32 torch-CPU restatements of the op on the bf16-rounded inputs (tolerance: bf16 output rounding)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def H():
+    from ess_amd import hip
+    hip.lib()
+    return hip
+
+
+def bfr(x):
+    """round to bf16 and back (the values a BF16_C8 tensor can hold)"""
+    return x.to(torch.bfloat16).float()
+
+
+def c8(H, x):
+    return H.to_bf16_c8(x.cuda().contiguous())
+
+
+def un8(H, y, C):
+    return H.from_bf16_c8(y, C).cpu()
+
+
+def assert_bf16_close(got, ref, what, ulps=1.0):
+    """|got - ref| <= ulps * 2^-8 * max(|ref|, tiny) elementwise (got, ref: fp32 views of bf16-representable values)"""
+    got, ref = got.double(), ref.double()
+    tol = ulps * 2.0 ** -7 * ref.abs().clamp(min=1e-30) + 1e-30
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f'{what}: {int(bad.sum())} of {bad.numel()} elements off by more than {ulps} bf16 ulp; ' \
+                          f'max abs diff {(got - ref).abs().max().item():.3e}'
+
+
+def _up(x, mode):
+    if mode == 1:
+        return F.interpolate(x, scale_factor=2, mode='nearest')
+    if mode == 2:
+        z = torch.zeros(x.shape[0], x.shape[1], 2 * x.shape[2], 2 * x.shape[3])
+        z[:, :, ::2, ::2] = x
+        return z
+    return x
+
+
+C8_CONV_CASES = [
+    # N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, act, affine, residual, split, src_c8, out_c8
+    (2, 256, 0, 256, 12, 20, 3, 1, 1, 0, 0, 0, False, False, 0, True, True),     # decoder resblock conv
+    (2, 256, 0, 256, 12, 20, 3, 1, 1, 0, 0, 0, False, True, 0, True, True),      # dgrad + fused skip gradient
+    (2, 128, 128, 128, 12, 20, 3, 1, 1, 1, 0, 0, True, False, 0, True, True),    # cat(nearest_up(x), skip)
+    (1, 64, 0, 32, 32, 48, 3, 1, 1, 1, 0, 1, True, False, 0, True, True),        # nearest-up single source + relu
+    (2, 128, 0, 256, 12, 20, 3, 1, 1, 0, 0, 0, False, False, 128, True, True),   # dgrad of a concat conv: split outputs
+    (2, 128, 0, 128, 24, 40, 3, 1, 1, 0, 0, 4, False, False, 0, True, True),     # pooled data-gradient (one-row blocks off: W<32)
+    (2, 64, 0, 64, 16, 64, 3, 1, 1, 0, 0, 4, False, False, 0, True, True),       # pooled, 32-wide pixel blocks
+    (1, 64, 0, 128, 16, 64, 3, 1, 1, 0, 0, 4, False, False, 64, True, True),     # pooled first output + full-res second
+    (2, 128, 0, 64, 24, 40, 3, 1, 1, 2, 0, 0, False, False, 0, True, True),      # dgrad of a 3x3/s2 conv (zero-insert source)
+    (2, 64, 0, 128, 24, 40, 3, 2, 1, 0, 0, 0, False, False, 0, True, True),      # resnet 3x3 s2
+    (2, 64, 0, 128, 24, 40, 1, 2, 0, 0, 0, 0, False, False, 0, True, True),      # resnet downsample 1x1 s2
+    (2, 128, 0, 64, 24, 40, 1, 1, 0, 2, 0, 0, False, False, 0, True, True),      # its data-gradient (1x1 over zero-inserted dy)
+    (2, 32, 0, 11, 24, 40, 1, 1, 0, 0, 0, 0, True, False, 0, True, False),       # head 1x1: BF16_C8 in, fp32 logits out
+    (2, 11, 0, 32, 24, 40, 1, 1, 0, 0, 0, 0, False, False, 0, False, True),      # its data-gradient: fp32 in, BF16_C8 out
+    (2, 1, 0, 64, 24, 40, 7, 2, 3, 0, 0, 0, False, False, 0, False, True),       # stem: fp32 image in, BF16_C8 out
+    (1, 24, 0, 40, 17, 30, 3, 1, 1, 0, 0, 1, True, False, 0, True, True),        # odd extents, ragged channel blocks
+    (1, 512, 0, 256, 12, 20, 3, 1, 1, 0, 0, 0, False, False, 0, True, True),     # 128-row tiles (MB = 4)
+]
+
+
+@pytest.mark.parametrize('case', C8_CONV_CASES)
+def test_conv_c8_forms(H, case):
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, act, affine, res, split, src_c8, out_c8 = case
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+        d0, d1 = (2 if m0 else 1), (2 if m1 else 1)
+        x0 = bfr(torch.randn(N, C0, Hv // d0, Wv // d0, generator=g))
+        x1 = bfr(torch.randn(N, C1, Hv // d1, Wv // d1, generator=g)) if C1 else None
+        w = torch.randn(Cout, C0 + C1, k, k, generator=g) / math.sqrt((C0 + C1) * k * k)
+        scale = torch.rand(Cout, generator=g) + 0.5 if affine else None
+        shift = torch.randn(Cout, generator=g) if affine else None
+        spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, k, s, p, m0, m1, act=act, out_split=split)
+        Ho, Wo = spec.H_out, spec.W_out
+        r = bfr(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
+        pw = H.pack_weights(spec, w.cuda())
+        ps = H.pack_rows(spec, scale.cuda(), fill=1.0) if affine else None
+        pb = H.pack_rows(spec, shift.cuda()) if affine else None
+        pool = act == H.ACT_SUMPOOL2
+        c_first = split if split else Cout
+        # ---- fp32-NCHW form of the same launch
+        o1 = torch.empty(N, c_first, Ho // 2 if pool else Ho, Wo // 2 if pool else Wo, device='cuda')
+        o2 = torch.empty(N, Cout - split, Ho, Wo, device='cuda') if split else None
+        H.conv_forward(spec, x0.cuda(), None if x1 is None else x1.cuda(), pw, ps, pb, None if r is None else r.cuda(), out=o1, out2=o2)
+        # ---- the form under test
+        sfmt = H.FMT_BF16_C8 if src_c8 else H.FMT_F32_NCHW
+        ofmt = H.FMT_BF16_C8 if out_c8 else H.FMT_F32_NCHW
+        s0 = c8(H, x0) if src_c8 else x0.cuda()
+        s1 = None if x1 is None else (c8(H, x1) if src_c8 else x1.cuda())
+        if out_c8:
+            q1 = H.bf16_c8_empty(N, c_first, o1.shape[2], o1.shape[3], 'cuda')
+            q2 = H.bf16_c8_empty(N, Cout - split, Ho, Wo, 'cuda') if split else None
+            q1.fill_(float('nan'))
+            rr = None if r is None else c8(H, r)
+        else:
+            q1, q2, rr = torch.empty_like(o1), None, None if r is None else r.cuda()
+        H.conv_forward(spec, s0, s1, pw, ps, pb, rr, out=q1, out2=q2, src_fmt=sfmt, out_fmt=ofmt)
+        torch.cuda.synchronize()
+        if out_c8:
+            assert_bf16_close(un8(H, q1, c_first), bfr(o1.cpu()), 'first output')
+            if split:
+                assert_bf16_close(un8(H, q2, Cout - split), bfr(o2.cpu()), 'second output')
+            # channels past C inside the last block are zeros
+            if c_first % 8:
+                tail = q1.float().cpu()[:, -1, :, :, c_first % 8:]
+                assert (tail == 0).all()
+        else:
+            assert torch.equal(q1.cpu(), o1.cpu())
+        # ---- sanity against torch on the rounded operands
+        xin = _up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), _up(x1, m1)], 1)
+        ref = F.conv2d(xin, bfr(w), None, s, p)
+        if affine:
+            ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if res:
+            ref = ref + r
+        if act == 1:
+            ref = torch.relu(ref)
+        if pool:
+            first = 4 * F.avg_pool2d(ref[:, :c_first], 2)
+        else:
+            first = ref[:, :c_first]
+        got = un8(H, q1, c_first) if out_c8 else q1.cpu()
+        err = (got - first).abs().max().item() / first.abs().max().item()
+        assert err < 1e-2, err
+    finally:
+        H.set_compute('fp32')
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def _in_ref(x, res, relu, eps=1e-5):
+    y = F.instance_norm(x, eps=eps)
+    if relu:
+        y = torch.relu(y)
+    return y + res if res is not None else y
+
+
+IN_CASES = [
+    # N, C, H, W, relu, residual
+    (2, 16, 12, 20, 1, False),     # fused, 256 threads
+    (2, 24, 12, 20, 0, True),      # IN(x) + residual (INSResBlock tail), whole blocks
+    (8, 64, 80, 100, 1, False),    # fused, 1024 threads (64 groups)
+    (1, 16, 160, 168, 1, False),   # split (reduce + apply)
+    (2, 8, 7, 9, 1, True),         # tiny odd plane
+]
+
+
+@pytest.mark.parametrize('case', IN_CASES)
+def test_instance_norm_c8(H, case):
+    N, C, Hh, W, relu, has_res = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bfr(torch.randn(N, C, Hh, W, generator=g) * 1.7 + 0.4)
+    res = bfr(torch.randn(N, C, Hh, W, generator=g)) if has_res else None
+    dy = bfr(torch.randn(N, C, Hh, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    ref = _in_ref(xr, res, relu)
+    ref.backward(dy)
+    y8, stats = H.instnorm_forward_c8(c8(H, x), C, None if res is None else c8(H, res), relu)
+    dx8 = H.instnorm_backward_c8(c8(H, x), C, c8(H, dy), stats, relu)
+    torch.cuda.synchronize()
+    y, dx = un8(H, y8, C), un8(H, dx8, C)
+    assert (y - ref.detach()).abs().max().item() < 2.0 ** -7 * ref.detach().abs().max().item() + 1e-6
+    mean = x.mean(dim=(2, 3)).reshape(-1)
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3), unbiased=False) + 1e-5).reshape(-1)
+    assert (stats[:, 0].cpu() - mean).abs().max().item() < 1e-5
+    assert ((stats[:, 1].cpu() - rstd) / rstd).abs().max().item() < 1e-5
+    assert (dx - xr.grad).abs().max().item() < 2.0 ** -7 * xr.grad.abs().max().item() + 1e-6
+
+
+BN_CASES = [
+    # N, C, H, W, relu, residual
+    (2, 64, 12, 20, 1, False),
+    (3, 128, 6, 10, 1, True),
+    (2, 64, 48, 80, 0, False),
+    (8, 64, 60, 80, 1, True),
+]
+
+
+@pytest.mark.parametrize('case', BN_CASES)
+def test_batch_norm_train_c8(H, case):
+    N, C, Hh, W, relu, has_res = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bfr(torch.randn(N, C, Hh, W, generator=g) * 1.3 - 0.2)
+    res = bfr(torch.randn(N, C, Hh, W, generator=g)) if has_res else None
+    dy = bfr(torch.randn(N, C, Hh, W, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if has_res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if has_res:
+        ref = ref + rr
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(dy)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    x8 = c8(H, x)
+    y8, stats = H.batchnorm_train_forward_c8(x8, C, None if res is None else c8(H, res), gamma.cuda(), beta.cuda(), rm_d, rv_d, 0.1,
+                                             1e-5, relu)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dx8, dres8 = H.batchnorm_train_backward_c8(x8, C, y8, c8(H, dy), gamma.cuda(), stats, relu, True, has_res, dg, db)
+    torch.cuda.synchronize()
+    y = un8(H, y8, C)
+    assert (y - ref.detach()).abs().max().item() < 2.0 ** -7 * ref.detach().abs().max().item() + 1e-6
+    assert (rm_d.cpu() - rm_ref).abs().max().item() < 1e-5 and (rv_d.cpu() - rv_ref).abs().max().item() < 1e-5
+    # the ReLU mask comes from the bf16-rounded output: identical to the reference's mask except where |y| < one bf16 ulp
+    assert (un8(H, dx8, C) - xr.grad).abs().max().item() < 3e-2 * xr.grad.abs().max().item()
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    assert rel(un8(H, dx8, C), xr.grad) < 5e-3
+    assert rel(dg.cpu(), gr.grad) < 5e-3 and rel(db.cpu(), br.grad) < 5e-3
+    if has_res:
+        assert rel(un8(H, dres8, C), rr.grad) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients
+WGRAD_C8_CASES = [
+    # N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, bias
+    (2, 256, 0, 256, 12, 20, 3, 1, 1, 0, 0, True),
+    (2, 64, 0, 64, 24, 40, 3, 1, 1, 0, 0, True),
+    (2, 128, 128, 128, 12, 20, 3, 1, 1, 1, 0, True),    # cat(nearest_up(x), skip)
+    (1, 64, 0, 32, 32, 48, 3, 1, 1, 1, 0, True),        # nearest-up single source, 32 output channels
+    (2, 64, 0, 128, 24, 40, 1, 2, 0, 0, 0, False),      # ResNet downsample 1x1 / stride 2
+    (2, 128, 0, 128, 12, 20, 1, 1, 0, 0, 0, False),     # 1x1 / stride 1
+    (1, 24, 0, 40, 17, 30, 3, 1, 1, 0, 0, True),        # ragged channel blocks, odd extents
+    (2, 64, 0, 64, 6, 10, 3, 1, 1, 0, 0, True),         # smaller than one pixel tile
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_C8_CASES)
+def test_conv_wgrad_c8(H, case):
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, bias = case
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+        d0, d1 = (2 if m0 else 1), (2 if m1 else 1)
+        x0 = bfr(torch.randn(N, C0, Hv // d0, Wv // d0, generator=g))
+        x1 = bfr(torch.randn(N, C1, Hv // d1, Wv // d1, generator=g)) if C1 else None
+        spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, k, s, p, m0, m1)
+        dy = bfr(torch.randn(N, Cout, spec.H_out, spec.W_out, generator=g))
+        xin = (_up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), _up(x1, m1)], 1)).requires_grad_(True)
+        w = torch.zeros(Cout, C0 + C1, k, k, requires_grad=True)
+        b = torch.zeros(Cout, requires_grad=True)
+        F.conv2d(xin, w, b, s, p).backward(dy)
+        dw = torch.full((Cout, C0 + C1, k, k), float('nan'), device='cuda')
+        db = torch.full((Cout,), float('nan'), device='cuda') if bias else None
+        H.conv_wgrad(spec, c8(H, x0), None if x1 is None else c8(H, x1), c8(H, dy), dw, db)
+        torch.cuda.synchronize()
+        err = ((dw.cpu() - w.grad).abs().max() / w.grad.abs().max()).item()
+        assert err < 2e-5, err  # the operands are exact in bf16: only the fp32 summation order differs
+        if bias:
+            assert ((db.cpu() - b.grad).abs().max() / b.grad.abs().max()).item() < 2e-5
+        # accumulate form
+        dw2 = dw.clone()
+        H.conv_wgrad(spec, c8(H, x0), None if x1 is None else c8(H, x1), c8(H, dy), dw2, None, accumulate=True)
+        assert ((dw2.cpu() - 2 * w.grad).abs().max() / w.grad.abs().max()).item() < 4e-5
+    finally:
+        H.set_compute('fp32')
+
+
+def test_conv_wgrad_head_and_stem_c8(H):
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(7)
+        # 1x1 head: X BF16_C8 (32 channels), dY fp32 logit gradients (K = 11 / 6 classes), odd pixel count
+        for (N, Cin, K, Hh, W) in ((2, 32, 11, 24, 40), (1, 32, 6, 25, 37), (2, 16, 11, 8, 16)):
+            x = bfr(torch.randn(N, Cin, Hh, W, generator=g))
+            dy = torch.randn(N, K, Hh, W, generator=g)
+            spec = H.conv_spec(N, Hh, W, Cin, 0, K, 1, 1, 0)
+            dw = torch.empty(K, Cin, 1, 1, device='cuda')
+            db = torch.empty(K, device='cuda')
+            H.conv_wgrad(spec, c8(H, x), None, dy.cuda(), dw, db)
+            ref = torch.einsum('nkhw,nchw->kc', dy, x)
+            assert ((dw.cpu().view(K, Cin) - ref).abs().max() / ref.abs().max()).item() < 2e-5
+            assert ((db.cpu() - dy.sum(dim=(0, 2, 3))).abs().max() / dy.sum(dim=(0, 2, 3)).abs().max()).item() < 2e-5
+        # 7x7 / stride 2 stem: X = fp32 image (1 channel), dY BF16_C8 (64 channels)
+        N, Hh, W = 2, 24, 40
+        img = torch.rand(N, 1, Hh, W, generator=g)
+        spec = H.conv_spec(N, Hh, W, 1, 0, 64, 7, 2, 3)
+        dy = bfr(torch.randn(N, 64, spec.H_out, spec.W_out, generator=g))
+        w = torch.zeros(64, 1, 7, 7, requires_grad=True)
+        F.conv2d(img, w, None, 2, 3).backward(dy)
+        dw = torch.empty(64, 1, 7, 7, device='cuda')
+        H.conv_wgrad(spec, img.cuda(), None, c8(H, dy), dw, None)
+        assert ((dw.cpu() - w.grad).abs().max() / w.grad.abs().max()).item() < 2e-5
+    finally:
+        H.set_compute('fp32')
+
+
+def test_l1_and_layout_roundtrip_c8(H):
+    g = torch.Generator().manual_seed(3)
+    for C in (8, 24, 13):
+        x = torch.randn(2, C, 9, 14, generator=g)
+        y = c8(H, x)
+        assert torch.equal(un8(H, y, C), bfr(x))
+        if C % 8:
+            assert (y.float().cpu()[:, -1, :, :, C % 8:] == 0).all()
+    a, b = bfr(torch.randn(2, 16, 12, 20, generator=g)), bfr(torch.randn(2, 16, 12, 20, generator=g))
+    b[0, 3] = a[0, 3]  # exact ties: zero gradient
+    loss, da = H.l1_loss_c8(c8(H, a), c8(H, b), a.numel(), True, scale=0.7)
+    ref = 0.7 * (a - b).abs().mean()
+    assert abs(loss.item() - ref.item()) < 1e-6 * ref.item() + 1e-8
+    gs = bfr(torch.tensor(0.7 / a.numel()))
+    assert torch.equal(un8(H, da, 16), torch.sign(a - b) * gs)
