@@ -9,8 +9,9 @@ One "step" = one ESSModel.train_step (T x E2VID recurrent encoder forward, image
 bwd x3, losses, 2 x RAdam) on one synthetic batch per GPU, inputs resident in HBM before the timed region.
 Workload = BASELINE config 3/4: DSEC-shape, B=8 sequences per GPU, T=5, C=2, 480x640, K=11, DSEC branch.
 Prints ONE JSON line on rank 0 (value = voxel grids/s over all GPUs = N*B*T / max-over-ranks step time), with
-`roofline` for the dominant kernel (fused ConvLSTM gate conv, fp32 MFMA) and `cpu_baseline` (the oracle timed on the
-host cores, N=1 only).
+`roofline` for the time-dominant kernel (the plain 3x3 convolution of the trainable networks; the ConvLSTM gate kernel and the
+weight-gradient kernel as `roofline.others`), `step` (whole-step FLOPs against the matrix-core peak), `extra` (the fp32
+parity-grade configuration's ms/step) and `cpu_baseline` (the oracle timed on the host cores, N=1 only).
 """
 import argparse
 import ctypes
@@ -46,6 +47,8 @@ def parse():
                     help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3) or exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-fp32-extra', action='store_true', help='skip the fp32 (parity-grade) steps reported in `extra`')
+    ap.add_argument('--quick-cpu-baseline', action='store_true', help='1 warm-up + 2 timed oracle steps instead of 2 + 5')
     return ap.parse_args()
 
 
@@ -75,65 +78,135 @@ class HipEvents:
         return ms.value
 
 
-def roofline_gate_kernels(args, device):
-    """Time the dominant kernel -- the fused ConvLSTM step: 3x3 gate conv over cat(x,h) + LSTM epilogue -- on the
-    three encoder levels of the workload, with HIP events on the launch stream.  Algorithmic FLOPs per launch =
-    2 * B*H*W * 9 * (2*hid) * (4*hid) (2.265e10 MACs per sample per level at 480x640)."""
+def _timed(ev, stream, fn, reps=20, warm=3):
+    """average duration (ms) of one call of fn() measured with HIP events on the launch stream"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = ev.event(), ev.event()
+    ev.record(e0, stream)
+    for _ in range(reps):
+        fn()
+    ev.record(e1, stream)
+    return ev.elapsed_ms(e0, e1) / reps
+
+
+def decoder_conv3x3_layers(args):
+    """The 16 plain 3x3 convolutions of ONE SemSegE2VID forward at the bench shape (models/style_networks.py:69-88,158-193):
+    (C0, C1, Cout, Hv, Wv, mode0 = nearest-up2 of source 0, count).  These are the launches of the time-dominant kernel of
+    the step (forward x3, and as data-gradients of the same geometry x3 per step)."""
+    H, W = args.height, args.width
+    return [(256, 0, 256, H // 8, W // 8, 0, 10), (256, 0, 128, H // 8, W // 8, 0, 1), (128, 128, 128, H // 4, W // 4, 1, 1),
+            (128, 0, 64, H // 4, W // 4, 0, 1), (64, 64, 64, H // 2, W // 2, 1, 1), (64, 0, 64, H // 2, W // 2, 0, 1),
+            (64, 0, 32, H, W, 1, 1)]
+
+
+def _traffic_from_profiles(tag):
+    """HBM bytes per launch set from the PMC passes of tools/pmc_traffic.py (rocprofv3 --pmc, separate passes, the guide's gfx950
+    unit corrections), committed as profiles/r2_traffic.json; None when this shape / kernel was not profiled."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+            t = json.load(f).get(tag)
+    except (OSError, ValueError):
+        return None
+    return t
+
+
+def roofline_blocks(args, device):
+    """`roofline` of the bench line: the time-dominant kernel of the step -- the plain 3x3 convolution of the trainable networks
+    (conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> in the bf16 configuration) -- timed LIVE with HIP events on the launch
+    stream over the 16 launches of one decoder forward, exactly as the product issues them (BF16_C8 in, BF16_C8 out, concat +
+    nearest-upsample in the tile loader).  achieved = algorithmic FLOPs (2 * N * Hout * Wout * 9 * Cin * Cout per launch) / time.
+    `others` carries the fused ConvLSTM gate kernel (three encoder levels of one time step) and the weight-gradient kernel (the same
+    16 decoder layers) measured the same way."""
     from ess_amd import hip
     ev = HipEvents()
     stream = torch.cuda.current_stream().cuda_stream
     B = args.batch
-    tot_flops, tot_ms, per_level = 0.0, 0.0, []
+    bf16 = args.compute == 'bf16'
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    g = torch.Generator(device='cpu').manual_seed(0)
+
+    def act(C, H, W):
+        t = torch.randn(B, C, H, W, generator=g).to(device)
+        return hip.to_bf16_c8(t) if bf16 else t
+
+    # ---- plain 3x3 convolutions (forward) and their weight gradients
+    conv_ms = conv_fl = wg_ms = wg_fl = 0.0
+    per_layer = []
+    for (C0, C1, Cout, Hv, Wv, m0, cnt) in decoder_conv3x3_layers(args):
+        spec = hip.conv_spec(B, Hv, Wv, C0, C1, Cout, 3, 1, 1, hip.SRC_NEAREST_UP2 if m0 else hip.SRC_DIRECT, hip.SRC_DIRECT)
+        x0 = act(C0, Hv // (2 if m0 else 1), Wv // (2 if m0 else 1))
+        x1 = act(C1, Hv, Wv) if C1 else None
+        w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5).to(device)
+        bias = torch.randn(Cout, generator=g).to(device)
+        pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, bias)
+        fmt = hip.FMT_BF16_C8 if bf16 else hip.FMT_F32_NCHW
+        out = hip.bf16_c8_empty(B, Cout, Hv, Wv, device) if bf16 else torch.empty(B, Cout, Hv, Wv, device=device)
+        ms = _timed(ev, stream, lambda: hip.conv_forward(spec, x0, x1, pw, None, pb, out=out, src_fmt=fmt, out_fmt=fmt))
+        fl = 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout
+        dy = act(Cout, Hv, Wv)
+        dw, db = torch.empty_like(w), torch.empty_like(bias)
+        wms = _timed(ev, stream, lambda: hip.conv_wgrad(spec, x0, x1, dy, dw, db), reps=10, warm=2)
+        per_layer.append({'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''), 'count': cnt, 'conv_ms': round(ms, 4),
+                          'conv_tflops': round(fl / ms / 1e9, 1), 'wgrad_ms': round(wms, 4), 'wgrad_tflops': round(fl / wms / 1e9, 1)})
+        conv_ms += cnt * ms; conv_fl += cnt * fl; wg_ms += cnt * wms; wg_fl += cnt * fl
+        del x0, x1, out, dy
+    # ---- fused ConvLSTM step (gate conv + epilogue), three encoder levels of one time step
+    gate_ms = gate_fl = 0.0
+    gate_levels = []
     for lvl, hid in enumerate((64, 128, 256)):
         H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
         spec = hip.conv_spec(B, H, W, hid, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
-        g = torch.Generator(device='cpu').manual_seed(lvl)
         w = (torch.randn(4 * hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device)
         bias = torch.randn(4 * hid, generator=g).to(device)
         x, h, c = [torch.randn(B, hid, H, W, generator=g).to(device) for _ in range(3)]
         pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, bias)
         ho, co = torch.empty_like(h), torch.empty_like(c)
         kw = {}
-        if args.compute == 'bf16':
-            # exactly the product launch (e2vid/model/submodules.py ConvLSTM.forward): x and h staged from the BF16_C8
-            # copies their producers left, and a BF16_C8 copy of h' written for the next time step
+        if bf16:  # exactly the product launch (e2vid/model/submodules.py ConvLSTM.forward)
             x, h = hip.to_bf16_c8(x), hip.to_bf16_c8(h)
             kw = dict(src_fmt=hip.FMT_BF16_C8, out_bf=hip.bf16_c8_empty(B, hid, H, W, device))
-        for _ in range(5):
-            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, **kw)
-        reps = 20
-        e0, e1 = ev.event(), ev.event()
-        ev.record(e0, stream)
-        for _ in range(reps):
-            hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, **kw)
-        ev.record(e1, stream)
-        ms = ev.elapsed_ms(e0, e1) / reps
-        flops = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)
-        per_level.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'tflops': round(flops / ms / 1e9, 2)})
-        tot_flops += flops
-        tot_ms += ms
-    achieved = tot_flops / tot_ms / 1e9
-    bf16 = args.compute == 'bf16'
-    traffic = None
-    try:  # HBM bytes of the same three launches from the committed PMC passes (null when this shape was not profiled)
-        with open(os.path.join(ROOT, 'profiles', 'gate_kernel_traffic.json')) as f:
-            t = json.load(f).get(f'{args.compute}/{B}/{args.height}x{args.width}')
-        if t:
-            traffic = {'bytes': sum(t['per_level_bytes']), 'algorithmic_bytes': sum(t['algorithmic_bytes']),
-                       'source': 'profiles/r1_gate_kernel_pmc_c8.txt (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'}
-    except OSError:
-        pass
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'kernel': 'conv_bf16_ws_k3s1_kernel<MB,EPI_LSTM,BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,EPI_LSTM,8>',
-            'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-            'traffic': traffic, 'per_level': per_level,
+        ms = _timed(ev, stream, lambda: hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, **kw))
+        fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)
+        gate_levels.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
+        gate_ms += ms; gate_fl += fl
+    tag = f'{args.compute}/{B}/{args.height}x{args.width}'
+    conv_t = conv_fl / conv_ms / 1e9
+    return {'bound': 'mfma',
+            'kernel': ('conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> (plain 3x3 conv of the trainable networks)' if bf16
+                       else 'conv_f32_kernel<3,1,MB,LINEAR,8>') + ': the 16 launches of one decoder forward',
+            'achieved': round(conv_t, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(conv_t / peak, 4),
+            'traffic': _traffic_from_profiles('conv3x3/' + tag), 'ms_per_launch_set': round(conv_ms, 4), 'per_layer': per_layer,
+            'others': {
+                'convlstm_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
+                                  'achieved': round(gate_fl / gate_ms / 1e9, 1), 'frac': round(gate_fl / gate_ms / 1e9 / peak, 4),
+                                  'per_level': gate_levels, 'traffic': _traffic_from_profiles('gate/' + tag)},
+                'wgrad': {'kernel': 'wgrad_c8_kernel<9> + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
+                          'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
+                          'ms_per_launch_set': round(wg_ms, 4)}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
-                    '; sum over the 3 encoder-level launches of one time step; HIP events on the launch stream'}
+                    '; HIP events on the launch stream, inside this process after the timed steps'}
+
+
+def executed_flops_per_step(args):
+    """Algorithmic FLOPs of the launches ONE train step issues per GPU (MAC = 2 FLOP; P = H*W):
+    (T-1) encoder-only E2VID steps + 1 full step, minus the h-half of the first step's gate convs (h = 0 is not contracted);
+    UDA: decoder 3 forwards + 3 data-gradient passes + 2 weight-gradient passes, image encoder 2 forwards + 1 backward
+    (data- and weight-gradient); supervised: decoder forward + backward."""
+    P, C, K, T, B = args.height * args.width, args.C, args.classes, args.T, args.batch
+    m_eenc, m_e, m_d, m_a = (800 * C + 259584) * P, (800 * C + 450080) * P, (165888 + 32 * K) * P, 103184 * P
+    macs = (T - 1) * m_eenc - 110592 * P
+    if args.trainer == 'ess':
+        macs += m_e + 8 * m_d + 4 * m_a
+    else:
+        macs += m_eenc + 3 * m_d
+    return 2.0 * B * macs
 
 
 def cpu_baseline(args):
-    """The oracle's UDA step (oracle/ess_oracle.py, pinned to the reference) on the host cores: a bounded sample of
-    the same workload -- B=1 sequence of the same T/C/HxW/K -- 1 warm-up + 2 timed steps."""
+    """The oracle's train step (oracle/ess_oracle.py, pinned to the reference by tests/golden) on the host cores: a bounded
+    sample of the same workload -- B=1 sequence of the same T/C/HxW/K -- 2 warm-ups, median of 5 timed steps."""
+    import statistics
     from oracle import ess_oracle as O
     nthreads = torch.get_num_threads()
     B, T, C, H, W, K = 1, args.T, args.C, args.height, args.width, args.classes
@@ -144,7 +217,8 @@ def cpu_baseline(args):
     of = O.radam_init_state([sd_f[k] for k in O.trainable_keys(sd_f)])
     ob = O.radam_init_state([sd_d[k] for k in O.trainable_keys(sd_d)])
     times = []
-    for s in range(3):
+    warm, timed = (2, 5) if not args.quick_cpu_baseline else (1, 2)
+    for s in range(warm + timed):
         ev, img, lab_a, lab_b = O.synth_batch(B, T, C, H, W, K, seed=s)
         t0 = time.perf_counter()
         if args.trainer == 'ess':
@@ -152,12 +226,12 @@ def cpu_baseline(args):
         else:
             O.supervised_train_step(sd_e, cfg, sd_d, ob, ev, lab_b, T, K, 5e-4)
         times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / len(times[1:])
+    t = statistics.median(times[warm:])
     return {'value': round(B * T / t, 3), 'unit': 'voxel_grids/s', 'cores': nthreads, 'kind': 'port',
-            'sample': f'{args.trainer} step, B=1 sequence (T={T}, C={C}, {H}x{W}, K={K}), fp32 torch-CPU oracle doing the work as '
+            'sample': f'{args.trainer} step, B={B} sequence (T={T}, C={C}, {H}x{W}, K={K}), fp32 torch-CPU oracle doing the work as '
                       f'written by the reference (full UNet every time step' +
                       (', 5 decoder forwards' if args.trainer == 'ess' else '') +
-                      f'), mean of 2 steps after 1 warm-up; {t:.2f} s/step'}
+                      f'), median of {timed} steps after {warm} warm-ups; {t:.2f} s/step'}
 
 
 def self_launch(args):
@@ -213,12 +287,9 @@ def main():
     torch.manual_seed(6)
     st = synthetic_settings(args.trainer, 'DSEC_events', (args.height, args.width), args.classes, args.batch, args.T, args.C,
                             device_index=dev_index)
-    if args.trainer == 'ess':
-        from ess_amd.training.ess_trainer import ESSModel
-        trainer = ESSModel(st)
-    else:
-        from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
-        trainer = ESSSupervisedModel(st)
+    from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
+    from ess_amd.training.ess_trainer import ESSModel
+    trainer = ESSModel(st) if args.trainer == 'ess' else ESSSupervisedModel(st)
     ev, img, lab_a, lab_b = make_batch(args.batch, args.T, args.C, args.height, args.width, args.classes,
                                        seed=1000 + rank, device=device)
     batch = [[img, lab_a], [ev, lab_b]] if args.trainer == 'ess' else [ev, lab_b]
@@ -242,25 +313,59 @@ def main():
         elapsed = t.item()
     final_loss = float(out[-1])
 
+    extra = {}
+    if world == 1 and args.compute == 'bf16' and not args.no_fp32_extra:
+        # the parity-grade configuration next to the headline one: the SAME step in exact-fp32 arithmetic (fp32 MFMA, fp32 NCHW
+        # tensors; logits within 1e-3 / argmax-exact / mIoU within 1e-4 of the oracle: tests/test_hip_modules.py), 1 warm-up + 3 steps
+        del trainer
+        torch.cuda.empty_cache()
+        hip.set_compute('fp32')
+        torch.manual_seed(6)
+        tr32 = ESSModel(st) if args.trainer == 'ess' else ESSSupervisedModel(st)
+        tr32.train_step(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            tr32.train_step(batch)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t1) / 3 * 1e3
+        extra['fp32_ms_per_step'] = round(ms32, 3)
+        extra['fp32_voxel_grids_per_s'] = round(args.batch * args.T / ms32 * 1e3, 2)
+        del tr32
+        torch.cuda.empty_cache()
+        hip.set_compute(args.compute)
+
     result = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         grids = world * args.batch * args.T * args.steps / elapsed
+        bf16 = args.compute == 'bf16'
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        step_flops = executed_flops_per_step(args)
+        storage = ('activations and activation gradients of the decoder / image encoder stored as BF16_C8 only, BF16_C8 staging '
+                   'copies inside the frozen encoder; parameters, weight gradients (bf16 operands, fp32 accumulate / storage), norm '
+                   'statistics, recurrent cell state, losses and optimiser state fp32') if bf16 else 'all tensors fp32 NCHW'
         result = {
             'metric': 'UDA train-step throughput (voxel grids/s = N*B*T/step_time)' if args.trainer == 'ess'
             else 'supervised train-step throughput (voxel grids/s)',
             'value': round(grids, 2), 'unit': 'voxel_grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.compute == 'bf16' else 'f32',
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
             'data': 'synthetic', 'sequences_per_s': round(world * args.batch * args.steps / elapsed, 3),
             'final_loss': final_loss,
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
                                    f'{"DSEC" if args.width == 640 else "DDD17" if args.width == 352 else "custom"}-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
                                    f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
-                                   f'conv contractions {args.compute} (fp32 accumulate; tensors fp32 NCHW' + (', plus BF16_C8 staging copies inside the frozen encoder' if args.compute == 'bf16' else '') + '), weight gradients fp32',
-                       'global_batch': world * args.batch, 'parallelism': f'dp{world}'},
+                                   f'conv contractions {args.compute} MFMA operands, fp32 accumulate; {storage}',
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'ranks': world,
+                       'collective_backend': (dist.get_backend() if world > 1 else None)},
+            # whole step against the matrix-core peak: FLOPs of the launches the step issues (executed_flops_per_step) / step time
+            'step': {'flops_per_gpu': step_flops, 'tflops_per_gpu': round(step_flops / ms / 1e9, 1),
+                     'step_frac': round(step_flops / ms / 1e9 / peak, 4)},
         }
+        if extra:
+            result['extra'] = extra
         if not args.no_roofline:
-            result['roofline'] = roofline_gate_kernels(args, device)
+            result['roofline'] = roofline_blocks(args, device)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(result), flush=True)

@@ -22,6 +22,12 @@ def dev(t):
     return None if t is None else t.cuda().contiguous()
 
 
+def _un8(y, C):
+    """BF16_C8 [N, C/8, H, W, 8] -> fp32 NCHW on the host (plain torch)"""
+    N, nb, Hh, Ww, _ = y.shape
+    return y.cpu().permute(0, 1, 4, 2, 3).reshape(N, nb * 8, Hh, Ww)[:, :C].float().contiguous()
+
+
 def relerr(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return ((a - b).abs().max() / b.abs().max().clamp(min=1e-6)).item()
@@ -542,7 +548,7 @@ def test_conv_bf16_c8_sources_and_copy(H, case):
             outs.append((ho.cpu(), co.cpu(), hb.cpu()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
         for ho, _, hb in outs:
-            assert torch.equal(H.from_bf16_c8(hb, hid), ho.bfloat16().float())
+            assert torch.equal(_un8(hb, hid), ho.bfloat16().float())
     else:
         N, C, _, Cout, Hh, Ww, _ = case
         x = torch.randn(N, C, Hh, Ww, generator=g)
@@ -561,7 +567,7 @@ def test_conv_bf16_c8_sources_and_copy(H, case):
         ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1))
         assert relerr(outs[0][0], ref) < 1e-4
         for o, ob in outs:
-            assert torch.equal(H.from_bf16_c8(ob, Cout), o.bfloat16().float())
+            assert torch.equal(_un8(ob, Cout), o.bfloat16().float())
             assert not ob.view(N, -1, Hh, Ww, 8).float().permute(0, 1, 4, 2, 3).reshape(N, -1, Hh, Ww)[:, Cout:].any()  # zero tail
 
 
@@ -588,19 +594,26 @@ def test_conv5x5_paired_c8_sources(H, case):
     assert torch.equal(outs[0][0], outs[1][0])
     ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, stride=s, padding=2))
     assert relerr(outs[0][0], ref) < 1e-4
-    assert torch.equal(H.from_bf16_c8(outs[1][1], Cout), outs[1][0].bfloat16().float())
+    assert torch.equal(_un8(outs[1][1], Cout), outs[1][0].bfloat16().float())
 
 
 def test_bf16_c8_roundtrip_and_refusals(H):
     x = torch.randn(2, 13, 6, 10)
     y = H.to_bf16_c8(dev(x))
     assert y.shape == (2, 2, 6, 10, 8)
-    assert torch.equal(H.from_bf16_c8(y.cpu(), 13), x.bfloat16().float())
-    spec = H.conv_spec(1, 8, 8, 8, 0, 8, 1, 1, 0, compute=H.COMPUTE_BF16)   # 1x1: no BF16_C8 staging
-    w = H.pack_weights(spec, dev(torch.randn(8, 8, 1, 1)))
+    assert torch.equal(H.from_bf16_c8(y, 13).cpu(), x.bfloat16().float())
+    assert torch.equal(_un8(y, 13), x.bfloat16().float())  # the device kernel and the host view agree
+    spec = H.conv_spec(1, 8, 8, 8, 0, 8, 7, 1, 3, compute=H.COMPUTE_BF16)   # 7x7: no BF16_C8 staging
+    w = H.pack_weights(spec, dev(torch.randn(8, 8, 7, 7)))
     with pytest.raises(H.EssHipError):
         H.conv_forward(spec, H.to_bf16_c8(dev(torch.randn(1, 8, 8, 8))), None, w, out=torch.empty(1, 8, 8, 8, device='cuda'),
                        src_fmt=H.FMT_BF16_C8)
+    with pytest.raises(H.EssHipError):  # a BF16_C8 residual needs a BF16_C8 output
+        sp3 = H.conv_spec(1, 8, 8, 8, 0, 8, 3, 1, 1, compute=H.COMPUTE_BF16)
+        _check_desc = sp3.desc_fmt(H.FMT_BF16_C8, H.FMT_F32_NCHW, H.FMT_BF16_C8)
+        rc = H.lib().ess_conv2d_plan(__import__('ctypes').byref(_check_desc), __import__('ctypes').byref(H.EssConvPlan()))
+        if rc != 0:
+            raise H.EssHipError(H.lib().ess_last_error().decode())
     spec32 = H.conv_spec(1, 8, 8, 8, 0, 8, 3, 1, 1, compute=H.COMPUTE_FP32)  # fp32 compute: no copy
     w32 = H.pack_weights(spec32, dev(torch.randn(8, 8, 3, 3)))
     with pytest.raises(H.EssHipError):

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Launch set for the HBM-traffic PMC passes (tools/pmc_traffic.py): at the bench shape (B=8, 480x640, bf16 configuration)
+  * the 7 distinct plain 3x3 convolutions of one decoder forward, BF16_C8 in / out, exactly as the product issues them
+    (REPS launches each, in the order of bench.decoder_conv3x3_layers);
+  * the fused ConvLSTM step on the three encoder levels (BF16_C8 sources, BF16_C8 copy of h').
+Prints the launch plan as JSON on the last line: pmc_traffic.py maps the profiler's dispatch sequence back onto it."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ess_amd import hip  # noqa: E402
+
+REPS = 4
+hip.lib()
+hip.set_compute('bf16')
+args = bench.parse() if False else type('A', (), dict(batch=8, height=480, width=640))()
+dev = torch.device('cuda', 0)
+B = args.batch
+g = torch.Generator().manual_seed(0)
+plan = []
+
+
+def act(C, H, W):
+    return hip.to_bf16_c8(torch.randn(B, C, H, W, generator=g).to(dev))
+
+
+for (C0, C1, Cout, Hv, Wv, m0, cnt) in bench.decoder_conv3x3_layers(args):
+    spec = hip.conv_spec(B, Hv, Wv, C0, C1, Cout, 3, 1, 1, hip.SRC_NEAREST_UP2 if m0 else hip.SRC_DIRECT, hip.SRC_DIRECT)
+    x0 = act(C0, Hv // (2 if m0 else 1), Wv // (2 if m0 else 1))
+    x1 = act(C1, Hv, Wv) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5).to(dev)
+    pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(Cout, generator=g).to(dev))
+    out = hip.bf16_c8_empty(B, Cout, Hv, Wv, dev)
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        hip.conv_forward(spec, x0, x1, pw, None, pb, out=out, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)
+    torch.cuda.synchronize()
+    px_in = B * (C0 * (Hv * Wv // (4 if m0 else 1)) + C1 * Hv * Wv)
+    plan.append({'group': 'conv3x3', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
+                 'count': cnt, 'reps': REPS, 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 2 * 9 * (C0 + C1) * Cout,
+                 'flops': 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout})
+    del x0, x1, out
+for lvl, hid in enumerate((64, 128, 256)):
+    H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
+    spec = hip.conv_spec(B, H, W, hid, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
+    w = (torch.randn(4 * hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(dev)
+    pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(4 * hid, generator=g).to(dev))
+    x, h = act(hid, H, W), act(hid, H, W)
+    c = torch.randn(B, hid, H, W, generator=g).to(dev)
+    ho, co, hb = torch.empty_like(c), torch.empty_like(c), hip.bf16_c8_empty(B, hid, H, W, dev)
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, out_bf=hb, src_fmt=hip.FMT_BF16_C8)
+    torch.cuda.synchronize()
+    n = B * hid * H * W
+    plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS,
+                 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 4 + 2) * n + 2 * 9 * 2 * hid * 4 * hid,
+                 'flops': 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)})
+print('PLAN ' + json.dumps(plan))
