@@ -181,6 +181,19 @@ def test_uda_steps_vs_golden(golden, branch):
             assert int(sdf['encoder_scale_1.1.num_batches_tracked']) == 2
 
 
+def _miou_bound(conf_ref, n_moved):
+    """How far mean IoU can move when `n_moved` pixels change their predicted class: a pixel leaving class a for class b changes
+    either the intersection or the union of each of the two classes by one, i.e. each of the two IoUs by at most
+    1 / (U - n_moved); mIoU averages over the K classes (absent classes count with IoU 0 on both sides)."""
+    c = conf_ref.double().cpu()
+    union = c.sum(0) + c.sum(1) - c.diag()
+    present = union[union > 0]
+    if n_moved == 0 or present.numel() == 0:
+        return 1e-12
+    u_min = max(present.min().item() - n_moved, 1.0)
+    return 2.0 * n_moved / (c.shape[0] * u_min)
+
+
 def _conf_close(got, ref, max_moved):
     """Confusion matrices of two fp32 implementations differ only where a pixel's top-2 logits tie to within rounding
     (random-weight logits are nearly flat): every label row keeps its exact count, at most `max_moved` pixels change
@@ -223,7 +236,10 @@ def test_uda_val_steps_vs_golden(golden, branch):
     for name, m in (('a', tr.metrics_semseg_a), ('b', tr.metrics_semseg_b), ('cycle', tr.metrics_semseg_cycle)):
         ms, ref = m.get_metrics_summary(), run['metrics_' + name]
         assert _conf_close(ms['cm'], ref['cm'], max(2, npix // 200)), (name, ms['cm'], ref['cm'])
-        assert abs(float(ms['mean_iou']) - float(ref['miou'])) < 0.5 and abs(float(ms['acc']) - float(ref['acc'])) < 0.5
+        # mIoU / accuracy: as far as the pixels that changed column can move them, no further
+        moved = int((ms['cm'].cpu().long() - ref['cm'].cpu().long()).abs().sum()) // 2
+        assert abs(float(ms['mean_iou']) - float(ref['miou'])) <= _miou_bound(ref['cm'], moved) + 1e-6, (name, moved)
+        assert abs(float(ms['acc']) - float(ref['acc'])) <= moved / max(int(ref['cm'].sum()), 1) + 1e-6, (name, moved)
     # the BatchNorm running statistics were only read
     sdf = tr.front_end_sensor_a.state_dict()
     assert int(sdf['encoder_scale_1.1.num_batches_tracked']) == 0
@@ -318,7 +334,11 @@ def test_config2_ddd17_shape_parity_vs_oracle():
           f'min margin at mismatches={(margin[mism].min().item() if mism.any() else float("nan")):.2e}')
     miou_ref = O.miou_acc(ref_conf)[0].item()
     miou = O.miou_acc(conf.cpu())[0].item()
-    assert abs(miou - miou_ref) < 1e-4 or int(mism.sum()) > 0
+    # mIoU: exact (1e-4 of BASELINE.json) when no pixel flipped; otherwise bounded by what the flipped tie pixels can move
+    n_tie = int((margin <= 2 * err).sum())
+    n_flip = int(mism.sum())
+    assert n_flip <= n_tie
+    assert abs(miou - miou_ref) <= (1e-4 if n_flip == 0 else min(1e-4 + _miou_bound(ref_conf, n_flip), 1e-2)), (miou, miou_ref, n_flip)
 
 
 def test_config3_bf16_vs_oracle_and_bf16_reference():
