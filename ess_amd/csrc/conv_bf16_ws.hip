@@ -20,7 +20,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   constexpr int KPC = kpc(3, 1);
   constexpr int WSZ = KS * KS * CB8 * COT;
   constexpr int WV = (WSZ + 255) / 256;
-  const int role = threadIdx.x >> 8;  // 0: consumer (MFMA), 1: producer (staging) -- wave-uniform
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);  // 0: consumer (MFMA), 1: producer (staging): a scalar (wave-uniform) value
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
@@ -64,10 +64,14 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       v_keep0[k] = in0 ? 0xffffffffu : 0u;
       v_keep1[k] = in1 ? 0xffffffffu : 0u;
     }
-    u32x4 pre[CB8][KPC];
-    u32x4 wpre[WV];
+    // Two chunks of loads in flight in two register sets: a load issued in iteration ch is committed to LDS in iteration
+    // ch + 2.  With BF16_C8 sources the producer is a pure load -> ds_write pipe (no conversion), and under full-machine load
+    // the L2 round trip exceeds one chunk of matrix work: with a single set the consumers waited at the barrier for the
+    // producers' vmcnt.
+    struct Set { u32x4 pre[CB8][KPC]; u32x4 wpre[WV]; };
+    Set sa, sb;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
-    auto load_chunk = [&](int ch) {
+    auto load_chunk = [&](int ch, Set& r) {
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;                 // wave-uniform
@@ -75,13 +79,13 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
         const int bi = (first ? c0 : c0 - a.C0) >> 3, nbs = first ? nb0 : nb1;
         const u32x4* sp = (first ? s0 : s1) + (size_t)(bi < nbs ? bi : 0) * (first ? hw0 : hw1);  // blocks past the end: clamped, masked
 #pragma unroll
-        for (int k = 0; k < KPC; ++k) pre[cb][k] = sp[first ? v_pos0[k] : v_pos1[k]];
+        for (int k = 0; k < KPC; ++k) r.pre[cb][k] = sp[first ? v_pos0[k] : v_pos1[k]];
       }
       const u32x4* wsrc = wbase + (size_t)ch * WSZ;
 #pragma unroll
-      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; r.wpre[it] = wsrc[i < WSZ ? i : 0]; }
     };
-    auto commit = [&](int ch, int buf) {
+    auto commit = [&](int ch, int buf, const Set& r) {
       u32x4* in_t = smem16 + buf * bufsz;
       u32x4* w_t = in_t + CB8 * a.plane;
 #pragma unroll
@@ -92,24 +96,47 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #pragma unroll
         for (int k = 0; k < KPC; ++k) {
           const unsigned m = (first ? v_keep0[k] : v_keep1[k]) & blk_ok;
-          u32x4 v = pre[cb][k];
+          u32x4 v = r.pre[cb][k];
           v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
           if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = v;
         }
       }
 #pragma unroll
-      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
     };
-    load_chunk(0);
-    commit(0, 0);
-    if (a.n_chunks > 1) load_chunk(1);
-    __syncthreads();  // stage 0 is ready
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
-      if (ch + 1 < a.n_chunks) {
-        commit(ch + 1, (ch + 1) & 1);
-        if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+    const int nch = a.n_chunks;
+    if (a.deep) {
+      load_chunk(0, sa);
+      if (nch > 1) load_chunk(1, sb);
+      commit(0, 0, sa);
+      if (nch > 2) load_chunk(2, sa);
+      __syncthreads();  // stage 0 is ready
+      for (int ch = 0; ch < nch; ch += 2) {
+        if (ch + 1 < nch) {
+          commit(ch + 1, 1, sb);
+          if (ch + 3 < nch) load_chunk(ch + 3, sb);
+        }
+        __syncthreads();
+        if (ch + 1 < nch) {
+          if (ch + 2 < nch) {
+            commit(ch + 2, 0, sa);
+            if (ch + 4 < nch) load_chunk(ch + 4, sa);
+          }
+          __syncthreads();
+        }
       }
-      __syncthreads();
+    } else {
+      load_chunk(0, sa);
+      commit(0, 0, sa);
+      if (nch > 1) load_chunk(1, sa);
+      __syncthreads();  // stage 0 is ready
+      for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) {
+          commit(ch + 1, (ch + 1) & 1, sa);
+          if (ch + 2 < nch) load_chunk(ch + 2, sa);
+        }
+        __syncthreads();
+      }
     }
     return;
   }
@@ -203,6 +230,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   __syncthreads();  // stage 0 is ready
+  // the matrix waves take issue priority over the staging waves that share their SIMDs (s_setprio is a scalar instruction that
+  // ignores EXEC: `role` is a readfirstlane value, so only consumer waves reach this point)
+  __builtin_amdgcn_s_setprio(1);
   for (int ch = 0; ch < a.n_chunks; ++ch) {
     const u32x4* in_t = smem16 + (ch & 1) * bufsz;
     const u32x4* w_t = in_t + CB8 * a.plane;
@@ -229,6 +259,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     }
     __syncthreads();
   }
+  __builtin_amdgcn_s_setprio(0);
   conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
 }
 

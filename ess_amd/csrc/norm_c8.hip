@@ -73,11 +73,17 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
   float s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  // all loads of the plane are issued back to back from clamped (always valid) addresses: a load under a per-lane condition
+  // would be waited for inside its branch, one memory round trip per vector
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    xv[k] = x[base + (i < hw ? i : hw - 1)];
+  }
 #pragma unroll
   for (int k = 0; k < MV; ++k) {
     const int i = threadIdx.x + k * THREADS;
     if (i < hw) {
-      xv[k] = x[base + i];
       float f[8];
       unpack8(xv[k], f);
 #pragma unroll
@@ -109,21 +115,33 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
     stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x)] = m;
     stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x) + 1] = r;
   }
+  constexpr int RB = THREADS == 1024 ? 1 : 5;  // residual vectors in flight per batch (register budget)
 #pragma unroll
-  for (int k = 0; k < MV; ++k) {
-    const int i = threadIdx.x + k * THREADS;
-    if (i < hw) {
-      float f[8], rf[8];
-      unpack8(opaque(xv[k]), f);
-      if (res) unpack8(res[base + i], rf);
+  for (int k0 = 0; k0 < MV; k0 += RB) {
+    u32x4n rv[RB];
+    if (res) {  // (uniform)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = (f[j] - mean[j]) * rstd[j];
-        if (relu) t = fmaxf(t, 0.f);
-        if (res) t += rf[j];
-        f[j] = cb * 8 + j < C ? t : 0.f;
+      for (int u = 0; u < RB; ++u) {
+        const int i = threadIdx.x + (k0 + u) * THREADS;
+        if (k0 + u < MV) rv[u] = res[base + (i < hw ? i : hw - 1)];
       }
-      y[base + i] = pack8n(f);
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int k = k0 + u, i = threadIdx.x + k * THREADS;
+      if (k < MV && i < hw) {
+        float f[8], rf[8];
+        unpack8(opaque(xv[k]), f);
+        if (res) unpack8(rv[u], rf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = (f[j] - mean[j]) * rstd[j];
+          if (relu) t = fmaxf(t, 0.f);
+          if (res) t += rf[j];
+          f[j] = cb * 8 + j < C ? t : 0.f;
+        }
+        y[base + i] = pack8n(f);
+      }
     }
   }
 }
@@ -147,11 +165,15 @@ __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
+  for (int k = 0; k < MAXV; ++k) {  // (unconditional loads from clamped addresses: see in_fwd_c8_kernel)
+    const int i = threadIdx.x + k * 256;
+    xv[k] = x[base + (i < hw ? i : hw - 1)];
+    gv[k] = dy[base + (i < hw ? i : hw - 1)];
+  }
+#pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int i = threadIdx.x + k * 256;
     if (i < hw) {
-      xv[k] = x[base + i];
-      gv[k] = dy[base + i];
       float f[8], gg[8];
       unpack8(xv[k], f);
       unpack8(gv[k], gg);
@@ -213,25 +235,40 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
   double s0[8], s1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s0[j] = 0; s1[j] = 0; }
+  constexpr int U = MODE == 0 ? 4 : 2;  // vectors per tensor in flight per thread
   for (int sgm = 0; sgm < nseg; ++sgm) {
     const size_t base = ((size_t)sgm * seg_stride + g) * hw;
-    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
-      float f[8];
-      unpack8(x[base + i], f);
-      if (MODE == 0) {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256 * U) {
+      u32x4n xv[U], gv[U], yv[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += (double)f[j] * f[j]; }
-      } else {
-        float gg[8], yy[8];
-        unpack8(dy[base + i], gg);
-        if (relu && relu_from_y) unpack8(y[base + i], yy);
+      for (int u = 0; u < U; ++u) {  // clamped addresses: the loads carry no per-lane branch and are all in flight together
+        const int ii = i + u * 256, ic = ii < i1 ? ii : i1 - 1;
+        xv[u] = x[base + ic];
+        if (MODE == 1) {
+          gv[u] = dy[base + ic];
+          if (relu && relu_from_y) yv[u] = y[base + ic];
+        }
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (f[j] - mean[j]) * rstd[j];
-          const bool off = relu && (relu_from_y ? yy[j] <= 0.f : xh <= 0.f);
-          const float gr = off ? 0.f : gg[j];
-          s0[j] += gr;
-          s1[j] += (double)gr * xh;
+      for (int u = 0; u < U; ++u) {
+        if (i + u * 256 >= i1) continue;
+        float f[8];
+        unpack8(xv[u], f);
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += (double)f[j] * f[j]; }
+        } else {
+          float gg[8], yy[8];
+          unpack8(gv[u], gg);
+          if (relu && relu_from_y) unpack8(yv[u], yy);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (f[j] - mean[j]) * rstd[j];
+            const bool off = relu && (relu_from_y ? yy[j] <= 0.f : xh <= 0.f);
+            const float gr = off ? 0.f : gg[j];
+            s0[j] += gr;
+            s1[j] += (double)gr * xh;
+          }
         }
       }
     }
@@ -281,18 +318,32 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
       if (cb * 8 + j < C) { stats[2 * ((size_t)n * C + cb * 8 + j)] = mean[j]; stats[2 * ((size_t)n * C + cb * 8 + j) + 1] = rstd[j]; }
   }
   const size_t base = (size_t)g * hw;
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
-    float f[8], rf[8];
-    unpack8(x[base + i], f);
-    if (res) unpack8(res[base + i], rf);
+  constexpr int U = 4;
+  const int stride = gridDim.y * 256;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
+    u32x4n xv[U], rv[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = (f[j] - mean[j]) * rstd[j];
-      if (relu) t = fmaxf(t, 0.f);
-      if (res) t += rf[j];
-      f[j] = cb * 8 + j < C ? t : 0.f;
+    for (int u = 0; u < U; ++u) {  // clamped, unconditional: all in flight together
+      const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
+      xv[u] = x[base + ic];
+      if (res) rv[u] = res[base + ic];
     }
-    y[base + i] = pack8n(f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride;
+      if (ii >= hw) continue;
+      float f[8], rf[8];
+      unpack8(xv[u], f);
+      if (res) unpack8(rv[u], rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (f[j] - mean[j]) * rstd[j];
+        if (relu) t = fmaxf(t, 0.f);
+        if (res) t += rf[j];
+        f[j] = cb * 8 + j < C ? t : 0.f;
+      }
+      y[base + ii] = pack8n(f);
+    }
   }
 }
 
@@ -312,17 +363,31 @@ __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __re
     m2[j] = (float)(t1[j] / hw);
   }
   const size_t base = (size_t)g * hw;
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
-    float f[8], gg[8];
-    unpack8(x[base + i], f);
-    unpack8(dy[base + i], gg);
+  constexpr int U = 3;
+  const int stride = gridDim.y * 256;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
+    u32x4n xv[U], gv[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (f[j] - mean[j]) * rstd[j];
-      const float gr = (relu && xh <= 0.f) ? 0.f : gg[j];
-      f[j] = cb * 8 + j < C ? rstd[j] * (gr - m1[j] - xh * m2[j]) : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
+      xv[u] = x[base + ic];
+      gv[u] = dy[base + ic];
     }
-    dx[base + i] = pack8n(f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride;
+      if (ii >= hw) continue;
+      float f[8], gg[8];
+      unpack8(xv[u], f);
+      unpack8(gv[u], gg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (f[j] - mean[j]) * rstd[j];
+        const float gr = (relu && xh <= 0.f) ? 0.f : gg[j];
+        f[j] = cb * 8 + j < C ? rstd[j] * (gr - m1[j] - xh * m2[j]) : 0.f;
+      }
+      dx[base + ii] = pack8n(f);
+    }
   }
 }
 
@@ -356,18 +421,32 @@ __global__ __launch_bounds__(256) void bn_apply_c8_kernel(const u32x4n* __restri
     b[j] = beta[c] - mean * a[j];
   }
   const size_t base = (size_t)g * hw;
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
-    float f[8], rf[8];
-    unpack8(x[base + i], f);
-    if (res) unpack8(res[base + i], rf);
+  constexpr int U = 4;
+  const int stride = gridDim.y * 256;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
+    u32x4n xv[U], rv[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = f[j] * a[j] + b[j];
-      if (res) t += rf[j];
-      if (relu) t = fmaxf(t, 0.f);
-      f[j] = cb * 8 + j < C ? t : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
+      xv[u] = x[base + ic];
+      if (res) rv[u] = res[base + ic];
     }
-    y[base + i] = pack8n(f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride;
+      if (ii >= hw) continue;
+      float f[8], rf[8];
+      unpack8(xv[u], f);
+      if (res) unpack8(rv[u], rf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = f[j] * a[j] + b[j];
+        if (res) t += rf[j];
+        if (relu) t = fmaxf(t, 0.f);
+        f[j] = cb * 8 + j < C ? t : 0.f;
+      }
+      y[base + ii] = pack8n(f);
+    }
   }
 }
 
@@ -395,20 +474,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
     gr[j] = gamma[c] * rstd[j];
   }
   const size_t base = (size_t)g * hw;
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) {
-    float gg[8], yy[8], f[8];
-    unpack8(dy[base + i], gg);
-    if (relu) {
-      unpack8(y[base + i], yy);
+  constexpr int U = 2;
+  const int stride = gridDim.y * 256;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
+    u32x4n gv[U], yv[U], xv[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (yy[j] <= 0.f) gg[j] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
+      gv[u] = dy[base + ic];
+      if (relu) yv[u] = y[base + ic];
+      if (dx) xv[u] = x[base + ic];
     }
-    if (dres) dres[base + i] = pack8n(gg);
-    if (dx) {
-      unpack8(x[base + i], f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? gr[j] * (gg[j] - m1[j] - (f[j] - mean[j]) * rstd[j] * m2[j]) : 0.f;
-      dx[base + i] = pack8n(f);
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride;
+      if (ii >= hw) continue;
+      float gg[8], yy[8], f[8];
+      unpack8(gv[u], gg);
+      if (relu) {
+        unpack8(yv[u], yy);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (yy[j] <= 0.f) gg[j] = 0.f;
+      }
+      if (dres) dres[base + ii] = pack8n(gg);
+      if (dx) {
+        unpack8(xv[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? gr[j] * (gg[j] - m1[j] - (f[j] - mean[j]) * rstd[j] * m2[j]) : 0.f;
+        dx[base + ii] = pack8n(f);
+      }
     }
   }
 }
