@@ -14,6 +14,27 @@ _pack_cache = {}
 # (a view of the optimiser's flat gradient buffer) instead of materialising dW and letting AccumulateGrad add it.
 DIRECT_GRAD_ACCUM = False
 
+class direct_grad_accum:
+    """with direct_grad_accum(False): ...  -- the weight-gradient functions return dW / db to autograd as usual (needed under
+    torch.autograd.grad() or with gradient hooks); the default inside the trainers is direct accumulation into `.grad`."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global DIRECT_GRAD_ACCUM
+        self.prev, DIRECT_GRAD_ACCUM = DIRECT_GRAD_ACCUM, self.on
+
+    def __exit__(self, *a):
+        global DIRECT_GRAD_ACCUM
+        DIRECT_GRAD_ACCUM = self.prev
+
+
+def _direct(p):
+    """may the gradient of leaf `p` be added straight into p.grad?  (an optimiser of ours owns it and the switch is on)"""
+    return DIRECT_GRAD_ACCUM and getattr(p, '_ess_direct_grad', False) and p.is_leaf and p.grad is not None and p.grad.is_contiguous()
+
+
 # Set by training.distributed.GradAllReducer.arm(): called with a parameter as soon as the launch that completes its gradient
 # in the running backward pass has been issued (bucketed gradient all-reduce overlapped with the rest of the backward).
 GRAD_READY_HOOK = None
@@ -261,11 +282,10 @@ class Conv2dFn(torch.autograd.Function):
             if need1:
                 d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
         s2_1x1 = s == 2 and k == 1 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1)
-        direct = DIRECT_GRAD_ACCUM and needw and weight.is_leaf and weight.grad is not None and weight.grad.is_contiguous() \
-            and not (s == 2 and k == 3)
+        direct = needw and _direct(weight) and not (s == 2 and k == 3)
         if direct:
             bias = ctx.bias_ref() if ctx.bias_ref is not None else None
-            db_t = bias.grad if (needb and bias is not None and bias.grad is not None and bias.grad.is_contiguous()) else None
+            db_t = bias.grad if (needb and bias is not None and _direct(bias)) else None
             if needb and db_t is None:
                 direct = False
         if direct:
@@ -386,8 +406,7 @@ class BatchNormTrainFn(torch.autograd.Function):
             bwd = lambda *a, **k: hip.batchnorm_train_backward(x, *a, **k)  # noqa: E731
         # like the conv weight gradients: add straight into the leaves' .grad (views of the optimiser's flat buffer)
         # instead of returning two C-element tensors for AccumulateGrad to add with one tiny launch each
-        direct = DIRECT_GRAD_ACCUM and need_g and need_b and beta is not None and gamma.is_leaf and beta.is_leaf and \
-            gamma.grad is not None and beta.grad is not None and gamma.grad.is_contiguous() and beta.grad.is_contiguous()
+        direct = need_g and need_b and beta is not None and _direct(gamma) and _direct(beta)
         if direct:
             dx, dres = bwd(y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, gamma.grad, beta.grad, accumulate=True)
             return dx, dres, None, None, None, None, None, None, None

@@ -26,7 +26,13 @@ class RAdam(Optimizer):
             raise NotImplementedError('weight_decay is always 0. in the ESS trainers (training/ess_trainer.py:91,99)')
         self._step = 0
         self._flatten()
-        _fn.DIRECT_GRAD_ACCUM = True  # gradients accumulate straight into the flat buffer's views
+        # gradients of these parameters accumulate straight into the flat buffer's views: the weight-gradient kernels add into
+        # `.grad` themselves (functional.Conv2dFn / BatchNormTrainFn) instead of returning dW for AccumulateGrad.  Scoped to the
+        # parameters of this optimiser by a per-tensor marker; functional.direct_grad_accum(False) switches it off for callers
+        # that need the gradients returned (torch.autograd.grad, hooks).
+        for p in self.param_groups[0]['params']:
+            p._ess_direct_grad = True
+        _fn.DIRECT_GRAD_ACCUM = True
 
     def _flatten(self):
         ps = [p for p in self.param_groups[0]['params']]
@@ -94,13 +100,60 @@ class RAdam(Optimizer):
         return loss
 
     def state_dict(self):
+        """torch.optim layout -- param_groups + per-parameter state {step, exp_avg, exp_avg_sq} as the reference's RAdam keeps it
+        (utils/radam.py:31-47; the tensors are views of the flat buffers) -- plus the flat buffers themselves under 'flat'."""
         sd = super().state_dict()
+        state, off = {}, 0
+        for i, k in enumerate(self._sizes):
+            shape = self.param_groups[0]['params'][i].shape
+            state[i] = {'step': self._step, 'exp_avg': self.exp_avg[off:off + k].view(shape),
+                        'exp_avg_sq': self.exp_avg_sq[off:off + k].view(shape)}
+            off += k
+        sd['state'] = state
         sd['flat'] = {'step': self._step, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq}
         return sd
 
     def load_state_dict(self, state_dict):
+        """Accepts this class's own checkpoints ('flat') and the reference's per-parameter layout (an `Epoch_N.pt` written by
+        the reference's RAdam: state[idx] = {step, exp_avg, exp_avg_sq}); param_groups (lr, betas, eps) are restored either
+        way.  Anything else is refused instead of silently resetting the moments."""
+        groups = state_dict.get('param_groups')
+        if groups:
+            if len(groups) != 1 or len(groups[0].get('params', [])) != len(self._sizes):
+                raise ValueError('RAdam.load_state_dict: parameter group layout does not match this optimiser')
+            for key in ('lr', 'betas', 'eps', 'weight_decay'):
+                if key in groups[0]:
+                    self.param_groups[0][key] = groups[0][key]
         flat = state_dict.get('flat')
         if flat is not None:
-            self._step = flat['step']
+            if flat['exp_avg'].numel() != self.exp_avg.numel():
+                raise ValueError('RAdam.load_state_dict: flat buffers of a different model')
+            self._step = int(flat['step'])
             self.exp_avg.copy_(flat['exp_avg'])
             self.exp_avg_sq.copy_(flat['exp_avg_sq'])
+            return
+        state = state_dict.get('state')
+        if state is None:
+            raise ValueError("RAdam.load_state_dict: neither 'flat' nor per-parameter 'state' in the checkpoint")
+        if len(state) == 0:  # a checkpoint taken before the first step
+            self._step = 0
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            return
+        steps, off = set(), 0
+        with torch.no_grad():
+            for i, k in enumerate(self._sizes):
+                st = state.get(i, state.get(str(i)))
+                if st is None:  # the reference skips parameters that never received a gradient
+                    self.exp_avg[off:off + k].zero_()
+                    self.exp_avg_sq[off:off + k].zero_()
+                else:
+                    if st['exp_avg'].numel() != k:
+                        raise ValueError(f'RAdam.load_state_dict: parameter {i} has {k} elements, checkpoint {st["exp_avg"].numel()}')
+                    self.exp_avg[off:off + k].copy_(st['exp_avg'].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st['exp_avg_sq'].reshape(-1))
+                    steps.add(int(st['step']))
+                off += k
+        if len(steps) > 1:
+            raise ValueError(f'RAdam.load_state_dict: per-parameter step counts differ ({sorted(steps)}); the flat kernel keeps one')
+        self._step = steps.pop() if steps else 0

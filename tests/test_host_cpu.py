@@ -321,3 +321,32 @@ def test_voxel_api_mirrors_reference_and_refuses_cpu(built_lib):
     ws = lib.ess_voxel_grid_trilinear_workspace(4_000_000, 40, 480, 640)
     assert 4_000_000 * 16 <= ws < 4_000_000 * 16 + (32 << 20)  # sorted events + per-tile tables (halo table sized for 7 channels)
     assert lib.ess_voxel_grid_trilinear_workspace(0, 40, 480, 640) == 0
+
+
+def test_radam_state_dict_interop():
+    """RAdam.state_dict() carries the reference's per-parameter layout (utils/radam.py:31-47) next to the flat
+    buffers; load_state_dict() restores from either, restores param_groups, and refuses anything else."""
+    from ess_amd.utils.radam import RAdam
+    mk = lambda: [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]  # noqa: E731
+    a = RAdam(mk(), lr=1e-3, betas=(0.0, 0.999))
+    a._step = 7
+    a.exp_avg.copy_(torch.arange(17.0))
+    a.exp_avg_sq.copy_(torch.arange(17.0) * 2)
+    sd = a.state_dict()
+    assert set(sd['state']) == {0, 1} and sd['state'][0]['exp_avg'].shape == (4, 3) and sd['state'][1]['step'] == 7
+    b = RAdam(mk(), lr=5e-4, betas=(0.0, 0.999))
+    b.load_state_dict(sd)
+    assert b._step == 7 and torch.equal(b.exp_avg, a.exp_avg) and b.param_groups[0]['lr'] == 1e-3
+    # the reference's own checkpoint layout: per-parameter state only
+    ref_sd = {'state': {0: {'step': 3, 'exp_avg': torch.ones(4, 3), 'exp_avg_sq': torch.full((4, 3), 2.0)},
+                        1: {'step': 3, 'exp_avg': torch.zeros(5), 'exp_avg_sq': torch.ones(5)}},
+              'param_groups': [{'lr': 2e-3, 'betas': (0.0, 0.999), 'eps': 1e-8, 'weight_decay': 0, 'params': [0, 1]}]}
+    c = RAdam(mk(), lr=5e-4, betas=(0.0, 0.999))
+    c.load_state_dict(ref_sd)
+    assert c._step == 3 and c.param_groups[0]['lr'] == 2e-3
+    assert torch.equal(c.exp_avg[:12], torch.ones(12)) and torch.equal(c.exp_avg_sq[12:], torch.ones(5))
+    with pytest.raises(ValueError):
+        c.load_state_dict({'param_groups': ref_sd['param_groups']})
+    with pytest.raises(ValueError):
+        bad = {'state': {0: dict(ref_sd['state'][0], step=4), 1: ref_sd['state'][1]}, 'param_groups': ref_sd['param_groups']}
+        c.load_state_dict(bad)
