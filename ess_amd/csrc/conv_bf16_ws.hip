@@ -12,7 +12,10 @@ using namespace essconv;
 // shadow of the matrix pipe instead of in front of it.  LDS is double-buffered; ONE barrier per channel chunk:
 //   iteration ch: consumers read buffer ch&1 | producers convert+write chunk ch+1 into buffer (ch+1)&1 (its last
 //   readers passed the previous barrier) and then issue the loads of chunk ch+2, which land during iteration ch+1.
-template <int MB, int EPI, bool SRCBF>
+// OUT8: the output(s) are BF16_C8 tensors (LINEAR epilogue): an instantiation of its own that contains conv_epilogue_c8 and
+// nothing of the fp32 epilogue variants -- the all-variants kernel is ~57k instructions with ~300 spilled registers in its
+// epilogues, this one a tenth of that.
+template <int MB, int EPI, bool SRCBF, bool OUT8 = false>
 __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16;
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     Set sa, sb;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
     auto load_chunk = [&](int ch, Set& r) {
+      if (a.deep & 4) return;  // (ablation switch ESS_WS_ABL: no global loads)
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;                 // wave-uniform
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; r.wpre[it] = wsrc[i < WSZ ? i : 0]; }
     };
     auto commit = [&](int ch, int buf, const Set& r) {
+      if (a.deep & 16) return;  // (ablation: no LDS writes)
       u32x4* in_t = smem16 + buf * bufsz;
       u32x4* w_t = in_t + CB8 * a.plane;
 #pragma unroll
@@ -233,39 +238,78 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   // the matrix waves take issue priority over the staging waves that share their SIMDs (s_setprio is a scalar instruction that
   // ignores EXEC: `role` is a readfirstlane value, so only consumer waves reach this point)
   __builtin_amdgcn_s_setprio(1);
+  // ---- K loop.  The fragment reads of tap t+1 are issued BEFORE the MFMAs of tap t (register double buffer) and waited for
+  // with a counted lgkmcnt just before their own MFMAs.  hipcc undoes that order when it sees plain loads (it sinks each
+  // ds_read to just above its first use and waits for it there: one exposed LDS round trip per tap), so the reads and the
+  // waits are volatile asm statements -- the wait takes the fragments as in/out operands, which ties the MFMAs behind it.
+  // LDS byte addresses: A (weights) = one base + immediates; B (pixels) = one base per (pixel block, filter row).
+  const unsigned lds0 = (unsigned)(size_t)(smem16);  // (LDS address of the dynamic segment: its low 32 bits)
+  unsigned a_base = (unsigned)((half * COT + p) * 16);
+  unsigned b_base[NBW][KS];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) b_base[nb][ky] = (unsigned)((boff[nb] + ky * a.row_pitch) * 16);
+  const unsigned w_off = (unsigned)(CB8 * a.plane * 16), buf_bytes = (unsigned)(bufsz * 16);
+  struct Frags { u32x4 a[MB]; u32x4 b[NBW]; };
   for (int ch = 0; ch < a.n_chunks; ++ch) {
-    const u32x4* in_t = smem16 + (ch & 1) * bufsz;
-    const u32x4* w_t = in_t + CB8 * a.plane;
-    // fragments of tap t+1 are read from LDS while the MFMAs of tap t issue (register double buffer, fully unrolled)
-    bf16x8 af[2][MB], bfr[2][NBW];
-    auto read_tap = [&](int tap, int slot) {
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const u32x4* wp = w_t + (tap * CB8 + half) * COT + p;
-      const u32x4* ip = in_t + ky * a.row_pitch + kx;
+    const unsigned stage_b = lds0 + (ch & 1) * buf_bytes;
+    const unsigned wa = stage_b + w_off + a_base;
+    unsigned ba[NBW][KS];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) af[slot][mb] = __builtin_bit_cast(bf16x8, wp[mb * 32]);
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) bfr[slot][nb] = __builtin_bit_cast(bf16x8, ip[boff[nb]]);
-    };
-    read_tap(0, 0);
-#pragma unroll
-    for (int tap = 0; tap < KS * KS; ++tap) {
-      if (tap + 1 < KS * KS) read_tap(tap + 1, (tap + 1) & 1);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[tap & 1][mb], bfr[tap & 1][nb], acc[mb][nb], 0, 0, 0);
+      for (int ky = 0; ky < KS; ++ky) ba[nb][ky] = stage_b + b_base[nb][ky];
+    Frags f0, f1;
+#define ESS_READ_TAP(F_, TAP_)                                                                                                   \
+    {                                                                                                                            \
+      constexpr int ky_ = (TAP_) / KS, kx_ = (TAP_) % KS;                                                                        \
+      _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.a[mb]) : "v"(wa + (unsigned)(mb * 32 * 16)), "n"((TAP_) * CB8 * COT * 16)); \
+      _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                         \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.b[nb]) : "v"(ba[nb][ky_]), "n"(kx_ * 16));                       \
     }
+#define ESS_WAIT(F_, N_)                                                                                                         \
+    {                                                                                                                            \
+      if constexpr (MB == 1) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F_.a[0]), "+v"(F_.b[0]), "+v"(F_.b[1]) : "n"(N_));      \
+      else if constexpr (MB == 2) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F_.a[0]), "+v"(F_.a[MB > 1 ? 1 : 0]), "+v"(F_.b[0]), "+v"(F_.b[1]) : "n"(N_)); \
+      else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(F_.a[0]), "+v"(F_.a[MB > 1 ? 1 : 0]), "+v"(F_.a[MB > 2 ? 2 : 0]), "+v"(F_.a[MB > 3 ? 3 : 0]), "+v"(F_.b[0]), "+v"(F_.b[1]) : "n"(N_)); \
+    }
+#define ESS_MMA(F_)                                                                                                              \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                            \
+      _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                         \
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F_.a[mb]), __builtin_bit_cast(bf16x8, F_.b[nb]), acc[mb][nb], 0, 0, 0);
+    constexpr int NR = MB + NBW;  // LDS reads per tap
+    if (a.deep & 2) { __syncthreads(); continue; }  // (ablation: no fragment reads, no MFMAs)
+    ESS_READ_TAP(f0, 0)
+    ESS_READ_TAP(f1, 1) ESS_WAIT(f0, NR) ESS_MMA(f0)
+    ESS_READ_TAP(f0, 2) ESS_WAIT(f1, NR) ESS_MMA(f1)
+    ESS_READ_TAP(f1, 3) ESS_WAIT(f0, NR) ESS_MMA(f0)
+    ESS_READ_TAP(f0, 4) ESS_WAIT(f1, NR) ESS_MMA(f1)
+    ESS_READ_TAP(f1, 5) ESS_WAIT(f0, NR) ESS_MMA(f0)
+    ESS_READ_TAP(f0, 6) ESS_WAIT(f1, NR) ESS_MMA(f1)
+    ESS_READ_TAP(f1, 7) ESS_WAIT(f0, NR) ESS_MMA(f0)
+    ESS_READ_TAP(f0, 8) ESS_WAIT(f1, NR) ESS_MMA(f1)
+    ESS_WAIT(f0, 0) ESS_MMA(f0)
+#undef ESS_READ_TAP
+#undef ESS_WAIT
+#undef ESS_MMA
     __syncthreads();
   }
   __builtin_amdgcn_s_setprio(0);
-  conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  if (a.deep & 8) return;  // (ablation: no epilogue)
+  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly);
 }
 
 
 template <int MB, bool SRCBF>
 void launch_ws(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if (a.fmt_out == ESS_FMT_BF16_C8) {  // (validated: LINEAR epilogue)
+    ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, ESS_EPI_LINEAR, SRCBF, true>, lds);
+    hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, ESS_EPI_LINEAR, SRCBF, true>), grid, dim3(512), lds, st, a);
+    return;
+  }
 #define ESS_WS(E_) { ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>, lds); hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, E_, SRCBF>), grid, dim3(512), lds, st, a); }
   switch (epi) {
     case ESS_EPI_LSTM: ESS_WS(ESS_EPI_LSTM) break;

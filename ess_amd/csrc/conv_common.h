@@ -354,7 +354,9 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
   }
 }
 
-template <int MB, int EPI>
+// ALLOW8 = false: the caller dispatches BF16_C8 outputs to a dedicated kernel instantiation (conv_epilogue_c8 only: a fraction
+// of the code and registers of this function), so the run-time branch to it is left out here.
+template <int MB, int EPI, bool ALLOW8 = true>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                               int y0, const int (&ly)[NBW]) {
   constexpr int COT = MB * 32;
@@ -373,7 +375,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
     else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
-    if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB>(a, acc, ct, n, half, x, y0, ly); return; }
+    if constexpr (ALLOW8) {
+      if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB>(a, acc, ct, n, half, x, y0, ly); return; }
+    }
     const bool bare = a.act == ESS_ACT_NONE && !a.out_bf && a.out;
     if (a.act == ESS_ACT_SUMPOOL2) conv_epilogue_pool<MB>(a, acc, ct, n, half, x, y0, ly, plane_b);
     else if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
