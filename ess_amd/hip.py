@@ -43,7 +43,7 @@ EXPORTS = [
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
-    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8',
+    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label',
 ]
 
 
@@ -119,6 +119,7 @@ def lib():
             'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P, c_size_t, P],
             'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
+            'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -538,6 +539,19 @@ def l1_loss_c8(a, b, n_real, want_grad, scale=1.0):
     _check(lib().ess_l1_loss_c8(ptr(a, torch.bfloat16), ptr(b, torch.bfloat16), ptr(loss), ptr(da, torch.bfloat16), c_float(scale),
                                 a.numel() // 8, int(n_real), c_void_p(ws.data_ptr()), stream()), 'ess_l1_loss_c8')
     return loss, da
+
+
+def augment_image_label(img, label, params, height, width, id_lut=None):
+    """Batch augmentation in one launch (ess_augment_image_label).  img fp32 [N, Hs, Ws] on the 0..255 scale, label int64
+    [N, Hs, Ws] or None, params fp32 [N, 12] (datasets/augment.py draws them) -> (fp32 [N, 1, H, W] in [0, 1], int64 [N, H, W])."""
+    N, Hs, Ws = img.shape
+    if params.shape != (N, 12):
+        raise EssHipError('augment_image_label: params must be [N, 12]')
+    out = torch.empty(N, 1, height, width, dtype=torch.float32, device=img.device)
+    out_l = torch.empty(N, height, width, dtype=torch.int64, device=img.device) if label is not None else None
+    _check(lib().ess_augment_image_label(ptr(img), ptr(label, torch.int64), ptr(params), ptr(id_lut, torch.int64), ptr(out),
+                                         ptr(out_l, torch.int64), N, Hs, Ws, height, width, stream()), 'ess_augment_image_label')
+    return out, out_l
 
 
 def radam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_size, n_sma_ge5):

@@ -239,6 +239,17 @@ size_t ess_voxel_normalize_workspace(int32_t n_slices);
 int ess_voxel_normalize(float* grid, int32_t n_slices, int64_t elems_per_slice, int32_t mode, void* workspace,
                         size_t workspace_bytes, ess_stream_t stream);
 
+/* ---- image-branch augmentation on the device: the geometric + photometric core of the albumentations
+ * pipeline of datasets/cityscapes_loader.py:39-74 (HorizontalFlip, ShiftScaleRotate with rotate 0 and a constant-0 border,
+ * centred PadIfNeeded, RandomCrop, GaussNoise, RandomBrightnessContrast), uint8 quantisation, ToTensor (/255), and for the label
+ * map nearest sampling + the id -> trainId table of utils/labels.py:123-127 -- a whole batch in one launch.
+ * img: fp32 [N][H_src][W_src] on the 0..255 scale; label (nullable): int64 [N][H_src][W_src] raw ids; id_lut (nullable):
+ * int64[256]; params: fp32 [N][12] = flip, scale, dx, dy (pixels), pad_top, pad_left, crop_y, crop_x, alpha, beta (levels),
+ * noise sigma (levels, 0 = off), noise seed -- drawn by the host.  out_img: fp32 [N][1][H][W] in [0,1]; out_label: int64.   */
+int ess_augment_image_label(const float* img, const int64_t* label, const float* params, const int64_t* id_lut, float* out_img,
+                            int64_t* out_label, int32_t N, int32_t H_src, int32_t W_src, int32_t H, int32_t W,
+                            ess_stream_t stream);
+
 /* TaskLoss = Dice + CrossEntropy (utils/loss_functions.py:6-24,96-135), forward AND gradient w.r.t.
  * logits in one pass pair.  logits [N][K][H][W], labels int64 [N][H][W].  loss: 1 float.
  * dlogits (nullable): d(loss*loss_scale)/dlogits.  workspace: ess_task_loss_workspace(K) bytes.     */

@@ -715,3 +715,34 @@ def test_pack_weights_multi_matches_single(H):
             H.pack_weights_multi([(sf, H.W_CONV, w3, H.pack_weights(sf, w3, None, H.W_CONV))])
     finally:
         H.set_compute(prev)
+
+
+@pytest.mark.parametrize('shape', [((256, 512), (200, 352)), ((64, 96), (80, 120)), ((33, 47), (32, 40))])
+def test_augment_image_label_vs_oracle(H, shape):
+    """the fused batch augmentation (flip, scale / shift with zero border, centred pad, crop, noise, brightness /
+    contrast, uint8 quantisation, label nearest + id table) against the oracle's restatement on the same parameter rows.
+    Labels exact; image levels equal except where the pre-quantisation value sits within fp32 noise of a .5 boundary."""
+    from ess_amd.datasets.augment import draw_params
+    (Hs, Ws), (Ho, Wo) = shape
+    N = 6
+    g = torch.Generator().manual_seed(Hs + Wo)
+    img = torch.randint(0, 256, (N, Hs, Ws), generator=g).float()
+    lab = torch.randint(0, 34, (N, Hs, Ws), generator=g)
+    lut = torch.full((256,), 255, dtype=torch.int64)
+    lut[:34] = torch.randint(0, 11, (34,), generator=g)
+    params = draw_params(N, (Hs, Ws), (Ho, Wo), 0.1, g)
+    params[0, 1:4] = torch.tensor([1.37, 5.25, -3.5])   # make sure scale + shift, noise and contrast are all exercised
+    params[1, 10:12] = torch.tensor([6.0, 12345.0])
+    params[2, 8:10] = torch.tensor([1.15, -20.0])
+    ref_img, ref_lab = O.augment_image_label(img, lab, params, Ho, Wo, lut)
+    out, out_l = H.augment_image_label(dev(img), dev(lab), dev(params), Ho, Wo, dev(lut))
+    assert torch.equal(out_l.cpu(), ref_lab)
+    lv, lr = (out.cpu() * 255).round(), (ref_img * 255).round()
+    diff = (lv - lr).abs()
+    assert diff.max().item() <= 1 and (diff > 0).float().mean().item() < 2e-3, (diff.max().item(), (diff > 0).float().mean().item())
+    assert out.min().item() >= 0 and out.max().item() <= 1
+    # un-augmented path = centred pad / crop
+    ident = draw_params(N, (Hs, Ws), (Ho, Wo), augment=False)
+    o2, l2 = H.augment_image_label(dev(img), dev(lab), dev(ident), Ho, Wo, None)
+    r2, rl2 = O.augment_image_label(img, lab, ident, Ho, Wo, None)
+    assert torch.equal(l2.cpu(), rl2) and torch.equal((o2.cpu() * 255).round(), (r2 * 255).round())

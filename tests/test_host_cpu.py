@@ -350,3 +350,41 @@ def test_radam_state_dict_interop():
     with pytest.raises(ValueError):
         bad = {'state': {0: dict(ref_sd['state'][0], step=4), 1: ref_sd['state'][1]}, 'param_groups': ref_sd['param_groups']}
         c.load_state_dict(bad)
+
+
+def test_wrapper_dataset_zipper_vs_reference_golden():
+    """ess_amd.datasets.wrapper_dataloader.WrapperDataset against the sequences the reference's class produced
+    (tests/golden/zipper.json, generated by tests/golden/make_golden_zipper.py): 48 cases = 4 length pairs x paired / unpaired
+    on either side x dataset_len_to_use, two epochs each, including where the epoch-setting loader raises StopIteration."""
+    import json
+    import sys
+    from ess_amd.datasets.wrapper_dataloader import WrapperDataset
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from zipper_driver import run
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'zipper.json')))
+    assert len(cases) == 48
+    for c in cases:
+        got = run(WrapperDataset, c['na'], c['nb'], c['paired_a'], c['paired_b'], c['use'])
+        assert got == c['log'], (c['na'], c['nb'], c['paired_a'], c['paired_b'], c['use'])
+
+
+def test_augmentation_params_and_oracle_semantics():
+    """SURVEY 8(f)4 host side: parameter rows follow the reference's probabilities / ranges; the oracle's identity parameters
+    reproduce a centred pad + crop exactly; flip / integer shift are exact pixel moves."""
+    from oracle import ess_oracle as O
+    from ess_amd.datasets.augment import draw_params
+    g = torch.Generator().manual_seed(0)
+    p = draw_params(4000, (256, 512), (200, 352), 0.1, g)
+    assert 0.45 < p[:, 0].mean() < 0.55 and (p[:, 1] >= 1).all() and (p[:, 1] <= 1.5).all()
+    assert 0.45 < (p[:, 1] > 1).float().mean() < 0.55 and 0.15 < (p[:, 10] > 0).float().mean() < 0.25
+    assert (p[:, 6] >= 0).all() and (p[:, 6] <= 56).all() and (p[:, 7] <= 160).all() and p[:, 2].abs().max() <= 51.2
+    img = torch.randint(0, 256, (2, 6, 8)).float()
+    lab = torch.randint(0, 34, (2, 6, 8))
+    ident = draw_params(2, (6, 8), (10, 8), augment=False)
+    out, ol = O.augment_image_label(img, lab, ident, 10, 8)
+    assert torch.equal((out[:, 0, 2:8] * 255).round(), img) and (out[:, 0, :2] == 0).all() and torch.equal(ol[:, 2:8], lab)
+    fl = draw_params(2, (6, 8), (6, 8), augment=False)
+    fl[:, 0] = 1
+    fl[:, 2] = 0
+    out, ol = O.augment_image_label(img, lab, fl, 6, 8)
+    assert torch.equal((out[:, 0] * 255).round(), img.flip(-1)) and torch.equal(ol, lab.flip(-1))
