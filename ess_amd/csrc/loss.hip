@@ -388,6 +388,30 @@ extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* d
   return ess_launch_status("l1_loss_c8");
 }
 
+// the same update with the step-dependent scalars read from DEVICE memory (hyper[0] = -step_size * lr, hyper[1] != 0: rectified
+// Adam phase): a captured step (hipGraph) replays with the values the host wrote for THIS step, kernel arguments would be frozen
+__global__ void radam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 int64_t n, const float* __restrict__ hyper, float b1, float b2, float eps) {
+  const float neg_step = hyper[0];
+  const bool rect = hyper[1] != 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float vi = v[i] * b2 + (1.f - b2) * (gi * gi);
+    const float mi = m[i] * b1 + (1.f - b1) * gi;
+    v[i] = vi;
+    m[i] = mi;
+    p[i] = rect ? p[i] + neg_step * (mi / (sqrtf(vi) + eps)) : p[i] + neg_step * mi;
+  }
+}
+
+extern "C" int ess_radam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
+                                  float eps, const float* hyper, ess_stream_t stream) {
+  ESS_CHECK_ARG(p && g && exp_avg && exp_avg_sq && hyper && n > 0, "radam_step_dev: bad arguments");
+  hipLaunchKernelGGL(radam_dev_kernel, dim3(wave_uniform_grid((size_t)n, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg,
+                     exp_avg_sq, n, hyper, beta1, beta2, eps);
+  return ess_launch_status("radam_step_dev");
+}
+
 extern "C" int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                               float beta2, float eps, float step_size, int32_t n_sma_ge5, ess_stream_t stream) {
   ESS_CHECK_ARG(p && g && exp_avg && exp_avg_sq && n > 0, "radam_step: bad arguments");

@@ -309,6 +309,15 @@ class Conv2dFn(torch.autograd.Function):
                 dw = None
             if not needb:
                 db = None
+            # stride-2 3x3 (assembled from parity phases into a temporary): still no AccumulateGrad node -- those keep the
+            # stream they were created on, which breaks a later hipGraph capture of the step
+            if dw is not None and _direct(weight) and (db is None or (ctx.bias_ref is not None and ctx.bias_ref() is not None and _direct(ctx.bias_ref()))):
+                weight.grad.add_(dw)
+                if db is not None:
+                    ctx.bias_ref().grad.add_(db)
+                dw = db = None
+                if GRAD_READY_HOOK is not None:
+                    GRAD_READY_HOOK(weight)
         if d_skip is not None and need0:  # not fusable (or no data-gradient was computed): plain sum
             d0 = d_skip if d0 is None else (d0 + d_skip if c8in else hip.add(d0, d_skip.contiguous()))
         return d0, d1, dw, db, None, None, None, None, None, None

@@ -43,7 +43,7 @@ EXPORTS = [
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
-    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label',
+    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev',
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
             'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
+            'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -558,6 +559,12 @@ def radam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_size, n_sm
     _check(lib().ess_radam_step(ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), p.numel(), c_float(lr), c_float(beta1),
                                 c_float(beta2), c_float(eps), c_float(step_size), int(n_sma_ge5), stream()),
            'ess_radam_step')
+
+
+def radam_step_dev(p, g, exp_avg, exp_avg_sq, beta1, beta2, eps, hyper):
+    """RAdam update with (-step_size * lr, rectified?) read from the device tensor `hyper` (2 floats)."""
+    _check(lib().ess_radam_step_dev(ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), p.numel(), c_float(beta1), c_float(beta2),
+                                    c_float(eps), ptr(hyper), stream()), 'ess_radam_step_dev')
 
 
 def resize_nearest(x, size):

@@ -65,6 +65,55 @@ class BaseTrainer(object):
     def init_fn(self):
         """Model + optimisers are constructed in the child class."""
 
+    # ------------------------------------------------------------------ captured train step (hipGraph)
+    # One train step issues ~700 launches through ctypes + the autograd tape: 12-25 ms of host time per step.  With static
+    # shapes the whole step -- frozen recurrent loop, forwards, the backward passes, both RAdam kernels and the packed-weight
+    # refresh -- is captured ONCE (torch.cuda.CUDAGraph = hipGraph) and replayed: host time per step = two input copies, two
+    # 8-byte optimiser-scalar copies and one graph launch.  Results are bit-identical to the eager step (same kernels, same
+    # order, same buffers: tests/test_hip_graph.py).  Single-process only: with data parallelism the step stays eager (the
+    # bucketed all-reduces are issued from inside the backward by Python hooks).
+    def enable_step_graph(self, example_batch, warmup=2):
+        if D.world_size() > 1:
+            raise RuntimeError('the captured train step is single-process; data-parallel runs stay eager')
+        flat = lambda b: [t for part in b for t in (part if isinstance(part, (list, tuple)) else [part])]  # noqa: E731
+        unflat = lambda like, ts: [unflat_part(p, ts) for p in like]  # noqa: E731
+
+        def unflat_part(part, ts):
+            return [ts.pop(0) for _ in part] if isinstance(part, (list, tuple)) else ts.pop(0)
+        self._g_inputs = [t.to(self.device).clone() for t in flat(example_batch)]
+        static_batch = unflat(example_batch, list(self._g_inputs))
+        opts = list(self.optimizers_dict.values())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # (torch: a few eager iterations on a side stream before capture)
+            for _ in range(warmup):
+                self._train_step_eager(static_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for o in opts:
+            o.prepare_step()  # the capture below must not contain the host -> device copy of the step scalars
+        self._g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g):
+            losses, outputs, final = self._train_step_eager(static_batch)
+            self._g_keys = sorted(losses)
+            self._g_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._g_keys] + [final.detach().float().reshape(())])
+        for o in opts:
+            o._step -= 1  # capture records the launches without running them: the step prepared above did not happen
+        self._g_like, self._g_outputs = example_batch, outputs
+        return self
+
+    def _replay_step(self, batch):
+        flat = [t for part in batch for t in (part if isinstance(part, (list, tuple)) else [part])]
+        for dst, src in zip(self._g_inputs, flat):
+            if dst.shape != src.shape:
+                raise ValueError('captured train step: batch shape differs from the captured one')
+            dst.copy_(src, non_blocking=True)
+        for o in self.optimizers_dict.values():
+            o.prepare_step()
+        self._g.replay()
+        vec = self._g_vec.clone()  # the graph's own buffers are overwritten by the next replay
+        return {k: vec[i] for i, k in enumerate(self._g_keys)}, self._g_outputs, vec[-1]
+
     # ------------------------------------------------------------------ data
     def createDataLoaders(self):
         s = self.settings

@@ -60,6 +60,12 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
                                                               betas=(0., 0.999))}
 
     def train_step(self, input_batch):
+        """-> (losses, outputs, final_loss).  After enable_step_graph(example_batch) the step is a graph replay."""
+        if getattr(self, '_g', None) is not None:
+            return self._replay_step(input_batch)
+        return self._train_step_eager(input_batch)
+
+    def _train_step_eager(self, input_batch):
         opt = self.optimizers_dict['optimizer_back']
         opt.zero_grad()
         d_final_loss, d_losses, d_outputs = self.task_train_step(input_batch)

@@ -116,6 +116,12 @@ class ESSModel(base_trainer.BaseTrainer):
 
     # ------------------------------------------------------------------ the UDA step (reference :103-148)
     def train_step(self, input_batch):
+        """-> (losses, outputs, final_loss).  After enable_step_graph(example_batch) the step is a graph replay."""
+        if getattr(self, '_g', None) is not None:
+            return self._replay_step(input_batch)
+        return self._train_step_eager(input_batch)
+
+    def _train_step_eager(self, input_batch):
         losses, outputs = {}, {}
         opt_front, opt_back = self.optimizers_dict['optimizer_front_sensor_a'], self.optimizers_dict['optimizer_back']
         opt_back.zero_grad()

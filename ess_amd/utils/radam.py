@@ -25,6 +25,8 @@ class RAdam(Optimizer):
         if weight_decay != 0:
             raise NotImplementedError('weight_decay is always 0. in the ESS trainers (training/ess_trainer.py:91,99)')
         self._step = 0
+        self._hyper = self._hyper_host = None
+        self._prepared = False
         self._flatten()
         # gradients of these parameters accumulate straight into the flat buffer's views: the weight-gradient kernels add into
         # `.grad` themselves (functional.Conv2dFn / BatchNormTrainFn) instead of returning dW for AccumulateGrad.  Scoped to the
@@ -78,6 +80,23 @@ class RAdam(Optimizer):
             step_size = 1.0 / (1 - beta1 ** step)
         return n_sma, step_size
 
+    def prepare_step(self):
+        """Host half of step(): advance the step counter, evaluate the rectification (reference radam.py:49-64, python floats)
+        and put (-step_size * lr, rectified?) into the 2-float device tensor the kernel reads.  step() calls it itself; a
+        trainer that replays a captured step calls it BEFORE each replay (the copy must not be part of the graph)."""
+        group = self.param_groups[0]
+        self._step += 1
+        beta1, beta2 = group['betas']
+        n_sma, step_size = self.rectification(self._step, beta1, beta2)
+        if self._hyper is None:
+            self._hyper = torch.zeros(2, dtype=torch.float32, device=self.flat_param.device)
+            self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        f32 = lambda v: float(torch.tensor(float(v), dtype=torch.float32))  # noqa: E731  (the C ABI of ess_radam_step took floats)
+        self._hyper_host[0] = -f32(step_size) * f32(group['lr'])  # product in double, rounded once on assignment
+        self._hyper_host[1] = 1.0 if n_sma >= 5 else 0.0
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._prepared = True
+
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         group = self.param_groups[0]
@@ -90,11 +109,11 @@ class RAdam(Optimizer):
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad.reshape(-1))
             off += k
-        self._step += 1
+        if not self._prepared:
+            self.prepare_step()
+        self._prepared = False
         beta1, beta2 = group['betas']
-        n_sma, step_size = self.rectification(self._step, beta1, beta2)
-        hip.radam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, group['lr'], beta1, beta2,
-                       group['eps'], step_size, n_sma >= 5)
+        hip.radam_step_dev(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, beta1, beta2, group['eps'], self._hyper)
         repack(group['params'])  # the kernel wrote the weights behind autograd's back: refresh their packed copies
         self._bind_grads()
         return loss

@@ -277,6 +277,11 @@ int ess_radam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
                    float beta1, float beta2, float eps, float step_size, int32_t n_sma_ge5,
                    ess_stream_t stream);
 
+/* The same update with the two step-dependent scalars in device memory: hyper[0] = -step_size * lr, hyper[1] != 0 in the
+ * rectified phase (N_sma >= 5).  For a train step captured in a hipGraph: the host writes `hyper` before each replay.       */
+int ess_radam_step_dev(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2,
+                       float eps, const float* hyper, ess_stream_t stream);
+
 /* F.interpolate(x, size=(H_out, W_out), mode='nearest') on fp32 [planes][H_in][W_in] -- the resize of the validation
  * logits to img_size_b (training/ess_trainer.py:484,525; training/ess_supervised_trainer.py:284).               */
 int ess_resize_nearest(const float* x, float* y, int32_t planes, int32_t H_in, int32_t W_in, int32_t H_out,

@@ -1,0 +1,96 @@
+"""GPU tier: the train step captured in a hipGraph (BaseTrainer.enable_step_graph) against the eager step -- same kernels, same
+order, same buffers, so losses and weights must be BIT-identical -- and the host-side issue time it removes."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ess_oracle as O  # noqa: E402
+
+
+def _trainer(kind, mode, shape):
+    from ess_amd import hip
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
+    from ess_amd.training.ess_trainer import ESSModel
+    B, T, C, H, W, K = shape
+    hip.set_compute(mode)
+    torch.manual_seed(6)
+    st = synthetic_settings(kind, 'DSEC_events', (H, W), K, B, T, C, train_on_event_labels=kind == 'ess_supervised')
+    tr = (ESSModel if kind == 'ess' else ESSSupervisedModel)(st)
+    cfg = O.e2vid_config(num_bins=C)
+    tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), 91))
+    tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, K), 92, decoder_style=True))
+    if kind == 'ess':
+        tr.front_end_sensor_a.load_state_dict(O.synth_state_dict(O.style_encoder_param_shapes(1), 93))
+    return tr
+
+
+def _batch(kind, shape, seed):
+    B, T, C, H, W, K = shape
+    ev, img, lab_a, lab_b = O.synth_batch(B, T, C, H, W, K, seed=seed)
+    return [[img.cuda(), lab_a.cuda()], [ev.cuda(), lab_b.cuda()]] if kind == 'ess' else [ev.cuda(), lab_b.cuda()]
+
+
+@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16')])
+def test_captured_step_is_bit_identical_to_eager(kind, mode):
+    from ess_amd import hip
+    shape = (2, 3, 2, 96, 128, 11)
+    try:
+        runs = []
+        for graph in (False, True):
+            tr = _trainer(kind, mode, shape)
+            b0 = _batch(kind, shape, 300)
+            if graph:
+                tr.enable_step_graph(b0, warmup=2)
+            else:
+                tr.train_step(b0)
+                tr.train_step(b0)
+            hist = []
+            for s in range(7):  # crosses RAdam's switch to the rectified phase (step 6): the step scalars are re-written per replay
+                losses, _, final = tr.train_step(_batch(kind, shape, 301 + s))
+                hist.append({k: v.item() for k, v in losses.items()} | {'final': final.item()})
+            torch.cuda.synchronize()
+            w = {k: v.detach().clone() for k, v in tr.task_backend.state_dict().items()}
+            runs.append((hist, w, tr.optimizers_dict['optimizer_back']._step))
+        (h0, w0, s0), (h1, w1, s1) = runs
+        assert s0 == s1 == 9
+        assert h0 == h1, [(a, b) for a, b in zip(h0, h1) if a != b][:2]
+        assert all(torch.equal(w0[k], w1[k]) for k in w0)
+    finally:
+        hip.set_compute('fp32')
+
+
+def test_captured_step_host_issue_time():
+    """Full-size config 3 step: host-side time to ISSUE one step (no synchronisation inside the timed region), eager vs replay."""
+    from ess_amd import hip
+    shape = (8, 5, 2, 480, 640, 11)
+    try:
+        tr = _trainer('ess', 'bf16', shape)
+        b = _batch('ess', shape, 400)
+        for _ in range(3):
+            tr.train_step(b)
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tr.train_step(b)
+            t.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        eager_ms = min(t) * 1e3
+        tr.enable_step_graph(b, warmup=1)  # (after eager steps on the default stream: no AccumulateGrad node may be involved)
+        tr.train_step(b)
+        torch.cuda.synchronize()
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tr.train_step(b)
+            t.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+        graph_ms = min(t) * 1e3
+        print(f'host issue time per step: eager {eager_ms:.1f} ms, captured {graph_ms:.2f} ms')
+        assert graph_ms < 5.0 and graph_ms < eager_ms
+    finally:
+        hip.set_compute('fp32')
