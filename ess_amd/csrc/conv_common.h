@@ -248,7 +248,11 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
 
 // LINEAR epilogue with BF16_C8 OUTPUT(S) (fmt_out): the stored form of the trainable networks' activations and activation
 // gradients in the bf16 configuration.  A lane owns 4 consecutive channels (4*half .. +3 of 8-channel block rowbase/8 + j) of
-// its pixel = one 8-byte store; the two half-waves complete the 16-byte pixel vector, 32 lanes = 512 contiguous bytes.
+// its pixel.  Blocks are handled in PAIRS (j, j+1): after the arithmetic the two half-waves exchange halves with
+// v_permlane32_swap so that lanes 0-31 hold the complete 16-byte pixel vector of block j and lanes 32-63 that of block j+1 --
+// one 16-byte store per lane, 32 lanes = 512 contiguous bytes (the first version stored 8 bytes per lane with the two
+// half-waves interleaved inside every 16-byte vector: twice the store instructions and half-filled write transactions).
+// The BF16_C8 residual is read the same way (16 bytes per lane, halves exchanged back).
 // Options (all wave-uniform): per-channel scale / shift, a BF16_C8 residual (the skip gradient riding on a data-gradient),
 // ReLU, out_split (channels >= out_split go to out2: the data-gradient of a concat convolution; out_split % 8 == 0),
 // SUMPOOL2 (the first output leaves as the 2x2 pixel sum at half resolution: gradient of a nearest-x2-upsampled source).
@@ -288,67 +292,94 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
   for (int mb = 0; mb < MB; ++mb) {
     const int rowbase = ct * COT + mb * 32;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int blk = (rowbase >> 3) + j, c0 = blk * 8 + 4 * half;
-      const bool blk_ok = blk < nb_all;  // wave-uniform
-      float sc[4], sh[4];
+    for (int jp = 0; jp < 4; jp += 2) {  // block pair (jp, jp + 1)
+      const int blk0 = (rowbase >> 3) + jp;      // wave-uniform; this lane stores block blk0 + half
+      const int myblk = blk0 + half;
+      // residual vectors of this lane's store block, one per pixel block of the wave
+      uint4 rv[NBW];
+      if (a.residual) {  // (uniform)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ci = c0 + i < c_out ? c0 + i : c_out - 1;
-        sc[i] = a.scale ? a.scale[ci] : 1.f;
-        sh[i] = a.shift ? a.shift[ci] : 0.f;
+        for (int nb = 0; nb < NBW; ++nb) rv[nb] = *(const uint4*)(rs + ((size_t)(myblk < nb_all ? myblk : 0) * HW + pix[nb]) * 16);
       }
-      float v[NBW][4];
+      uint2 pk[2][NBW];  // packed results [block of the pair][pixel block]: this lane's 4 channels
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) {
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = jp + jj, blk = blk0 + jj, c0 = blk * 8 + 4 * half;
+        // per-channel scale / shift of the block's 8 channels: wave-uniform addresses (scalar loads; the packed vectors are
+        // padded to the channel tile, so the block is always in range), the half-wave's four picked by a select
+        float sc[4], sh[4];
+        {
+          const int cb0 = __builtin_amdgcn_readfirstlane(blk * 8);
+          float s8[8], h8[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[nb][i] = acc[mb][nb][4 * j + i] * sc[i] + sh[i];
-        if (a.residual) {  // (uniform)
-          const uint2 rr = *(const uint2*)(rs + ((size_t)(blk_ok ? blk : 0) * HW + pix[nb]) * 16 + 8 * half);
-          const bf16x4 rb = __builtin_bit_cast(bf16x4, rr);
+          for (int i = 0; i < 8; ++i) {
+            s8[i] = a.scale ? a.scale[cb0 + i] : 1.f;
+            h8[i] = a.shift ? a.shift[cb0 + i] : 0.f;
+          }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[nb][i] += (float)rb[i];
+          for (int i = 0; i < 4; ++i) {
+            sc[i] = half ? s8[4 + i] : s8[i];
+            sh[i] = half ? h8[4 + i] : h8[i];
+          }
         }
+        float v[NBW][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (relu) v[nb][i] = fmaxf(v[nb][i], 0.f);
-          if (c0 + i >= c_out) v[nb][i] = 0.f;
+        for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[nb][i] = acc[mb][nb][4 * j + i] * sc[i] + sh[i];
+          if (a.residual) {
+            // lanes 0-31 loaded block blk0 (dwords 0,1 = channels 0-3; 2,3 = 4-7), lanes 32-63 block blk0 + 1:
+            // swap(A = dwords 0,1 ; B = dwords 2,3) gives lanes 0-31 (A own, A partner) = channels 0-3 of (blk0, blk0+1)
+            // and lanes 32-63 (B partner, B own) = channels 4-7 of (blk0, blk0+1)
+            const auto s0 = __builtin_amdgcn_permlane32_swap(rv[nb].x, rv[nb].z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(rv[nb].y, rv[nb].w, false, false);
+            const uint2 rr = jj == 0 ? make_uint2(s0[0], s1[0]) : make_uint2(s0[1], s1[1]);
+            const bf16x4 rb = __builtin_bit_cast(bf16x4, rr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[nb][i] += (float)rb[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (relu) v[nb][i] = fmaxf(v[nb][i], 0.f);
+            if (c0 + i >= c_out) v[nb][i] = 0.f;
+          }
         }
-      }
-      if (pool && blk < nb_first) {  // (uniform)
-        float t[NBW][4];
+        if (pool && blk < nb_first) {  // (uniform) 2x2 pixel sums; the owner lanes (even x, even y) hold the result
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (rows1) {
-            t[0][i] = v[0][i] + v[1][i];
-            t[0][i] += xor1(t[0][i]);
-            t[1][i] = 0.f;
-          } else {
+          for (int i = 0; i < 4; ++i) {
+            if (rows1) {
+              v[0][i] = v[0][i] + v[1][i];
+              v[0][i] += xor1(v[0][i]);
+            } else {
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-              t[nb][i] = v[nb][i] + __shfl_xor(v[nb][i], BW, 64);
-              t[nb][i] += xor1(t[nb][i]);
+              for (int nb = 0; nb < NBW; ++nb) {
+                v[nb][i] = v[nb][i] + __shfl_xor(v[nb][i], BW, 64);
+                v[nb][i] += xor1(v[nb][i]);
+              }
             }
           }
         }
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-          if (own[nb]) {
-            bf16x4 b;
+        for (int nb = 0; nb < NBW; ++nb) {
+          bf16x4 b;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = (__bf16)t[nb][i];
-            *(uint2*)(o1 + ((size_t)blk * HWl + pixl[nb]) * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
-          }
-      } else if (blk_ok) {
-        char* dst = blk < nb_first ? o1 + (size_t)blk * HW * 16 : o2 + (size_t)(blk - nb_first) * HW * 16;
+          for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
+          pk[jj][nb] = __builtin_bit_cast(uint2, b);
+        }
+      }
+      // exchange halves: lanes 0-31 end up with the whole vector of block blk0, lanes 32-63 with that of blk0 + 1
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-          if (inb[nb]) {
-            bf16x4 b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
-            *(uint2*)(dst + pix[nb] * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
-          }
+      for (int nb = 0; nb < NBW; ++nb) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
+        const uint4 vec = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        if (myblk >= nb_all) continue;
+        if (pool && myblk < nb_first) {
+          if (own[nb]) *(uint4*)(o1 + ((size_t)myblk * HWl + pixl[nb]) * 16) = vec;
+        } else if (inb[nb]) {
+          char* dst = myblk < nb_first ? o1 + (size_t)myblk * HW * 16 : o2 + (size_t)(myblk - nb_first) * HW * 16;
+          *(uint4*)(dst + pix[nb] * 16) = vec;
+        }
       }
     }
   }

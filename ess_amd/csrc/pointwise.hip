@@ -71,6 +71,63 @@ __global__ __launch_bounds__(256) void up2_bilinear_add_x4_kernel(const float* _
   }
 }
 
+// The same map with a BF16_C8 OUTPUT ([N][C/8][2H][2W][8] bfloat16): what the 5x5 decoder convolution of the frozen encoder
+// stages in the bf16 configuration (it rounds its input to bf16 either way: identical MFMA operands, half the bytes written and
+// a quarter of the cache-line touches read back).  One thread = 4 consecutive output pixels of a row x 8 channels = 64 contiguous
+// bytes; per output the expression and operation order of the kernels above.
+__global__ __launch_bounds__(256) void up2_bilinear_add_c8_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                  uint4* __restrict__ y, int N, int C, int H, int W) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int W2 = 2 * W, H2 = 2 * H, Q = W2 >> 2, CB = (C + 7) >> 3;
+  const unsigned total = (unsigned)N * CB * H2 * Q;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned q = i % Q, t = i / Q;
+    const unsigned yy = t % H2, g = t / H2;  // g = n * CB + cb
+    const unsigned cb = g % CB, n = g / CB;
+    const float sy = fmaxf(0.f, (yy + 0.5f) * 0.5f - 0.5f);
+    const int y0 = (int)sy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float ly = sy - y0, hy = 1.f - ly;
+    const int c[4] = {max(2 * (int)q - 1, 0), 2 * (int)q, 2 * (int)q + 1, min(2 * (int)q + 2, W - 1)};
+    float o[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = (int)cb * 8 + j;
+      const bool ok = ch < C;
+      const size_t base = ((size_t)n * C + (ok ? ch : C - 1)) * H * W;
+      const float* r0 = a + base + (size_t)y0 * W;
+      const float* r1 = a + base + (size_t)y1 * W;
+      float u0[4], u1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { u0[k] = r0[c[k]]; u1[k] = r1[c[k]]; }
+      if (b) {
+        const float* s0 = b + base + (size_t)y0 * W;
+        const float* s1 = b + base + (size_t)y1 * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u0[k] += s0[c[k]]; u1[k] += s1[c[k]]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = 4 * (int)q + k;
+        const float sx = fmaxf(0.f, (x + 0.5f) * 0.5f - 0.5f);
+        const int x0 = (int)sx;
+        const float lx = sx - x0, hx = 1.f - lx;
+        const int i0 = k == 0 ? 0 : (k == 3 ? 2 : 1);
+        const int i1 = k == 0 ? (q == 0 ? 2 : 1) : (k == 3 ? 3 : 2);
+        const float v = hy * (hx * u0[i0] + lx * u0[i1]) + ly * (hx * u1[i0] + lx * u1[i1]);
+        o[k][j] = ok ? v : 0.f;
+      }
+    }
+    uint4* dst = y + ((size_t)g * H2 + yy) * W2 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)o[k][j];
+      dst[k] = __builtin_bit_cast(uint4, v);
+    }
+  }
+}
+
 // 2x2 sum pooling (backward of nearest x2).  Wo even: one thread = 2 outputs = two 16-byte loads, one 8-byte store.
 __global__ void sumpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int planes, int Ho, int Wo, int acc) {
   const size_t total = (size_t)planes * Ho * Wo;
@@ -167,6 +224,16 @@ extern "C" int ess_upsample_bilinear2x_add(const float* a, const float* b, float
     hipLaunchKernelGGL(up2_bilinear_add_kernel, dim3(grid_for((int64_t)planes * H * W * 4)), dim3(256), 0, (hipStream_t)stream, a,
                        b, y, planes, H, W);
   return ess_launch_status("upsample_bilinear2x_add");
+}
+
+extern "C" int ess_upsample_bilinear2x_add_c8(const float* a, const float* b, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                              ess_stream_t stream) {
+  ESS_CHECK_ARG(a && y && N > 0 && C > 0 && H > 0 && W > 0, "upsample_bilinear2x_add_c8: bad arguments");
+  ESS_CHECK_ARG((W & 1) == 0 && (((uintptr_t)y) & 15) == 0, "upsample_bilinear2x_add_c8: even source width and a 16-byte aligned output");
+  const int64_t total = (int64_t)N * ((C + 7) / 8) * 2 * H * (W / 2);
+  ESS_CHECK_ARG(total < ((int64_t)1 << 31), "upsample_bilinear2x_add_c8: tensor too large for 32-bit indexing");
+  hipLaunchKernelGGL(up2_bilinear_add_c8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, (uint4*)y, N, C, H, W);
+  return ess_launch_status("upsample_bilinear2x_add_c8");
 }
 
 extern "C" int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int32_t W_out, int32_t accumulate,

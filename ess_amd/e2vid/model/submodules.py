@@ -203,30 +203,41 @@ class UpsampleConvLayer(nn.Module):
 
     def _conv(self, up0, up1=None):
         c = self.conv2d
-        N, C0, H, W = up0.shape
-        C1 = 0 if up1 is None else up1.shape[1]
+        c8 = hip.is_c8(up0)
+        N, C0, H, W = up0.shape[0], (up0.shape[1] * 8 if c8 else up0.shape[1]), up0.shape[2], up0.shape[3]
+        C1 = 0 if up1 is None else (up1.shape[1] * 8 if c8 else up1.shape[1])
         spec = hip.conv_spec(N, H, W, C0, C1, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0],
                              act=_ACT[self.activation])
         scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=up0.device)
-        return hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=out)
+        return hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=out,
+                                src_fmt=hip.FMT_BF16_C8 if c8 else hip.FMT_F32_NCHW)
+
+    def _up(self, x, skip=None):
+        """bilinear x2 of (x [+ skip]).  bf16 arithmetic: written as the BF16_C8 tensor the convolution stages (it would round
+        the fp32 tensor to exactly these values anyway; half the bytes written, contiguous pixel vectors read back)."""
+        k = self.conv2d.kernel_size[0]
+        if hip.get_compute() == 'bf16' and x.shape[1] % 8 == 0 and not (x.shape[3] & 1) and \
+                hip.c8_stageable(k, self.conv2d.stride[0], self.conv2d.padding[0]):
+            return hip.upsample_bilinear2x_add_c8(x, skip)
+        return hip.upsample_bilinear2x_add(x, skip)
 
     def forward(self, x):
         _inference_only(x)
         _check_eval(self, self.norm)
-        return self._conv(hip.upsample_bilinear2x_add(x))
+        return self._conv(self._up(x))
 
     def forward_sum(self, x, skip):
         """decoder(skip_sum(x, skip)) with the sum fused into the upsampling pass (unet.py:12-13,176)."""
         _inference_only(x, skip)
         _check_eval(self, self.norm)
-        return self._conv(hip.upsample_bilinear2x_add(x, skip))
+        return self._conv(self._up(x, skip))
 
     def forward_cat(self, x, skip):
         """decoder(skip_concat(x, skip)): bilinear commutes with the channel concat."""
         _inference_only(x, skip)
         _check_eval(self, self.norm)
-        return self._conv(hip.upsample_bilinear2x_add(x), hip.upsample_bilinear2x_add(skip))
+        return self._conv(self._up(x), self._up(skip))
 
 
 class ConvLSTM(nn.Module):

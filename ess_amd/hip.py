@@ -43,7 +43,7 @@ EXPORTS = [
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
-    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev',
+    'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
             'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
             'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
+            'ess_upsample_bilinear2x_add_c8': [P, P, P, I, I, I, I, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -417,6 +418,15 @@ def upsample_bilinear2x_add(a, b=None):
     N, C, H, W = a.shape
     y = torch.empty(N, C, 2 * H, 2 * W, dtype=torch.float32, device=a.device)
     _check(lib().ess_upsample_bilinear2x_add(ptr(a), ptr(b), ptr(y), N * C, H, W, stream()), 'ess_upsample_bilinear2x_add')
+    return y
+
+
+def upsample_bilinear2x_add_c8(a, b=None):
+    """bilinear_x2(a + b) written as a BF16_C8 tensor (the staging form of a following bf16 convolution)."""
+    N, C, H, W = a.shape
+    y = bf16_c8_empty(N, C, 2 * H, 2 * W, a.device)
+    _check(lib().ess_upsample_bilinear2x_add_c8(ptr(a), ptr(b), ptr(y, torch.bfloat16), N, C, H, W, stream()),
+           'ess_upsample_bilinear2x_add_c8')
     return y
 
 

@@ -5,6 +5,8 @@ reference (:72-359,455-609) are out of scope; loaders come
 which provides the seeded synthetic loaders when `settings.synthetic` is set and otherwise expects a subclass
 / caller to assign `train_loader` / `val_loader_sensor_b`.
 """
+import os
+
 import torch
 
 from ..utils.saver import CheckpointSaver
@@ -93,10 +95,16 @@ class BaseTrainer(object):
         for o in opts:
             o.prepare_step()  # the capture below must not contain the host -> device copy of the step scalars
         self._g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g):
-            losses, outputs, final = self._train_step_eager(static_batch)
-            self._g_keys = sorted(losses)
-            self._g_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._g_keys] + [final.detach().float().reshape(())])
+        self._side_stream = torch.cuda.Stream()
+        self._fork_branches = os.environ.get('ESS_GRAPH_FORK', '1') != '0'  # independent branches on forked streams (trainers that have them)
+        self._capturing = True
+        try:
+            with torch.cuda.graph(self._g):
+                losses, outputs, final = self._train_step_eager(static_batch)
+                self._g_keys = sorted(losses)
+                self._g_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._g_keys] + [final.detach().float().reshape(())])
+        finally:
+            self._capturing = False
         for o in opts:
             o._step -= 1  # capture records the launches without running them: the step prepared above did not happen
         self._g_like, self._g_outputs = example_batch, outputs

@@ -127,6 +127,16 @@ class ESSModel(base_trainer.BaseTrainer):
         opt_back.zero_grad()
         opt_front.zero_grad()
 
+        # The frozen recurrent encoder over the event sequence and the image branch (image encoder -> decoder -> task loss ->
+        # backward) do not depend on each other.  Inside a captured step (enable_step_graph) they are recorded on two forked
+        # streams, so the hipGraph may run the image branch's norm / loss / weight-gradient kernels under the encoder's convs;
+        # eagerly they run back to back on one stream.
+        fork = getattr(self, '_capturing', False) and self._fork_branches
+        if fork:
+            main, side = torch.cuda.current_stream(), self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc = self.encode_events(input_batch)
         t_final_loss, t_losses, t_outputs = self.img_train_step(input_batch)
         # DSEC: the image latents were detached, so this reaches the decoder only; DDD17: decoder + image encoder
         # (unit_backward == .backward() of the sum of the weighted terms, minus one gradient-times-scalar pass per term)
@@ -134,13 +144,24 @@ class ESSModel(base_trainer.BaseTrainer):
         final_loss = t_final_loss.detach()
         losses.update(t_losses)
         outputs.update(t_outputs)
+        if fork:
+            main.wait_stream(side)
+        else:
+            enc = self.encode_events(input_batch)
 
-        e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch)
-        Fn.unit_backward(self._e_terms)  # image encoder only: the decoder was frozen while this graph was recorded
-        self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
-        self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
-        Fn.unit_backward(self._t_terms)  # decoder only
-        self.grad_reducer.flush()
+        e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch, enc)
+        if fork:
+            # one backward over both sets of terms: the engine enqueues the image-encoder chain (recorded on B) and the decoder
+            # chain (recorded on A) on their own streams and joins them at the end; they write disjoint gradient buffers
+            Fn.unit_backward(self._e_terms + self._t_terms)
+            # (the weight-gradient kernels add into .grad themselves: no AccumulateGrad leaf tells the engine to join B)
+            torch.cuda.current_stream().wait_stream(self._side_stream)
+        else:
+            Fn.unit_backward(self._e_terms)  # image encoder only: the decoder was frozen while this graph was recorded
+            self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
+            self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
+            Fn.unit_backward(self._t_terms)  # decoder only
+            self.grad_reducer.flush()
         final_loss = final_loss + e_loss.detach() + t_loss.detach()
         losses.update(event_losses)
         outputs.update(event_outputs)
@@ -210,24 +231,42 @@ class ESSModel(base_trainer.BaseTrainer):
             losses['cycle_pred_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
         return g_loss, pred_first_sensor_no_grad, pred_second_sensor
 
-    def event_train_step(self, batch):
+    def encode_events(self, batch):
+        """The frozen recurrent encoder over the T event slices of the batch (reference :277-280) -> (img_fake, latent_real)."""
         s = self.settings
         data_b = batch[1][0]
+        self.models_dict['front_sensor_b'].eval()
+        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
+        T, C = s.nr_events_data_b, s.input_channels_b
+        with torch.no_grad():
+            for i in range(T):
+                img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
+                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1), lean_state=i < T - 1)
+        return img_fake, latent_real
+
+    def event_train_step(self, batch, enc=None):
+        s = self.settings
         labels_b = batch[1][2] if s.require_paired_data_train_b else batch[1][1]
+        img_fake, latent_real = enc if enc is not None else self.encode_events(batch)
         for name, m in self.models_dict.items():
             m.train()
             if name in ('front_sensor_b', 'e2vid_decoder', 'back_end'):
                 m.eval()
         gen_model_sensor_a = self.models_dict['front_sensor_a']
         back_end = self.models_dict['back_end']
-        self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         losses, out = {}, {}
-        T, C = s.nr_events_data_b, s.input_channels_b
-        with torch.no_grad():
-            for i in range(T):
-                img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
-                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1), lean_state=i < T - 1)
-        latent_fake = gen_model_sensor_a(img_fake.detach())
+        # Captured step: the image encoder on the reconstruction (+ the cycle pass of the frozen decoder behind it) and the
+        # decoder on the event latents are independent chains -- recorded on two forked streams ("B" = side, "A" = main); the
+        # two cross-uses (B needs A's predictions as its no-grad target, A needs B's) are ordered by stream waits.  autograd
+        # replays every node on the stream its forward ran on, so the combined backward (train_step) forks the same way.
+        fork = getattr(self, '_capturing', False) and self._fork_branches
+        import contextlib
+        main, side = torch.cuda.current_stream(), getattr(self, '_side_stream', None)
+        on_b = (lambda: torch.cuda.stream(side)) if fork else contextlib.nullcontext
+        if fork:
+            side.wait_stream(main)
+        with on_b():
+            latent_fake = gen_model_sensor_a(img_fake.detach())
         latent_real = {k: Fn.detach_keep_c8(v) for k, v in latent_real.items()}  # (keeps the encoder's BF16_C8 staging copies)
 
         # decoder on the event latents: ONE forward, with grad (task cycle loss), shared as no-grad target
@@ -239,10 +278,15 @@ class ESSModel(base_trainer.BaseTrainer):
         back_end.eval()
         for p in back_end.parameters():
             p.requires_grad = False
-        e_loss, pred_b, pred_a = self.trainCycleStep('sensor_b', 'sensor_a', latent_real, latent_fake, losses,
-                                                     pred_first_sensor_no_grad=pred_real_ng)
+        if fork:
+            side.wait_stream(main)  # B reads pred_real_ng
+        with on_b():
+            e_loss, pred_b, pred_a = self.trainCycleStep('sensor_b', 'sensor_a', latent_real, latent_fake, losses,
+                                                         pred_first_sensor_no_grad=pred_real_ng)
         for p in back_end.parameters():
             p.requires_grad = True
+        if fork:
+            main.wait_stream(side)  # A reads pred_a
 
         back_end.train()
         pred_fake_ng = {k: v.detach() for k, v in pred_a.items()}

@@ -198,6 +198,10 @@ int ess_batchnorm_train_backward(const float* x, const float* y, const float* dy
  * skip_sum e2vid/model/unet.py:12-13,176).  b may be NULL.  a: [planes][H][W] -> y: [planes][2H][2W] */
 int ess_upsample_bilinear2x_add(const float* a, const float* b, float* y, int32_t planes, int32_t H,
                                 int32_t W, ess_stream_t stream);
+/* The same map written as a BF16_C8 tensor [N][ceil(C/8)][2H][2W][8] for a bf16 convolution to stage (the 5x5 decoder convs of
+ * the frozen encoder: identical MFMA operands, half the bytes).  a, b: fp32 [N][C][H][W]; W even.                          */
+int ess_upsample_bilinear2x_add_c8(const float* a, const float* b, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                   ess_stream_t stream);
 /* 2x2 sum pooling = backward of nearest x2 upsampling (F.interpolate, models/style_networks.py:77).
  * accumulate != 0 adds into y.                                                                      */
 int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int32_t W_out, int32_t accumulate,
