@@ -13,6 +13,7 @@
 //   TAPS = 9: 3x3 / stride 1 / pad 1 (sources direct or nearest-x2-upsampled, one or two concat sources);
 //   TAPS = 1: 1x1 convolutions as the centre tap of the same tile geometry, input stride SX = 1 or 2 (ResNet downsample).
 #include "conv_wgrad_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,9 +30,16 @@ __device__ __forceinline__ void quad_transpose(const Quad& q, uint2 (&out)[8]) {
   }
 }
 
-template <int TAPS>
-__global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int sx) {
+template <int OFF>
+__device__ __forceinline__ void lds_read128(u32x4w& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
+// TWL = log2 of the pixel-tile width (4: 16 x 8 pixels, 5: 32 x 4): fixes every LDS offset of the fragment reads at compile time
+template <int TAPS, int TWL>
+__global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int sx_abl) {
   extern __shared__ __attribute__((aligned(16))) u32x4w smemv[];
+  const int sx = sx_abl & 0xff, abl = sx_abl >> 8;  // (abl: diagnostic ablation switches ESS_WG_ABL: 1 no MFMA, 2 no loads, 4 no LDS staging, 8 no slab write)
   const WgradArgs& a = b.w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
   Quad dq, xq_[XQ];
   unsigned dmask, xmask[XQ];  // bit i: pixel i of the quad is real data
   auto issue = [&](int tile) {
+    if (abl & 2) return;
     const int n = tile / (a.tiles_x * a.tiles_y);
     const int tr = tile - n * a.tiles_x * a.tiles_y;
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
     }
   };
   auto commit = [&](const Quad& qin, unsigned mask, uint2* base2, int lds2, int pitch2) {
+    if (abl & 4) return;
     Quad q = qin;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -137,10 +147,10 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
+  const bool want_b = a.ws_b && cit == 0 && ib == 0;
 
   // K loop over this workgroup's pixel tiles: 8 k-steps of 16 pixels x TAPS taps per tile, two LDS stages; the quads of tile
   // t+1 (loads issued behind the first k-step) are transposed and written into the other stage on k-steps 4-7
-  const int ksh = a.twl - 4, kmask = (1 << ksh) - 1;
   struct Frag { u32x4w a; u32x4w v[3][3]; };
   if (split < a.ntiles) {
     issue(split);
@@ -152,24 +162,48 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
   int st = 0;
   for (int tile = split; tile < a.ntiles; tile += nsplit, st ^= 1) {
     const bool more = tile + nsplit < a.ntiles;
-    const u32x4w* ap = dy_t + st * stage + (cb * 32 + p) * b.pyv + half;
-    const u32x4w* xp = x_t + st * stage + (ib * 32 + p) * b.pxv + half;
-    auto read_frag = [&](int ks, Frag& f) {
-      f.a = ap[2 * ks];
-      const u32x4w* row = xp + (ks >> ksh) * b.rv + ((ks & kmask) << 1);
-      if constexpr (TAPS == 1) {
-        f.v[1][1] = row[b.rv + 1];
-      } else {
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          f.v[ky][0] = row[ky * b.rv]; f.v[ky][1] = row[ky * b.rv + 1]; f.v[ky][2] = row[ky * b.rv + 2];
-        }
-      }
-    };
+    // ---- fragment reads / MFMAs of the 8 k-steps.  One wave per SIMD: nothing else hides an LDS round trip, and hipcc sinks
+    // plain fragment loads to just above their first MFMA with an `s_waitcnt lgkmcnt(0)` (every 2-3 MFMAs in the first version's
+    // ISA).  So: volatile-asm reads of k-step ks+1 are issued BEFORE the MFMAs of k-step ks, and the wait that releases k-step
+    // ks+1 is a counted lgkmcnt taking the fragments as in/out operands (which ties the MFMAs behind it).  LDS operations
+    // retire in order; between the reads of ks+1 and their wait only the NR reads of ks+2 are issued, the staging writes of a
+    // k-step come before its reads.
+    constexpr int KSH = TWL - 4, KMASK = (1 << KSH) - 1, RV = (1 << TWL) / 8 + 2;
+    constexpr int NR = TAPS == 1 ? 2 : 10;
+    const unsigned lds0 = (unsigned)(size_t)smemv;
+    const unsigned a_addr = lds0 + (unsigned)((st * stage + (cb * 32 + p) * b.pyv + half) * 16);
+    const unsigned x_addr = lds0 + (unsigned)((64 * b.pyv + st * stage + (ib * 32 + p) * b.pxv + half) * 16);
+#define ESS_ROFF(KS_) ((((KS_) >> KSH) * RV + (((KS_) & KMASK) << 1)) * 16)
+#define ESS_RD(F_, KS_)                                                                               \
+    {                                                                                                 \
+      lds_read128<(KS_) * 32>(F_.a, a_addr);                                                          \
+      if constexpr (TAPS == 1) {                                                                      \
+        lds_read128<ESS_ROFF(KS_) + (RV + 1) * 16>(F_.v[1][1], x_addr);                               \
+      } else {                                                                                        \
+        lds_read128<ESS_ROFF(KS_) + (0 * RV + 0) * 16>(F_.v[0][0], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (0 * RV + 1) * 16>(F_.v[0][1], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (0 * RV + 2) * 16>(F_.v[0][2], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (1 * RV + 0) * 16>(F_.v[1][0], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (1 * RV + 1) * 16>(F_.v[1][1], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (1 * RV + 2) * 16>(F_.v[1][2], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (2 * RV + 0) * 16>(F_.v[2][0], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (2 * RV + 1) * 16>(F_.v[2][1], x_addr);                           \
+        lds_read128<ESS_ROFF(KS_) + (2 * RV + 2) * 16>(F_.v[2][2], x_addr);                           \
+      }                                                                                               \
+    }
+#define ESS_WT(F_, N_)                                                                                \
+    {                                                                                                 \
+      if constexpr (TAPS == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(F_.a), "+v"(F_.v[1][1]) : "n"(N_)); \
+      else asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(F_.a), "+v"(F_.v[0][0]), "+v"(F_.v[0][1]), "+v"(F_.v[0][2]), "+v"(F_.v[1][0]), \
+                        "+v"(F_.v[1][1]), "+v"(F_.v[1][2]), "+v"(F_.v[2][0]), "+v"(F_.v[2][1]), "+v"(F_.v[2][2]) : "n"(N_)); \
+    }
     auto mma = [&](const Frag& f) {
+      if (abl & 1) return;
       const bf16x8w af = __builtin_bit_cast(bf16x8w, f.a);
+      if (want_b) {  // (wave-uniform: the bias gradient rides on one wave per output-channel half)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+      }
       if constexpr (TAPS == 1) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[1][1]), acc[0], 0, 0, 0);
       } else {
@@ -183,23 +217,28 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
         }
       }
     };
-    Frag fr[2];
-    read_frag(0, fr[0]);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks + 1 < 8) read_frag(ks + 1, fr[(ks + 1) & 1]);
-      mma(fr[ks & 1]);
-      if (ks == 0 && more) issue(tile + nsplit);
-      if (more) {  // wave-uniform
-        if (ks == 4) commit_d(st ^ 1);
-        if (ks == 5) commit_x(0, st ^ 1);
-        if (ks == 6) commit_x(1, st ^ 1);
-        if (ks == 7) commit_x(2, st ^ 1);
-      }
-    }
+    Frag f0, f1;
+    ESS_RD(f0, 0)
+    ESS_RD(f1, 1) ESS_WT(f0, NR) mma(f0);
+    if (more) issue(tile + nsplit);  // address arithmetic + 16 loads, behind the first k-step's MFMAs
+    ESS_RD(f0, 2) ESS_WT(f1, NR) mma(f1);
+    ESS_RD(f1, 3) ESS_WT(f0, NR) mma(f0);
+    ESS_RD(f0, 4) ESS_WT(f1, NR) mma(f1);
+    if (more) commit_d(st ^ 1);      // (staging writes of a k-step are issued before its fragment reads: see the wait counts)
+    ESS_RD(f1, 5) ESS_WT(f0, NR) mma(f0);
+    if (more) commit_x(0, st ^ 1);
+    ESS_RD(f0, 6) ESS_WT(f1, NR) mma(f1);
+    if (more) commit_x(1, st ^ 1);
+    ESS_RD(f1, 7) ESS_WT(f0, NR) mma(f0);
+    if (more) commit_x(2, st ^ 1);
+    ESS_WT(f1, 0) mma(f1);
+#undef ESS_RD
+#undef ESS_WT
+#undef ESS_ROFF
     __syncthreads();
   }
   const int ci = cit * 64 + ib * 32 + p;
+  if (abl & 8) return;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -207,7 +246,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
       const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * TAPS + t) * a.Cout + co) * Cin + ci] = acc[t][r];
     }
-  if (a.ws_b && cit == 0 && ib == 0) {
+  if (want_b) {
     bsum += __shfl_xor(bsum, 32, 64);
     const int co = cot * 64 + cb * 32 + p;
     if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
@@ -281,14 +320,17 @@ __global__ __launch_bounds__(256) void wgrad_small1x1_c8_kernel(const WgradArgs 
 
 }  // namespace
 
+template <int TAPS, int TWL>
+static void wgrad_c8_go(const WgradBArgs& b, int sx, int lds_bytes, dim3 grid, hipStream_t st) {
+  if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_c8_kernel<TAPS, TWL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL((wgrad_c8_kernel<TAPS, TWL>), grid, dim3(256), lds_bytes, st, b, sx);
+}
+
 int wgrad_c8_launch(const WgradBArgs& b, int taps, int sx, int lds_bytes, dim3 grid, hipStream_t st) {
-  if (taps == 1) {
-    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_c8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(wgrad_c8_kernel<1>, grid, dim3(256), lds_bytes, st, b, sx);
-  } else {
-    if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_c8_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(wgrad_c8_kernel<9>, grid, dim3(256), lds_bytes, st, b, sx);
-  }
+  if (b.w.twl != 4 && b.w.twl != 5) { ess_set_error("wgrad(BF16_C8): pixel tiles are 16 or 32 wide"); return ESS_EINVAL; }
+  { static const int abl = [] { const char* e = getenv("ESS_WG_ABL"); return e ? atoi(e) : 0; }(); sx |= abl << 8; }
+  if (taps == 1) { if (b.w.twl == 5) wgrad_c8_go<1, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<1, 4>(b, sx, lds_bytes, grid, st); }
+  else { if (b.w.twl == 5) wgrad_c8_go<9, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<9, 4>(b, sx, lds_bytes, grid, st); }
   return ess_launch_status("conv2d_wgrad(BF16_C8)");
 }
 
