@@ -14,6 +14,7 @@
 //   TAPS = 1: 1x1 convolutions as the centre tap of the same tile geometry, input stride SX = 1 or 2 (ResNet downsample).
 #include "conv_wgrad_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -253,6 +254,227 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
   }
 }
 
+// ---- 3x3 / stride 1 / pad 1, second generation: no staging registers, no transposition code.
+// gfx950 has the two instructions that make BF16_C8 the NATIVE operand format of a pixel-contraction:
+//   * buffer_load_dwordx4 ... lds  (LDS-DMA): 64 lanes x 16 bytes go from per-lane global addresses straight into 1 KiB of LDS
+//     (lane-linear), out-of-range lanes write zeros -- one instruction stages 64 pixel vectors (8 channels each) of a tile plane,
+//     image borders / tile overhang / absent channel blocks cost nothing (their lanes get an out-of-range offset);
+//   * ds_read_b64_tr_b16: a 16-lane group fetches 16 x 8 bytes from per-lane addresses and receives them transposed
+//     (lane c of the group gets element c%4 of pieces c/4, 4 + c/4, 8 + c/4, 12 + c/4).  With lane i of a group pointing at
+//     (pixel k0 + i/4, channels 4*(i%4) ..+3) the group ends up with lane = channel, elements = 4 consecutive pixels: two such
+//     reads are exactly one v_mfma_f32_32x32x16_bf16 operand (8 pixels of one channel per lane).
+// So the LDS tile is the tensor's own layout -- [8-channel block][tile pixel][8 channels], one plane per block, plane pitch =
+// 64 B mod 256 B so that the four blocks a 32-lane read group touches sit in different bank quarters -- and a filter tap is an
+// immediate offset of the X read ((ky * row + kx) pixels x 16 B): no shifts, no masks, no VALU in the loop at all.
+// Pipeline: three LDS stages; the DMA of tile t+2 is issued right behind the barrier that releases tile t (counted vmcnt, raw
+// s_barrier: nothing drains the queue early); fragment reads run two "units" (= one tile row of taps: 6 reads + 3 MFMAs, +2
+// reads for dY on the first) ahead of the MFMAs with counted lgkmcnt.  Every LDS access is inline asm: hipcc orders a ds_read it
+// can see behind ALL outstanding LDS-DMA (vmcnt(0)), which would serialise the stages.
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(uint2& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+#define ESS_LDS_PTR(off_) ((__attribute__((address_space(3))) void*)(size_t)(off_))
+
+template <int TWL>
+struct DmaGeom {
+  static constexpr int TW = 1 << TWL, TH = 128 >> TWL, RW = TW + 2, IH = TH + 2, XPX = IH * RW;
+  static constexpr int XP = (XPX + 63) / 64;                    // LDS-DMA pieces (64 pixels) per X plane: 3 (16x8 tile) / 4 (32x4)
+  static constexpr int DPL = 2 * 1024 + 64, XPL = XP * 1024 + 64;  // plane pitches
+  static constexpr int XREG = 8 * DPL, STAGE = 8 * (DPL + XPL), NST = 3;
+  static constexpr int PER_WAVE = 2 * (2 + XP);                 // DMA instructions per wave and tile (two planes of each operand)
+};
+
+template <int TWL>
+__global__ __launch_bounds__(256) void wgrad_c8_dma_kernel(const WgradBArgs b) {
+  using G = DmaGeom<TWL>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
+  const WgradArgs& a = b.w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, p = lane & 31;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
+  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
+  const int cb = wave >> 1, ib = wave & 1;
+  const int Cin = a.C0 + a.C1;
+  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+  const bool z0 = a.mode0 == ESS_SRC_ZERO_UP2, z1 = a.mode1 == ESS_SRC_ZERO_UP2;
+  const int nbo = (a.Cout + 7) >> 3, nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
+  const unsigned HWo16 = (unsigned)a.Hout * a.Wout * 16u;
+  const int W0 = a.Win >> sh0, W1 = a.Win >> sh1;
+  const unsigned HW0_16 = (unsigned)(a.Hin >> sh0) * W0 * 16u, HW1_16 = (unsigned)(a.Hin >> sh1) * W1 * 16u;
+  const unsigned lds0 = (unsigned)(size_t)smem_dma;
+
+  // ---- tile-independent part of the DMA plan: which tile pixel each lane fetches in piece q of a plane
+  int d_r[2], d_c[2], x_r[G::XP], x_c[G::XP];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const int pi = q * 64 + lane; d_r[q] = pi >> TWL; d_c[q] = pi & (G::TW - 1); }
+#pragma unroll
+  for (int q = 0; q < G::XP; ++q) { const int pi = q * 64 + lane; x_r[q] = pi < G::XPX ? pi / G::RW : -100000; x_c[q] = pi % G::RW; }
+  // the two planes of each operand this wave stages: output-channel blocks cot*8 + 2*wave + {0,1}, input blocks cit*8 + ...
+  unsigned dpl_off[2], xpl_off[2];
+  bool xpl_first[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pl = 2 * wave + j;
+    const int ob = cot * 8 + pl;
+    dpl_off[j] = ob < nbo ? (unsigned)ob * HWo16 : OOBW;
+    const int c0 = (cit * 8 + pl) * 8;
+    const bool first = c0 < a.C0 || a.C1 == 0;
+    const int bi = (first ? c0 : c0 - a.C0) >> 3;
+    xpl_first[j] = first;
+    xpl_off[j] = (c0 < Cin && bi < (first ? nb0 : nb1)) ? (unsigned)bi * (first ? HW0_16 : HW1_16) : OOBW;
+  }
+
+  auto issue = [&](int tile, int st) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int tr = tile - n * a.tiles_x * a.tiles_y;
+    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+    const __amdgpu_buffer_rsrc_t r_dy =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + (size_t)n * nbo * HWo16), 0, (int)(nbo * HWo16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.src0 + (size_t)n * nb0 * HW0_16), 0, (int)(nb0 * HW0_16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(a.C1 ? a.src1 : a.src0) + (size_t)n * (a.C1 ? nb1 * HW1_16 : 0u)), 0, (int)(a.C1 ? nb1 * HW1_16 : 0u), 0x00020000);
+    const unsigned sbase = lds0 + (unsigned)st * G::STAGE;
+    unsigned vd[2], vx0[G::XP], vx1[G::XP];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int y = y0 + d_r[q], x = x0 + d_c[q];
+      vd[q] = (y < a.Hout && x < a.Wout) ? (unsigned)(y * a.Wout + x) * 16u : OOBW;
+    }
+#pragma unroll
+    for (int q = 0; q < G::XP; ++q) {
+      const int gy = y0 - 1 + x_r[q], gx = x0 - 1 + x_c[q];
+      const bool in = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+      vx0[q] = (in && !(z0 && ((gy | gx) & 1))) ? (unsigned)((gy >> sh0) * W0 + (gx >> sh0)) * 16u : OOBW;
+      vx1[q] = (in && !(z1 && ((gy | gx) & 1))) ? (unsigned)((gy >> sh1) * W1 + (gx >> sh1)) * 16u : OOBW;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pl = 2 * wave + j;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned vo = (dpl_off[j] | vd[q]) & OOBW ? OOBW : dpl_off[j] + vd[q];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_dy, ESS_LDS_PTR(sbase + pl * G::DPL + q * 1024), 16, (int)vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < G::XP; ++q) {
+        const unsigned vq = xpl_first[j] ? vx0[q] : vx1[q];
+        const unsigned vo = (xpl_off[j] | vq) & OOBW ? OOBW : xpl_off[j] + vq;
+        if (xpl_first[j])
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x0, ESS_LDS_PTR(sbase + G::XREG + pl * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x1, ESS_LDS_PTR(sbase + G::XREG + pl * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool want_b = a.ws_b && cit == 0 && ib == 0;
+
+  // fragment read addresses of this lane (see the header): group g = lane / 16 -> channel half g % 2, pixel half g / 2
+  const int g = lane >> 4, i16 = lane & 15;
+  const unsigned pix_off = (unsigned)((8 * (g >> 1) + (i16 >> 2)) * 16 + (i16 & 1) * 8);
+  const unsigned pl_sel = (unsigned)(2 * (g & 1) + ((i16 & 3) >> 1));
+  const unsigned a_lane = (unsigned)(cb * 4 + pl_sel) * G::DPL + pix_off;
+  const unsigned x_lane = G::XREG + (unsigned)(ib * 4 + pl_sel) * G::XPL + pix_off;
+
+  struct FA { uint2 lo, hi; };
+  struct FB { uint2 lo[3], hi[3]; };
+  constexpr int KSH = TWL - 4, KMASK = (1 << KSH) - 1;
+
+  int ntl = 0;  // this split's tiles: split, split + nsplit, ...
+  if (split < a.ntiles) ntl = (a.ntiles - 1 - split) / nsplit + 1;
+  if (ntl > 0) issue(split, 0);
+  if (ntl > 1) issue(split + nsplit, 1);
+  for (int t = 0; t < ntl; ++t) {
+    const int st = t % G::NST;
+    // tile t has landed (this wave's share: leave the younger tile's DMA in flight), for every wave: barrier.  The barrier also
+    // says that every wave is done with tile t-1, whose stage the DMA of tile t+2 overwrites.
+    if (t + 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PER_WAVE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < ntl) issue(split + (t + 2) * nsplit, (t + 2) % G::NST);
+
+    const unsigned a_addr = lds0 + (unsigned)st * G::STAGE + a_lane;
+    const unsigned x_addr = lds0 + (unsigned)st * G::STAGE + x_lane;
+    FA fa[2];
+    FB fb[3];
+    // unit u = (k-step ks = u / 3: 16 pixels of a tile row, filter row ky = u % 3)
+    auto rd = [&](auto uc) {
+      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
+      if constexpr (KY == 0) {
+        lds_read_tr<KS * 256>(fa[KS & 1].lo, a_addr);
+        lds_read_tr<KS * 256 + 64>(fa[KS & 1].hi, a_addr);
+      }
+      constexpr int XO = (((KS >> KSH) + KY) * G::RW + ((KS & KMASK) << 4)) * 16;
+      lds_read_tr<XO + 0>(fb[U % 3].lo[0], x_addr);
+      lds_read_tr<XO + 64>(fb[U % 3].hi[0], x_addr);
+      lds_read_tr<XO + 16>(fb[U % 3].lo[1], x_addr);
+      lds_read_tr<XO + 80>(fb[U % 3].hi[1], x_addr);
+      lds_read_tr<XO + 32>(fb[U % 3].lo[2], x_addr);
+      lds_read_tr<XO + 96>(fb[U % 3].hi[2], x_addr);
+    };
+    auto unit = [&](auto uc) {
+      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
+      if constexpr (U + 2 < 24) rd(std::integral_constant<int, U + 2>{});
+      constexpr int LEFT = (U + 1 < 24 ? 6 + ((U + 1) % 3 == 0 ? 2 : 0) : 0) + (U + 2 < 24 ? 6 + ((U + 2) % 3 == 0 ? 2 : 0) : 0);
+      FA& A_ = fa[KS & 1];
+      FB& B_ = fb[U % 3];
+      if constexpr (KY == 0)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(A_.lo), "+v"(A_.hi), "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
+                     : "n"(LEFT));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
+                     : "n"(LEFT));
+      const u32x4w av = {A_.lo.x, A_.lo.y, A_.hi.x, A_.hi.y};
+      const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+      if constexpr (KY == 0) {
+        if (want_b) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const u32x4w xv = {B_.lo[kx].x, B_.lo[kx].y, B_.hi[kx].x, B_.hi[kx].y};
+        acc[KY * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, xv), acc[KY * 3 + kx], 0, 0, 0);
+      }
+    };
+    rd(std::integral_constant<int, 0>{});
+    rd(std::integral_constant<int, 1>{});
+    static_for<0, 24>(unit);
+  }
+  const int ci = cit * 64 + ib * 32 + p;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = acc[t][r];
+    }
+  if (want_b) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int co = cot * 64 + cb * 32 + p;
+    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
+  }
+}
+
 // ---- the K-class 1x1 head (32 -> K at full resolution): X is BF16_C8 (C_in <= 32), dY fp32 NCHW (the loss kernels' logit
 // gradients, C_out <= 32).  HBM-bound.  A workgroup walks chunks of 128 pixels: X and dY are staged to LDS as fp32
 // [channel][pixel] rows, each wave contracts its 32 pixels of the chunk on the exact-fp32 matrix core
@@ -326,9 +548,23 @@ static void wgrad_c8_go(const WgradBArgs& b, int sx, int lds_bytes, dim3 grid, h
   hipLaunchKernelGGL((wgrad_c8_kernel<TAPS, TWL>), grid, dim3(256), lds_bytes, st, b, sx);
 }
 
+template <int TWL>
+static void wgrad_c8_dma_go(const WgradBArgs& b, dim3 grid, hipStream_t st) {
+  constexpr int lds = DmaGeom<TWL>::STAGE * DmaGeom<TWL>::NST;
+  static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
+  (void)hipFuncSetAttribute((const void*)wgrad_c8_dma_kernel<TWL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((wgrad_c8_dma_kernel<TWL>), grid, dim3(256), lds, st, b);
+}
+
 int wgrad_c8_launch(const WgradBArgs& b, int taps, int sx, int lds_bytes, dim3 grid, hipStream_t st) {
   if (b.w.twl != 4 && b.w.twl != 5) { ess_set_error("wgrad(BF16_C8): pixel tiles are 16 or 32 wide"); return ESS_EINVAL; }
-  { static const int abl = [] { const char* e = getenv("ESS_WG_ABL"); return e ? atoi(e) : 0; }(); sx |= abl << 8; }
+  static const int abl = [] { const char* e = getenv("ESS_WG_ABL"); return e ? atoi(e) : 0; }();
+  static const bool dma = [] { const char* e = getenv("ESS_WG_DMA"); return !e || atoi(e) != 0; }();
+  if (taps == 9 && sx == 1 && dma) {
+    if (b.w.twl == 5) wgrad_c8_dma_go<5>(b, grid, st); else wgrad_c8_dma_go<4>(b, grid, st);
+    return ess_launch_status("conv2d_wgrad(BF16_C8, LDS-DMA)");
+  }
+  sx |= abl << 8;
   if (taps == 1) { if (b.w.twl == 5) wgrad_c8_go<1, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<1, 4>(b, sx, lds_bytes, grid, st); }
   else { if (b.w.twl == 5) wgrad_c8_go<9, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<9, 4>(b, sx, lds_bytes, grid, st); }
   return ess_launch_status("conv2d_wgrad(BF16_C8)");
