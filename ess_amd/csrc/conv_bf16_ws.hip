@@ -15,6 +15,12 @@ using namespace essconv;
 // OUT8: the output(s) are BF16_C8 tensors (LINEAR epilogue): an instantiation of its own that contains conv_epilogue_c8 and
 // nothing of the fp32 epilogue variants -- the all-variants kernel is ~57k instructions with ~300 spilled registers in its
 // epilogues, this one a tenth of that.
+#ifdef ESS_CV_TRACE
+__device__ unsigned long long g_cv_trace[2048 * 8 * 48];
+#define ESS_CT(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ESS_CT(i_) do { } while (0)
+#endif
 template <int MB, int EPI, bool SRCBF, bool OUT8 = false>
 __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -34,6 +40,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   const int y0 = ty * TH, x0 = tx * TW;
   const int bufsz = CB8 * a.plane + WSZ;  // one stage: input tile + weight slab (16-byte units)
+  ESS_CT(0);
 
   if (role == 1 && SRCBF) {
     // ------------------------------------------------------------------ producer, BF16_C8 sources
@@ -131,18 +138,23 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
         }
       }
     } else {
+      ESS_CT(1);
       load_chunk(0, sa);
       commit(0, 0, sa);
       if (nch > 1) load_chunk(1, sa);
+      ESS_CT(2);
       __syncthreads();  // stage 0 is ready
       for (int ch = 0; ch < nch; ++ch) {
+        if (ch < 40) ESS_CT(3 + ch);
         if (ch + 1 < nch) {
           commit(ch + 1, (ch + 1) & 1, sa);
           if (ch + 2 < nch) load_chunk(ch + 2, sa);
         }
+        if (ch == nch - 1) ESS_CT(44);
         __syncthreads();
       }
     }
+    ESS_CT(47);
     return;
   }
   if (role == 1) {
@@ -234,7 +246,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  ESS_CT(1);
   __syncthreads();  // stage 0 is ready
+  ESS_CT(2);
   // the matrix waves take issue priority over the staging waves that share their SIMDs (s_setprio is a scalar instruction that
   // ignores EXEC: `role` is a readfirstlane value, so only consumer waves reach this point)
   __builtin_amdgcn_s_setprio(1);
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   const unsigned w_off = (unsigned)(CB8 * a.plane * 16), buf_bytes = (unsigned)(bufsz * 16);
   struct Frags { u32x4 a[MB]; u32x4 b[NBW]; };
   for (int ch = 0; ch < a.n_chunks; ++ch) {
+    if (ch < 40) ESS_CT(3 + ch);
     const unsigned stage_b = lds0 + (ch & 1) * buf_bytes;
     const unsigned wa = stage_b + w_off + a_base;
     unsigned ba[NBW][KS];
@@ -294,12 +309,15 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #undef ESS_READ_TAP
 #undef ESS_WAIT
 #undef ESS_MMA
+    if (ch == a.n_chunks - 1) ESS_CT(44);
     __syncthreads();
   }
+  ESS_CT(45);
   __builtin_amdgcn_s_setprio(0);
   if (a.deep & 8) return;  // (ablation: no epilogue)
   if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly);
   else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  ESS_CT(47);
 }
 
 
@@ -335,3 +353,15 @@ void conv_bf16_launch_ws(int mb, int epi, bool c8, dim3 grid, size_t lds, hipStr
 }
 
 }  // namespace essconv
+
+#ifdef ESS_CV_TRACE
+extern "C" int ess_debug_conv_trace(unsigned long long* host_out, size_t n) {
+  (void)hipMemset((void*)nullptr, 0, 0);
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cv_trace), n * sizeof(unsigned long long));
+}
+extern "C" int ess_debug_conv_trace_clear() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_cv_trace)) != hipSuccess) return -1;
+  return (int)hipMemset(p, 0, sizeof(unsigned long long) * 2048 * 8 * 48);
+}
+#endif

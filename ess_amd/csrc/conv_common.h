@@ -257,33 +257,40 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
 // ReLU, out_split (channels >= out_split go to out2: the data-gradient of a concat convolution; out_split % 8 == 0),
 // SUMPOOL2 (the first output leaves as the 2x2 pixel sum at half resolution: gradient of a nearest-x2-upsampled source).
 // Channels past C_out inside the last block are written as zeros (the BF16_C8 contract).
-template <int MB>
-__device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
-                                                 int y0, const int (&ly)[NBW]) {
+template <int MB, bool SC, bool SH>
+__device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
+                                                      int y0, const int (&ly)[NBW]) {
   static_assert(NBW == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
   constexpr int COT = MB * 32;
-  const size_t HW = (size_t)a.Hout * a.Wout;
+  // Register-lean on purpose (the matrix waves own 128 registers, 64 of them accumulators): buffer stores / loads with 32-bit
+  // offsets (out-of-image lanes get an out-of-range offset instead of a predicate and a clamped 64-bit address), and the
+  // scale / shift / residual vectors of ONE 32-channel block are loaded at a time (a compiler fence per block keeps hipcc from
+  // hoisting all of them to the top, which spilled ~40 registers around every load: 14 k cycles per workgroup).
+  const unsigned HW = (unsigned)(a.Hout * a.Wout);
   const int c_out = a.Cout, split = a.out_split;
   const int c_first = split > 0 ? split : c_out;
   const int nb_first = (c_first + 7) >> 3, nb_all = nb_first + (split > 0 ? (c_out - split + 7) >> 3 : 0);
   const bool pool = a.act == ESS_ACT_SUMPOOL2, relu = a.act == ESS_ACT_RELU;
   const int Wl = a.Wout >> 1;
-  const size_t HWl = (size_t)(a.Hout >> 1) * Wl;
-  char* o1 = (char*)a.out + (size_t)n * nb_first * (pool ? HWl : HW) * 16;
-  char* o2 = (char*)a.out2 + (size_t)n * (nb_all - nb_first) * HW * 16;
-  const char* rs = (const char*)a.residual + (size_t)n * nb_all * HW * 16;
+  const unsigned HWl = (unsigned)((a.Hout >> 1) * Wl);
+  const unsigned HW1 = pool ? HWl : HW;  // pixels per block plane of the first output
+  const ess_rsrc r_o1 = ess_make_rsrc((const char*)a.out + (size_t)n * nb_first * HW1 * 16, (size_t)nb_first * HW1 * 16);
+  const ess_rsrc r_o2 = ess_make_rsrc(split > 0 ? (const char*)a.out2 + (size_t)n * (nb_all - nb_first) * HW * 16 : (const char*)a.out,
+                                      split > 0 ? (size_t)(nb_all - nb_first) * HW * 16 : 0);
+  const ess_rsrc r_rs = ess_make_rsrc(a.residual ? (const char*)a.residual + (size_t)n * nb_all * HW * 16 : (const char*)a.out,
+                                      a.residual ? (size_t)nb_all * HW * 16 : 0);
   const int BW = 1 << a.bwl;
   const bool rows1 = a.bwl == 5;
-  bool inb[NBW], own[NBW];
-  size_t pix[NBW], pixl[NBW];
+  unsigned pix16[NBW], st1_16[NBW];  // byte offset of this lane's pixel inside a block plane: full resolution / first output's
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
     const int y = y0 + ly[nb];
-    inb[nb] = y < a.Hout && x < a.Wout;
-    pix[nb] = inb[nb] ? (size_t)y * a.Wout + x : 0;  // clamped: loads are unconditional, stores predicated
-    own[nb] = inb[nb] && !(x & 1) && !(y & 1) && (!rows1 || nb == 0);
-    pixl[nb] = (size_t)(y >> 1) * Wl + (x >> 1);
+    const bool inb = (y < a.Hout) & (x < a.Wout);
+    const bool own = inb & !(x & 1) & !(y & 1) & (!rows1 | (nb == 0));
+    pix16[nb] = inb ? (unsigned)(y * a.Wout + x) * 16u : ESS_OOB;
+    st1_16[nb] = pool ? (own ? (unsigned)((y >> 1) * Wl + (x >> 1)) * 16u : ESS_OOB) : pix16[nb];
   }
   auto xor1 = [](float f) {  // lane^1 through DPP (quad_perm [1,0,3,2])
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xf, 0xf, true));
@@ -291,37 +298,39 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int rowbase = ct * COT + mb * 32;
+    asm volatile("" ::: "memory");
+    // everything this 32-channel block needs from memory, issued together (one round trip per mb): per-channel scale / shift
+    // of this lane's 4 channels in each of the four 8-channel blocks (the packed vectors are padded to the channel tile) and
+    // the residual vectors of this lane's store blocks, one per pixel block of the wave (absent blocks / pixels read zeros)
+    float4 scv[4], shv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c0 = rowbase + j * 8 + 4 * half;
+      if constexpr (SC) scv[j] = *(const float4*)(a.scale + c0);
+      if constexpr (SH) shv[j] = *(const float4*)(a.shift + c0);
+    }
+    u32x4e rva[2][NBW];
+    if (a.residual) {  // (uniform)
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const int blk = (rowbase >> 3) + 2 * jh + half;
+          rva[jh][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, (int)((blk < nb_all && pix16[nb] != ESS_OOB) ? (unsigned)blk * HW * 16u + pix16[nb] : ESS_OOB), 0, 0);
+        }
+    }
 #pragma unroll
     for (int jp = 0; jp < 4; jp += 2) {  // block pair (jp, jp + 1)
       const int blk0 = (rowbase >> 3) + jp;      // wave-uniform; this lane stores block blk0 + half
       const int myblk = blk0 + half;
-      // residual vectors of this lane's store block, one per pixel block of the wave
-      uint4 rv[NBW];
-      if (a.residual) {  // (uniform)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) rv[nb] = *(const uint4*)(rs + ((size_t)(myblk < nb_all ? myblk : 0) * HW + pix[nb]) * 16);
-      }
+      const u32x4e (&rv)[NBW] = rva[jp >> 1];
       uint2 pk[2][NBW];  // packed results [block of the pair][pixel block]: this lane's 4 channels
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = jp + jj, blk = blk0 + jj, c0 = blk * 8 + 4 * half;
-        // per-channel scale / shift of the block's 8 channels: wave-uniform addresses (scalar loads; the packed vectors are
-        // padded to the channel tile, so the block is always in range), the half-wave's four picked by a select
-        float sc[4], sh[4];
-        {
-          const int cb0 = __builtin_amdgcn_readfirstlane(blk * 8);
-          float s8[8], h8[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            s8[i] = a.scale ? a.scale[cb0 + i] : 1.f;
-            h8[i] = a.shift ? a.shift[cb0 + i] : 0.f;
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            sc[i] = half ? s8[4 + i] : s8[i];
-            sh[i] = half ? h8[4 + i] : h8[i];
-          }
-        }
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SC) { sc[0] = scv[j].x; sc[1] = scv[j].y; sc[2] = scv[j].z; sc[3] = scv[j].w; }
+        if constexpr (SH) { sh[0] = shv[j].x; sh[1] = shv[j].y; sh[2] = shv[j].z; sh[3] = shv[j].w; }
         float v[NBW][4];
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
@@ -331,8 +340,8 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
             // lanes 0-31 loaded block blk0 (dwords 0,1 = channels 0-3; 2,3 = 4-7), lanes 32-63 block blk0 + 1:
             // swap(A = dwords 0,1 ; B = dwords 2,3) gives lanes 0-31 (A own, A partner) = channels 0-3 of (blk0, blk0+1)
             // and lanes 32-63 (B partner, B own) = channels 4-7 of (blk0, blk0+1)
-            const auto s0 = __builtin_amdgcn_permlane32_swap(rv[nb].x, rv[nb].z, false, false);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(rv[nb].y, rv[nb].w, false, false);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(rv[nb][0], rv[nb][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(rv[nb][1], rv[nb][3], false, false);
             const uint2 rr = jj == 0 ? make_uint2(s0[0], s1[0]) : make_uint2(s0[1], s1[1]);
             const bf16x4 rb = __builtin_bit_cast(bf16x4, rr);
 #pragma unroll
@@ -368,20 +377,36 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
         }
       }
       // exchange halves: lanes 0-31 end up with the whole vector of block blk0, lanes 32-63 with that of blk0 + 1
+      const bool to1 = myblk < nb_first;
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
-        const uint4 vec = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        if (myblk >= nb_all) continue;
-        if (pool && myblk < nb_first) {
-          if (own[nb]) *(uint4*)(o1 + ((size_t)myblk * HWl + pixl[nb]) * 16) = vec;
-        } else if (inb[nb]) {
-          char* dst = myblk < nb_first ? o1 + (size_t)myblk * HW * 16 : o2 + (size_t)(myblk - nb_first) * HW * 16;
-          *(uint4*)(dst + pix[nb] * 16) = vec;
+        const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
+        // first output (pooled or not) / second output (never pooled): a pair may straddle the split, so both stores exist,
+        // each under a uniform condition, with the lanes of the other side pushed out of range
+        if (blk0 < nb_first) {
+          const unsigned o = (to1 && st1_16[nb] != ESS_OOB) ? (unsigned)myblk * HW1 * 16u + st1_16[nb] : ESS_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, (int)o, 0, 0);
+        }
+        if (split > 0 && blk0 + 1 >= nb_first) {
+          const unsigned o = (!to1 && myblk < nb_all && pix16[nb] != ESS_OOB) ? (unsigned)(myblk - nb_first) * HW * 16u + pix16[nb] : ESS_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(vec, r_o2, (int)o, 0, 0);
         }
       }
     }
+  }
+}
+
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
+                                                 int y0, const int (&ly)[NBW]) {
+  if (a.scale) {  // (uniform)
+    if (a.shift) conv_epilogue_c8_impl<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_impl<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
+  } else {
+    if (a.shift) conv_epilogue_c8_impl<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_impl<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
   }
 }
 

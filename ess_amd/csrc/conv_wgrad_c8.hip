@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void wgrad_c8_dma_kernel
 // a wave's LDS-DMA is ordered against its own reads by its own vmcnt -- and add their accumulators through LDS at the end.  4x
 // fewer slab bytes for 2x the L2 -> LDS traffic (every wave fetches both operands of its tiles).
 #ifdef ESS_WG_TRACE
-__device__ unsigned long long g_wg_trace[1024 * 4 * 40];
-#define ESS_TR(i_) do { if (lane == 0 && blockIdx.x < 1024) g_wg_trace[(blockIdx.x * 4 + wave) * 40 + (i_)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_wg_trace[1024 * 8 * 40];
+#define ESS_TR(i_) do { if (lane == 0 && blockIdx.x < 1024) g_wg_trace[(blockIdx.x * 8 + wave) * 40 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ESS_TR(i_) do { } while (0)
 #endif
@@ -748,6 +748,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   int ntl = 0;  // this workgroup's tiles: split, split + nsplit, ...
   if (split < a.ntiles) ntl = (a.ntiles - 1 - split) / nsplit + 1;
 
+  ESS_TR(0);
   if (loader) {
     const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
     const bool z0 = a.mode0 == ESS_SRC_ZERO_UP2, z1 = a.mode1 == ESS_SRC_ZERO_UP2;
@@ -822,8 +823,11 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
         }
       }
     };
+    ESS_TR(1);
     for (int k = 0; k < NST - 1 && k < ntl; ++k) issue(split + k * nsplit, k);
+    ESS_TR(2);
     for (int k = 0; k < ntl; ++k) {
+      if (k < 30) ESS_TR(3 + k);
       // tile k has landed (this wave's share); the NST - 2 younger ones may still be in flight
       const int younger = min(ntl - 1 - k, NST - 2);
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
@@ -832,6 +836,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
       __builtin_amdgcn_s_barrier();  // B_k: tile k is complete in LDS / the MFMA waves are done with tile k - 1
       if (k + NST - 1 < ntl) issue(split + (k + NST - 1) * nsplit, (k + NST - 1) % NST);
     }
+    ESS_TR(37);
     return;
   }
 
@@ -851,8 +856,10 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   const unsigned x_lane = G::XREG + (unsigned)(ib * 4 + pl_sel) * G::XPL + pix_off;
   struct FA { uint2 lo, hi; };
   struct FB { uint2 lo[3], hi[3]; };
+  ESS_TR(1);
   for (int k = 0; k < ntl; ++k) {
     const int st = k % NST;
+    if (k < 30) ESS_TR(3 + k);
     __builtin_amdgcn_s_barrier();  // B_k
     const unsigned a_addr = lds0 + (unsigned)st * G::STAGE + a_lane;
     const unsigned x_addr = lds0 + (unsigned)st * G::STAGE + x_lane;
@@ -904,6 +911,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     rd(std::integral_constant<int, 1>{});
     static_for<0, 24>(unit);
   }
+  ESS_TR(34);
   // ---- slab: ws[split][tap][co][ci]; one base pointer, 32-bit element offsets
   const int ci = cit * 64 + ib * 32 + p, co0 = cot * 64 + cb * 32 + 4 * half;
   float* wsp = a.ws + ((size_t)split * 9 * a.Cout + co0) * Cin + ci;
@@ -924,6 +932,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     const int co = cot * 64 + cb * 32 + p;
     if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
   }
+  ESS_TR(37);
 }
 
 // ---- the K-class 1x1 head (32 -> K at full resolution): X is BF16_C8 (C_in <= 32), dY fp32 NCHW (the loss kernels' logit
