@@ -183,7 +183,7 @@ def roofline_blocks(args, device):
                 'convlstm_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
                                   'achieved': round(gate_fl / gate_ms / 1e9, 1), 'frac': round(gate_fl / gate_ms / 1e9 / peak, 4),
                                   'per_level': gate_levels, 'traffic': _traffic_from_profiles('gate/' + tag)},
-                'wgrad': {'kernel': 'wgrad_c8_kernel<9> + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
+                'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           'ms_per_launch_set': round(wg_ms, 4)}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +

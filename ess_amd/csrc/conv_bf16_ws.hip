@@ -240,12 +240,18 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     boff[nb] = half * a.plane + ly[nb] * a.row_pitch + lx;
   }
   f32x16 acc[MB][NBW];
+  // bias-only epilogues (the ConvLSTM gates; BF16_C8 outputs without a scale): the accumulators start from the bias
+  const bool biased = (EPI == ESS_EPI_LSTM || (OUT8 && a.scale == nullptr)) && a.shift != nullptr;
+  if (biased) {
+    conv_bias_init<MB>(a, acc, ct, half);
+  } else {
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb)
+      for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+  }
   ESS_CT(1);
   __syncthreads();  // stage 0 is ready
   ESS_CT(2);
@@ -315,8 +321,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   ESS_CT(45);
   __builtin_amdgcn_s_setprio(0);
   if (a.deep & 8) return;  // (ablation: no epilogue)
-  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly);
-  else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
+  else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   ESS_CT(47);
 }
 

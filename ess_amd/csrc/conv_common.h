@@ -246,6 +246,22 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
   }
 }
 
+// Accumulators that START from the per-channel shift (bias): accumulator register r of 32-row block mb holds packed row
+// (r & 3) + 8 (r >> 2) + 4 half, so four float4 loads per block fill both pixel blocks.  The loads ride in the matrix waves' wait
+// for the first staged chunk; the epilogue then has no shift to fetch (in the LSTM epilogue that was one dependent round trip
+// per 32-row block in front of the gate arithmetic).
+template <int MB>
+__device__ __forceinline__ void conv_bias_init(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int half) {
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *(const float4*)(a.shift + ct * (MB * 32) + mb * 32 + 8 * g + 4 * half);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) { acc[mb][nb][4 * g] = v.x; acc[mb][nb][4 * g + 1] = v.y; acc[mb][nb][4 * g + 2] = v.z; acc[mb][nb][4 * g + 3] = v.w; }
+    }
+}
+
 // LINEAR epilogue with BF16_C8 OUTPUT(S) (fmt_out): the stored form of the trainable networks' activations and activation
 // gradients in the bf16 configuration.  A lane owns 4 consecutive channels (4*half .. +3 of 8-channel block rowbase/8 + j) of
 // its pixel.  Blocks are handled in PAIRS (j, j+1): after the arithmetic the two half-waves exchange halves with
@@ -398,10 +414,13 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
   }
 }
 
+// biased: the caller started its accumulators from the shift vector (conv_bias_init), nothing is left to add here
 template <int MB>
 __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
-                                                 int y0, const int (&ly)[NBW]) {
-  if (a.scale) {  // (uniform)
+                                                 int y0, const int (&ly)[NBW], bool biased = false) {
+  if (biased) {  // (uniform)
+    conv_epilogue_c8_impl<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+  } else if (a.scale) {
     if (a.shift) conv_epilogue_c8_impl<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
     else conv_epilogue_c8_impl<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
   } else {
@@ -414,7 +433,7 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
 // of the code and registers of this function), so the run-time branch to it is left out here.
 template <int MB, int EPI, bool ALLOW8 = true>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
-                                              int y0, const int (&ly)[NBW]) {
+                                              int y0, const int (&ly)[NBW], bool biased = false) {
   constexpr int COT = MB * 32;
   const unsigned HW = (unsigned)(a.Hout * a.Wout);
   const unsigned plane_b = HW * 4u;  // bytes of one channel plane
@@ -472,7 +491,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) sh[4 * g + jj] = ess_bload(r_sh, 16u * half, (unsigned)(rowbase + 8 * g + jj) * 4u);
+          for (int jj = 0; jj < 4; ++jj) sh[4 * g + jj] = biased ? 0.f : ess_bload(r_sh, 16u * half, (unsigned)(rowbase + 8 * g + jj) * 4u);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
           float hq[4];

@@ -831,7 +831,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, 
 }
 
 struct WPlan {
-  int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes, ctile;
+  int twl, tiles_x, tiles_y, ntiles, IH, IW, plx, co_tiles, ci_tiles, nsplit, lds_bytes;
   bool taps_variant, bf16, bf16_1x1, small1x1, small1x1_mfma, c8, small1x1_c8;
   int pyv, pxv, rv;
   size_t slab_floats;
@@ -891,15 +891,12 @@ WPlan wplan(const EssConvDesc* d) {
   w.ntiles = d->N * w.tiles_x * w.tiles_y;
   w.IH = (th - 1) * S + KS; w.IW = (tw - 1) * S + KS;
   w.plx = (w.IH * w.IW) | 1;
-  static const bool wave_private = [] { const char* e = getenv("ESS_WG_WAVE"); return e && atoi(e) != 0; }();
-  w.ctile = (w.c8 && KS == 3 && wave_private) ? 32 : 64;  // 32: conv_wgrad_c8.hip's wave-private arrangement
-  w.co_tiles = ceil_div(d->C_out, w.ctile);
-  w.ci_tiles = w.taps_variant ? 1 : ceil_div(cin, w.ctile);
+  w.co_tiles = ceil_div(d->C_out, 64);
+  w.ci_tiles = w.taps_variant ? 1 : ceil_div(cin, 64);
   w.slab_floats = (size_t)KS * KS * d->C_out * cin + d->C_out;
   const int pairs = w.co_tiles * w.ci_tiles;
   // the bf16 kernel runs one workgroup per CU (512-register waves): aim at one full round of the 256 CUs
-  static const int c8_target = [] { const char* e = getenv("ESS_WG_TARGET"); return e ? atoi(e) : 256; }();
-  int ns = w.bf16 ? ceil_div((w.c8 && KS == 3) ? c8_target : 256, pairs) : ceil_div(2048, pairs);
+  int ns = w.bf16 ? ceil_div(256, pairs) : ceil_div(2048, pairs);
   if (ns > w.ntiles) ns = w.ntiles;
   const size_t cap = ((size_t)64 << 20) / (w.slab_floats * 4);
   if ((size_t)ns > cap) ns = (int)(cap ? cap : 1);
@@ -981,7 +978,7 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     if ((rc = wgrad_small1x1_c8_launch(a, w.nsplit, st))) return rc;
   } else if (w.c8) {
     WgradBArgs bb{};
-    bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv; bb.ctile = w.ctile;
+    bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     if (w.bf16_1x1) bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile
     if ((rc = wgrad_c8_launch(bb, w.bf16_1x1 ? 1 : 9, d->stride, 2 * w.lds_bytes, grid, st))) return rc;
   } else if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {

@@ -3,15 +3,15 @@
 //
 // GEMM view as in conv_wgrad.hip:  dW[tap][co][ci] = sum_px dY[co][px] * X[ci][px (+) tap], contraction over PIXELS on
 // v_mfma_f32_32x32x16_bf16 -- both operands want 8 consecutive pixels of ONE channel per lane, while BF16_C8 keeps the 8
-// channels of one pixel together.  The transposition happens in registers while a tile is staged: a thread loads a "quad" =
-// 4 consecutive pixel vectors of one 8-channel block (64 contiguous bytes), regroups the 16-bit elements with 16 v_perm_b32
-// into 8 half-vectors (4 pixels of one channel each) and writes them to the channel-major LDS tile the MFMA loop reads
-// (ds_write_b64).  No conversion (the tensors already hold the bf16 operands), no alignment constraints (every pixel is its own
-// 16-byte vector: any width / height works, masks are per pixel), half the bytes and half the staging registers of the
-// fp32-NCHW kernel.  The MFMA loop, the LDS tile layout, the split-K slabs and the reduce kernel are those of
-// wgrad_bf16_k3s1_fast_kernel.
-//   TAPS = 9: 3x3 / stride 1 / pad 1 (sources direct or nearest-x2-upsampled, one or two concat sources);
-//   TAPS = 1: 1x1 convolutions as the centre tap of the same tile geometry, input stride SX = 1 or 2 (ResNet downsample).
+// channels of one pixel together.
+//   3x3 / stride 1 / pad 1 (95 % of the weight-gradient FLOPs): wgrad_c8_ws_kernel -- the tiles go global -> LDS by LDS-DMA in
+//     the tensors' own layout and are transposed by the LDS read itself (ds_read_b64_tr_b16); loader waves issue the DMA, MFMA
+//     waves contract.  See the comment block in front of it.
+//   1x1 (ResNet downsample, stride 1 or 2): wgrad_c8_kernel<1, TWL> -- register staging: a thread loads a "quad" = 4 consecutive
+//     pixel vectors of one 8-channel block, regroups the 16-bit elements with 16 v_perm_b32 into 8 half-vectors (4 pixels of one
+//     channel each) and writes them to a channel-major LDS tile (ds_write_b64); one centre tap of the 3x3 tile geometry.
+//   1x1 head (32 -> K classes, fp32 dY): wgrad_small1x1_c8_kernel, exact-fp32 matrix core.
+// Split-K slabs and the reduce kernel are conv_wgrad.hip's.
 #include "conv_wgrad_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
   }
 }
 
-// ---- 3x3 / stride 1 / pad 1, second generation: no staging registers, no transposition code.
+// ---- 3x3 / stride 1 / pad 1: no staging registers, no transposition code.
 // gfx950 has the two instructions that make BF16_C8 the NATIVE operand format of a pixel-contraction:
 //   * buffer_load_dwordx4 ... lds  (LDS-DMA): 64 lanes x 16 bytes go from per-lane global addresses straight into 1 KiB of LDS
 //     (lane-linear), out-of-range lanes write zeros -- one instruction stages 64 pixel vectors (8 channels each) of a tile plane,
@@ -266,10 +266,8 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
 // So the LDS tile is the tensor's own layout -- [8-channel block][tile pixel][8 channels], one plane per block, plane pitch =
 // 64 B mod 256 B so that the four blocks a 32-lane read group touches sit in different bank quarters -- and a filter tap is an
 // immediate offset of the X read ((ky * row + kx) pixels x 16 B): no shifts, no masks, no VALU in the loop at all.
-// Pipeline: three LDS stages; the DMA of tile t+2 is issued right behind the barrier that releases tile t (counted vmcnt, raw
-// s_barrier: nothing drains the queue early); fragment reads run two "units" (= one tile row of taps: 6 reads + 3 MFMAs, +2
-// reads for dY on the first) ahead of the MFMAs with counted lgkmcnt.  Every LDS access is inline asm: hipcc orders a ds_read it
-// can see behind ALL outstanding LDS-DMA (vmcnt(0)), which would serialise the stages.
+// Every LDS access of the kernel is inline asm: hipcc orders a ds_read it can see behind ALL outstanding LDS-DMA (vmcnt(0)), which
+// would serialise the stages.
 template <int OFF>
 __device__ __forceinline__ void lds_read_tr(uint2& d, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
@@ -291,450 +289,33 @@ struct DmaGeom {  // 16 x 8 pixel tiles
   static constexpr int XREG = 8 * DPL, STAGE = 8 * (DPL + XPL);
 };
 
-// KG = 2: eight waves = two K-GROUPS of four.  Both groups work on the same (co, ci) tile pair and split of the pixel range, on
-// alternate pixel tiles, each with its own two LDS stages, and run half a tile apart: a group's tile boundary (DMA wait, barrier,
-// next DMA issue, pipeline refill) falls into the middle of the other group's tile, whose waves -- one per SIMD, next to one of
-// the waiting group's -- keep the matrix cores busy meanwhile.  Every s_barrier is a workgroup barrier: each group executes one
-// at its tile boundary and one in the middle of its tile, which is the other group's boundary.  At the end group 1 hands its
-// accumulators to group 0 through LDS (the stages are dead by then): one slab per workgroup, as with KG = 1.
-template <int KG>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void wgrad_c8_dma_kernel(const WgradBArgs b) {
-  using G = DmaGeom;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
-  const WgradArgs& a = b.w;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, p = lane & 31;
-  const int kg = wave >> 2, w4 = wave & 3;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
-  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
-  const int cb = w4 >> 1, ib = w4 & 1;
-  const int Cin = a.C0 + a.C1;
-  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
-  const bool z0 = a.mode0 == ESS_SRC_ZERO_UP2, z1 = a.mode1 == ESS_SRC_ZERO_UP2;
-  const int nbo = (a.Cout + 7) >> 3, nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
-  const unsigned HWo16 = (unsigned)a.Hout * a.Wout * 16u;
-  const int W0 = a.Win >> sh0, W1 = a.Win >> sh1;
-  const unsigned HW0_16 = (unsigned)(a.Hin >> sh0) * W0 * 16u, HW1_16 = (unsigned)(a.Hin >> sh1) * W1 * 16u;
-  const unsigned lds0 = (unsigned)(size_t)smem_dma + (unsigned)kg * 2u * G::STAGE;  // this group's two stages
-
-  // ---- tile-independent part of the DMA plan: which tile pixel each lane fetches in piece q of a plane
-  int d_r[2], d_c[2], x_r[G::XP], x_c[G::XP];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { const int pi = q * 64 + lane; d_r[q] = pi >> G::TWL; d_c[q] = pi & (G::TW - 1); }
-#pragma unroll
-  for (int q = 0; q < G::XP; ++q) { const int pi = q * 64 + lane; x_r[q] = pi / G::RW; x_c[q] = pi % G::RW; }
-  // the two planes of each operand this wave stages: output-channel blocks cot*8 + 2*w4 + {0,1}, input blocks cit*8 + ...
-  unsigned dpl_off[2], xpl_off[2];
-  bool xpl_first[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int pl = 2 * w4 + j;
-    const int ob = cot * 8 + pl;
-    dpl_off[j] = ob < nbo ? (unsigned)ob * HWo16 : OOBW;
-    const int c0 = (cit * 8 + pl) * 8;
-    const bool first = c0 < a.C0 || a.C1 == 0;
-    const int bi = (first ? c0 : c0 - a.C0) >> 3;
-    xpl_first[j] = first;
-    xpl_off[j] = (c0 < Cin && bi < (first ? nb0 : nb1)) ? (unsigned)bi * (first ? HW0_16 : HW1_16) : OOBW;
-  }
-
-  auto issue = [&](int tile, int st) {
-    const int n = tile / (a.tiles_x * a.tiles_y);
-    const int tr = tile - n * a.tiles_x * a.tiles_y;
-    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-    const int y0 = ty * G::TH, x0 = tx * G::TW;
-    const __amdgpu_buffer_rsrc_t r_dy =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + (size_t)n * nbo * HWo16), 0, (int)(nbo * HWo16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_x0 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.src0 + (size_t)n * nb0 * HW0_16), 0, (int)(nb0 * HW0_16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(a.C1 ? a.src1 : a.src0) + (size_t)n * (a.C1 ? nb1 * HW1_16 : 0u)), 0, (int)(a.C1 ? nb1 * HW1_16 : 0u), 0x00020000);
-    const unsigned sbase = lds0 + (unsigned)st * G::STAGE;
-    unsigned vd[2], vx0[G::XP], vx1[G::XP];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int y = y0 + d_r[q], x = x0 + d_c[q];
-      const bool in = (y < a.Hout) & (x < a.Wout);
-      vd[q] = in ? (unsigned)(y * a.Wout + x) * 16u : OOBW;
-    }
-#pragma unroll
-    for (int q = 0; q < G::XP; ++q) {
-      const int gy = y0 - 1 + x_r[q], gx = x0 - 1 + x_c[q];
-      const bool in = ((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win);
-      const bool odd = (gy | gx) & 1;
-      vx0[q] = (in & !(z0 & odd)) ? (unsigned)((gy >> sh0) * W0 + (gx >> sh0)) * 16u : OOBW;
-      vx1[q] = (in & !(z1 & odd)) ? (unsigned)((gy >> sh1) * W1 + (gx >> sh1)) * 16u : OOBW;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pl = 2 * w4 + j;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned vo = (dpl_off[j] | vd[q]) & OOBW ? OOBW : dpl_off[j] + vd[q];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_dy, ESS_LDS_PTR(sbase + pl * G::DPL + q * 1024), 16, (int)vo, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < G::XP; ++q) {
-        const unsigned vq = xpl_first[j] ? vx0[q] : vx1[q];
-        const unsigned vo = (xpl_off[j] | vq) & OOBW ? OOBW : xpl_off[j] + vq;
-        if (q < G::XP - 1 || lane < G::XTAIL) {  // (lanes switched off by EXEC write nothing: the last piece stops at the plane's end)
-          if (xpl_first[j])
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x0, ESS_LDS_PTR(sbase + G::XREG + pl * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
-          else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x1, ESS_LDS_PTR(sbase + G::XREG + pl * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
-  const bool want_b = a.ws_b && cit == 0 && ib == 0;
-
-  // fragment read addresses of this lane (see the header): group g = lane / 16 -> channel half g % 2, pixel half g / 2
-  const int g = lane >> 4, i16 = lane & 15;
-  const unsigned pix_off = (unsigned)((8 * (g >> 1) + (i16 >> 2)) * 16 + (i16 & 1) * 8);
-  const unsigned pl_sel = (unsigned)(2 * (g & 1) + ((i16 & 3) >> 1));
-  const unsigned a_lane = (unsigned)(cb * 4 + pl_sel) * G::DPL + pix_off;
-  const unsigned x_lane = G::XREG + (unsigned)(ib * 4 + pl_sel) * G::XPL + pix_off;
-
-  struct FA { uint2 lo, hi; };
-  struct FB { uint2 lo[3], hi[3]; };
-
-  // this split's tiles: split, split + nsplit, ... -- group kg takes every KG-th of them
-  int ntl = 0;
-  if (split < a.ntiles) ntl = (a.ntiles - 1 - split) / nsplit + 1;
-  const int ntg = ntl > kg ? (ntl - kg + KG - 1) / KG : 0;   // tiles of this group
-  const int niter = (ntl + KG - 1) / KG;                      // boundary/middle barrier pairs every wave executes
-  auto tile_of = [&](int j) { return split + (kg + KG * j) * nsplit; };
-  if (ntg > 0) issue(tile_of(0), 0);
-  if (KG == 2 && kg == 1) __builtin_amdgcn_s_barrier();       // group 0's first boundary
-  for (int j = 0; j < niter; ++j) {
-    const bool have = j < ntg;
-    const int st = j & 1;
-    // boundary: tile j has landed (this wave's share), for every wave of the group: barrier.  The barrier also says that the group
-    // is done with tile j-1, whose stage the next DMA overwrites.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (j + 1 < ntg) issue(tile_of(j + 1), st ^ 1);
-
-    const unsigned a_addr = lds0 + (unsigned)st * G::STAGE + a_lane;
-    const unsigned x_addr = lds0 + (unsigned)st * G::STAGE + x_lane;
-    FA fa[2];
-    FB fb[3];
-    // unit u = (k-step ks = u / 3: the 16 pixels of tile row ks, filter row ky = u % 3)
-    auto rd = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (KY == 0) {
-        lds_read_tr<KS * 256>(fa[KS & 1].lo, a_addr);
-        lds_read_tr<KS * 256 + 64>(fa[KS & 1].hi, a_addr);
-      }
-      constexpr int XO = (KS + KY) * G::RW * 16;
-      lds_read_tr<XO + 0>(fb[U % 3].lo[0], x_addr);
-      lds_read_tr<XO + 64>(fb[U % 3].hi[0], x_addr);
-      lds_read_tr<XO + 16>(fb[U % 3].lo[1], x_addr);
-      lds_read_tr<XO + 80>(fb[U % 3].hi[1], x_addr);
-      lds_read_tr<XO + 32>(fb[U % 3].lo[2], x_addr);
-      lds_read_tr<XO + 96>(fb[U % 3].hi[2], x_addr);
-    };
-    auto unit = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (U + 2 < 24) rd(std::integral_constant<int, U + 2>{});
-      constexpr int LEFT = (U + 1 < 24 ? 6 + ((U + 1) % 3 == 0 ? 2 : 0) : 0) + (U + 2 < 24 ? 6 + ((U + 2) % 3 == 0 ? 2 : 0) : 0);
-      FA& A_ = fa[KS & 1];
-      FB& B_ = fb[U % 3];
-      if constexpr (KY == 0)
-        asm volatile("s_waitcnt lgkmcnt(%8)"
-                     : "+v"(A_.lo), "+v"(A_.hi), "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%6)"
-                     : "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      const u32x4w av = {A_.lo.x, A_.lo.y, A_.hi.x, A_.hi.y};
-      const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
-      if constexpr (KY == 0) {
-        if (want_b) {
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) bsum += (float)af[jj];
-        }
-      }
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const u32x4w xv = {B_.lo[kx].x, B_.lo[kx].y, B_.hi[kx].x, B_.hi[kx].y};
-        acc[KY * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, xv), acc[KY * 3 + kx], 0, 0, 0);
-      }
-    };
-    if (have) {
-      rd(std::integral_constant<int, 0>{});
-      rd(std::integral_constant<int, 1>{});
-      static_for<0, 12>(unit);
-    }
-    if (KG == 2) __builtin_amdgcn_s_barrier();  // the other group's boundary
-    if (have) static_for<12, 24>(unit);
-  }
-  if (KG == 2) {
-    if (kg == 0) __builtin_amdgcn_s_barrier();  // group 1's last middle
-    // group 1 -> group 0 through LDS ([wave][register][lane]: conflict-free), then one slab as usual
-    float* xch = (float*)smem_dma;
-    __syncthreads();
-    if (kg == 1) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[((w4 * 144 + t * 16 + r) << 6) + lane] = acc[t][r];
-      xch[((4 * 144) << 6) + (w4 << 6) + lane] = bsum;
-    }
-    __syncthreads();
-    if (kg == 1) return;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] += xch[((w4 * 144 + t * 16 + r) << 6) + lane];
-    bsum += xch[((4 * 144) << 6) + (w4 << 6) + lane];
-  }
-  const int ci = cit * 64 + ib * 32 + p;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cot * 64 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = acc[t][r];
-    }
-  if (want_b) {
-    bsum += __shfl_xor(bsum, 32, 64);
-    const int co = cot * 64 + cb * 32 + p;
-    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bsum;
-  }
-}
-
-// ---- third arrangement of the same machinery: every wave on its own.
-// What the profile of the kernel above says (256 -> 256 @ 60x80, B = 8: 60 us + 8 us reduce): 1.9 us per pixel tile (2.7 us per
-// two with KG = 2: 77 % of the MFMA rate) and 22 - 34 us that do not depend on the tile count -- the 64 x 64 x 9 fp32 partial
-// sums of 256 workgroups are 37.7 MB to write and to read again.  Slab bytes = workgroups x output tile, so: a 32 x 32 output tile
-// per workgroup (one MFMA tile per tap: the accumulators of ONE wave), the four waves of a workgroup split the PIXEL range among
-// themselves -- each stages its own tiles into its own two LDS stages (4 + 4 planes), so there is no barrier in the loop at all:
-// a wave's LDS-DMA is ordered against its own reads by its own vmcnt -- and add their accumulators through LDS at the end.  4x
-// fewer slab bytes for 2x the L2 -> LDS traffic (every wave fetches both operands of its tiles).
 #ifdef ESS_WG_TRACE
 __device__ unsigned long long g_wg_trace[1024 * 8 * 40];
 #define ESS_TR(i_) do { if (lane == 0 && blockIdx.x < 1024) g_wg_trace[(blockIdx.x * 8 + wave) * 40 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ESS_TR(i_) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void wgrad_c8_wave_kernel(const WgradBArgs b) {
-  using G = DmaGeom;
-  constexpr int WSTAGE = 4 * (G::DPL + G::XPL), XREG = 4 * G::DPL;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
-  const WgradArgs& a = b.w;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, p = lane & 31;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int pair = logical % a.npairs, split = logical / a.npairs, nsplit = a.nsplit;
-  const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;  // 32-channel tiles
-  const int Cin = a.C0 + a.C1;
-  const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
-  const bool z0 = a.mode0 == ESS_SRC_ZERO_UP2, z1 = a.mode1 == ESS_SRC_ZERO_UP2;
-  const int nbo = (a.Cout + 7) >> 3, nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
-  const unsigned HWo16 = (unsigned)a.Hout * a.Wout * 16u;
-  const int W0 = a.Win >> sh0, W1 = a.Win >> sh1;
-  const unsigned HW0_16 = (unsigned)(a.Hin >> sh0) * W0 * 16u, HW1_16 = (unsigned)(a.Hin >> sh1) * W1 * 16u;
-  const unsigned lds0 = (unsigned)(size_t)smem_dma + (unsigned)wave * 2u * WSTAGE;  // this wave's two stages
-  ESS_TR(0);
-
-  int d_r[2], d_c[2], x_r[G::XP], x_c[G::XP];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) { const int pi = q * 64 + lane; d_r[q] = pi >> G::TWL; d_c[q] = pi & (G::TW - 1); }
-#pragma unroll
-  for (int q = 0; q < G::XP; ++q) { const int pi = q * 64 + lane; x_r[q] = pi / G::RW; x_c[q] = pi % G::RW; }
-  // the four 8-channel blocks of each operand (uniform): byte offset of the block's plane inside one image, or "absent"
-  unsigned dpl_off[4], xpl_off[4];
-  bool xpl_first[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ob = cot * 4 + j;
-    dpl_off[j] = ob < nbo ? (unsigned)ob * HWo16 : OOBW;
-    const int c0 = (cit * 4 + j) * 8;
-    const bool first = c0 < a.C0 || a.C1 == 0;
-    const int bi = (first ? c0 : c0 - a.C0) >> 3;
-    xpl_first[j] = first;
-    xpl_off[j] = (c0 < Cin && bi < (first ? nb0 : nb1)) ? (unsigned)bi * (first ? HW0_16 : HW1_16) : OOBW;
-  }
-
-  auto issue = [&](int tile, int st) {
-    const int n = tile / (a.tiles_x * a.tiles_y);
-    const int tr = tile - n * a.tiles_x * a.tiles_y;
-    const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-    const int y0 = ty * G::TH, x0 = tx * G::TW;
-    const __amdgpu_buffer_rsrc_t r_dy =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + (size_t)n * nbo * HWo16), 0, (int)(nbo * HWo16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_x0 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.src0 + (size_t)n * nb0 * HW0_16), 0, (int)(nb0 * HW0_16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)(a.C1 ? a.src1 : a.src0) + (size_t)n * (a.C1 ? nb1 * HW1_16 : 0u)), 0, (int)(a.C1 ? nb1 * HW1_16 : 0u), 0x00020000);
-    const unsigned sbase = lds0 + (unsigned)st * WSTAGE;
-    unsigned vd[2], vx0[G::XP], vx1[G::XP];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int y = y0 + d_r[q], x = x0 + d_c[q];
-      const bool in = (y < a.Hout) & (x < a.Wout);
-      vd[q] = in ? (unsigned)(y * a.Wout + x) * 16u : OOBW;
-    }
-#pragma unroll
-    for (int q = 0; q < G::XP; ++q) {
-      const int gy = y0 - 1 + x_r[q], gx = x0 - 1 + x_c[q];
-      const bool in = ((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win);
-      const bool odd = (gy | gx) & 1;
-      vx0[q] = (in & !(z0 & odd)) ? (unsigned)((gy >> sh0) * W0 + (gx >> sh0)) * 16u : OOBW;
-      vx1[q] = (in & !(z1 & odd)) ? (unsigned)((gy >> sh1) * W1 + (gx >> sh1)) * 16u : OOBW;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned vo = (dpl_off[j] | vd[q]) & OOBW ? OOBW : dpl_off[j] + vd[q];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_dy, ESS_LDS_PTR(sbase + j * G::DPL + q * 1024), 16, (int)vo, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < G::XP; ++q) {
-        const unsigned vq = xpl_first[j] ? vx0[q] : vx1[q];
-        const unsigned vo = (xpl_off[j] | vq) & OOBW ? OOBW : xpl_off[j] + vq;
-        if (q < G::XP - 1 || lane < G::XTAIL) {  // (lanes switched off by EXEC write nothing: the last piece stops at the plane's end)
-          if (xpl_first[j])
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x0, ESS_LDS_PTR(sbase + XREG + j * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
-          else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x1, ESS_LDS_PTR(sbase + XREG + j * G::XPL + q * 1024), 16, (int)vo, 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
-  const bool want_b = a.ws_b && cit == 0;
-
-  const int g = lane >> 4, i16 = lane & 15;
-  const unsigned pix_off = (unsigned)((8 * (g >> 1) + (i16 >> 2)) * 16 + (i16 & 1) * 8);
-  const unsigned pl_sel = (unsigned)(2 * (g & 1) + ((i16 & 3) >> 1));
-  const unsigned a_lane = pl_sel * G::DPL + pix_off;
-  const unsigned x_lane = XREG + pl_sel * G::XPL + pix_off;
-
-  struct FA { uint2 lo, hi; };
-  struct FB { uint2 lo[3], hi[3]; };
-
-  // this workgroup's tiles: split, split + nsplit, ... -- wave w takes every fourth of them
-  int ntl = 0;
-  if (split < a.ntiles) ntl = (a.ntiles - 1 - split) / nsplit + 1;
-  const int ntw = ntl > wave ? (ntl - wave + 3) / 4 : 0;
-  auto tile_of = [&](int j) { return split + (wave + 4 * j) * nsplit; };
-  ESS_TR(1);
-  if (ntw > 0) issue(tile_of(0), 0);
-  ESS_TR(2);
-  for (int j = 0; j < ntw; ++j) {
-    const int st = j & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile j has landed; the other stage's reads (tile j-1) retired with its last unit
-    if (j < 30) ESS_TR(3 + j);
-    const unsigned a_addr = lds0 + (unsigned)st * WSTAGE + a_lane;
-    const unsigned x_addr = lds0 + (unsigned)st * WSTAGE + x_lane;
-    FA fa[2];
-    FB fb[3];
-    auto rd = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (KY == 0) {
-        lds_read_tr<KS * 256>(fa[KS & 1].lo, a_addr);
-        lds_read_tr<KS * 256 + 64>(fa[KS & 1].hi, a_addr);
-      }
-      constexpr int XO = (KS + KY) * G::RW * 16;
-      lds_read_tr<XO + 0>(fb[U % 3].lo[0], x_addr);
-      lds_read_tr<XO + 64>(fb[U % 3].hi[0], x_addr);
-      lds_read_tr<XO + 16>(fb[U % 3].lo[1], x_addr);
-      lds_read_tr<XO + 80>(fb[U % 3].hi[1], x_addr);
-      lds_read_tr<XO + 32>(fb[U % 3].lo[2], x_addr);
-      lds_read_tr<XO + 96>(fb[U % 3].hi[2], x_addr);
-    };
-    auto unit = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (U + 2 < 24) rd(std::integral_constant<int, U + 2>{});
-      constexpr int LEFT = (U + 1 < 24 ? 6 + ((U + 1) % 3 == 0 ? 2 : 0) : 0) + (U + 2 < 24 ? 6 + ((U + 2) % 3 == 0 ? 2 : 0) : 0);
-      FA& A_ = fa[KS & 1];
-      FB& B_ = fb[U % 3];
-      if constexpr (KY == 0)
-        asm volatile("s_waitcnt lgkmcnt(%8)"
-                     : "+v"(A_.lo), "+v"(A_.hi), "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%6)"
-                     : "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      const u32x4w av = {A_.lo.x, A_.lo.y, A_.hi.x, A_.hi.y};
-      const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
-      if constexpr (KY == 0) {
-        if (want_b) {
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) bsum += (float)af[jj];
-        }
-      }
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const u32x4w xv = {B_.lo[kx].x, B_.lo[kx].y, B_.hi[kx].x, B_.hi[kx].y};
-        acc[KY * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, xv), acc[KY * 3 + kx], 0, 0, 0);
-      }
-    };
-    rd(std::integral_constant<int, 0>{});
-    rd(std::integral_constant<int, 1>{});
-    static_for<0, 3>(unit);
-    if (j + 1 < ntw) issue(tile_of(j + 1), st ^ 1);  // (behind the first MFMAs: the address arithmetic and the 20 DMA issues ride under them)
-    static_for<3, 24>(unit);
-  }
-  // ---- the four partial sums -> one: through LDS ([wave][register][lane], each wave's copy in its own -- now dead -- stages),
-  // wave w adds and stores registers 36 w .. 36 w + 35
-  ESS_TR(34);
-  float* xch = (float*)smem_dma;
-  constexpr int WPITCH = 2 * WSTAGE / 4;  // floats between the waves' regions (>= 145 * 64)
-  static_assert(WPITCH >= 145 * 64, "accumulator hand-over must fit a wave's stages");
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) xch[wave * WPITCH + ((t * 16 + r) << 6) + lane] = acc[t][r];
-  xch[wave * WPITCH + (144 << 6) + lane] = bsum;
-  ESS_TR(35);
-  __syncthreads();
-  ESS_TR(36);
-  const int ci = cit * 32 + p;
-#pragma unroll
-  for (int k = 0; k < 36; ++k) {
-    const int e = wave * 36 + k, t = e >> 4, r = e & 15;
-    const float v = (xch[(e << 6) + lane] + xch[WPITCH + (e << 6) + lane]) + (xch[2 * WPITCH + (e << 6) + lane] + xch[3 * WPITCH + (e << 6) + lane]);
-    const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (co < a.Cout && ci < Cin) a.ws[(((size_t)split * 9 + t) * a.Cout + co) * Cin + ci] = v;
-  }
-  if (want_b && wave == 0) {
-    float bs = (xch[(144 << 6) + lane] + xch[WPITCH + (144 << 6) + lane]) + (xch[2 * WPITCH + (144 << 6) + lane] + xch[3 * WPITCH + (144 << 6) + lane]);
-    bs += __shfl_xor(bs, 32, 64);
-    const int co = cot * 32 + p;
-    if (half == 0 && co < a.Cout) a.ws_b[(size_t)split * a.Cout + co] = bs;
-  }
-  ESS_TR(37);
-}
-
-// ---- fourth arrangement: loader waves.  Cycle stamps in the kernels above (s_memtime per tile) show what the tile time is made
-// of: a tile's 72 MFMAs need 2304 cycles, a wave that issues no DMA finishes a tile in 2900 -- and every buffer_load ... lds costs
-// the ISSUING wave 110 - 150 cycles (20 per tile in the wave-private kernel: 5070 cycles per tile).  LDS-DMA is asynchronous for the
-// data, not for the instruction.  So the instruction goes to waves that have nothing else to do: eight waves, 0-3 contract (one
-// per SIMD, 32 x 32 x 9 accumulators each, the 64 x 64 pair tile of the first arrangement), 4-7 only issue DMA (10 per tile each)
-// two tiles ahead into NST LDS stages.  One workgroup barrier per tile: the loaders arrive when their share of the NEXT tile has
-// landed (counted vmcnt), the MFMA waves when they are done with the previous one.
+// ---- loader waves.  What cycle stamps (s_memtime per tile, -DESS_WG_TRACE) said about the first arrangements of this kernel, in
+// which the MFMA waves issued their own DMA: a tile's 72 MFMAs need 2304 cycles, a wave that issues no DMA finishes a tile in
+// ~2900 -- and every buffer_load ... lds costs the ISSUING wave 110 - 150 cycles (20 per tile in a one-tile-per-wave variant:
+// 5070 cycles per tile; 10 per tile with four waves sharing a tile: 4200).  LDS-DMA is asynchronous for the data, not for the
+// instruction.  So the instruction goes to waves that have nothing else to do: eight waves, 0-3 contract (one per SIMD,
+// 32 x 32 x 9 accumulators each, a 64 x 64 (co, ci) pair tile per workgroup), 4-7 only issue DMA (10 per tile each), two tiles
+// ahead, into four LDS stages.  One workgroup barrier per tile: the loaders arrive when their share of the NEXT tile has landed
+// (counted vmcnt: the younger tile stays in flight), the MFMA waves two units before the end of the current one -- their fragment
+// reads run two units ahead of the MFMAs (counted lgkmcnt) and continue into the next tile behind that barrier.
+// Measured (B = 8): 256 -> 256 @ 60x80 101 us (register-staged kernel of this file's first version) -> 56 us incl. the 8 us
+// reduce; 2930 cycles per tile = 79 % of the MFMA rate in the loop.  The rest is one wave's issue stream: an MFMA wave cannot
+// issue its 20 ds_reads per 9 MFMAs under its own MFMAs (2304 + 24 x ~26); a second MFMA wave per SIMD needs <= 170 registers
+// (16x16x32 tiles, 72 accumulators): not done.  Two K-groups of four waves issuing their own DMA (1.37 us per tile, but 34 us
+// of tile-independent time) and 32 x 32 pair tiles with a wave-private pixel range (4x smaller slabs, 2x the L2 -> LDS traffic,
+// 20 DMA issues per tile and wave) were measured and dropped.
 template <int NST>
 __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   using G = DmaGeom;
   constexpr int PER_WAVE = 2 * (2 + G::XP);  // DMA instructions per loader wave and tile
+  constexpr int AHEAD = 2;                   // tiles the loaders run ahead of the barrier
+  static_assert(NST == AHEAD + 2, "stages: tile k - 1 (last two units), k, k + 1 (landing), k + 2 (being issued)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dma[];
   const WgradArgs& a = b.w;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, p = lane & 31;
@@ -824,17 +405,17 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
       }
     };
     ESS_TR(1);
-    for (int k = 0; k < NST - 1 && k < ntl; ++k) issue(split + k * nsplit, k);
+    for (int k = 0; k < AHEAD && k < ntl; ++k) issue(split + k * nsplit, k);
     ESS_TR(2);
     for (int k = 0; k < ntl; ++k) {
       if (k < 30) ESS_TR(3 + k);
-      // tile k has landed (this wave's share); the NST - 2 younger ones may still be in flight
-      const int younger = min(ntl - 1 - k, NST - 2);
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+      // tile k has landed (this wave's share); the younger one may still be in flight
+      if (k + 1 < ntl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // B_k: tile k is complete in LDS / the MFMA waves are done with tile k - 1
-      if (k + NST - 1 < ntl) issue(split + (k + NST - 1) * nsplit, (k + NST - 1) % NST);
+      // B_k: tile k is complete in LDS.  The MFMA waves arrive with two units of tile k - 1 left to do (their reads of those are
+      // already issued, but may not have returned), so the stage that is free to overwrite is tile k - 2's: four stages
+      __builtin_amdgcn_s_barrier();
+      if (k + AHEAD < ntl) issue(split + (k + AHEAD) * nsplit, (k + AHEAD) % NST);
     }
     ESS_TR(37);
     return;
@@ -856,60 +437,80 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   const unsigned x_lane = G::XREG + (unsigned)(ib * 4 + pl_sel) * G::XPL + pix_off;
   struct FA { uint2 lo, hi; };
   struct FB { uint2 lo[3], hi[3]; };
+  FA fa[2];
+  FB fb[3];
+  // unit u = (k-step ks = u / 3: the 16 pixels of tile row ks, filter row ky = u % 3): 6 X reads (+2 dY reads on ky = 0), 3 MFMAs.
+  // Reads run two units ahead of their MFMAs -- across the tile boundary too: units 22 / 23 of a tile fetch units 0 / 1 of the next
+  // one (NEXT = true), which the barrier in front of unit 22 has released.
+  unsigned a_addr = lds0 + a_lane, x_addr = lds0 + x_lane, a_next = 0, x_next = 0;
+  auto rd = [&](auto uc, unsigned aad, unsigned xad) {
+    constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
+    if constexpr (KY == 0) {
+      lds_read_tr<KS * 256>(fa[KS & 1].lo, aad);
+      lds_read_tr<KS * 256 + 64>(fa[KS & 1].hi, aad);
+    }
+    constexpr int XO = (KS + KY) * G::RW * 16;
+    lds_read_tr<XO + 0>(fb[U % 3].lo[0], xad);
+    lds_read_tr<XO + 64>(fb[U % 3].hi[0], xad);
+    lds_read_tr<XO + 16>(fb[U % 3].lo[1], xad);
+    lds_read_tr<XO + 80>(fb[U % 3].hi[1], xad);
+    lds_read_tr<XO + 32>(fb[U % 3].lo[2], xad);
+    lds_read_tr<XO + 96>(fb[U % 3].hi[2], xad);
+  };
+  auto unit = [&](auto uc, auto nextc) {
+    constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
+    constexpr bool NEXT = decltype(nextc)::value;
+    if constexpr (U + 2 < 24) rd(std::integral_constant<int, U + 2>{}, a_addr, x_addr);
+    else if constexpr (NEXT) rd(std::integral_constant<int, U + 2 - 24>{}, a_next, x_next);
+    constexpr int N1 = (U + 1 < 24 || NEXT) ? 6 + ((U + 1) % 3 == 0 ? 2 : 0) : 0, N2 = (U + 2 < 24 || NEXT) ? 6 + ((U + 2) % 3 == 0 ? 2 : 0) : 0;
+    constexpr int LEFT = N1 + N2;  // reads issued behind this unit's own
+    FA& A_ = fa[KS & 1];
+    FB& B_ = fb[U % 3];
+    if constexpr (KY == 0)
+      asm volatile("s_waitcnt lgkmcnt(%8)"
+                   : "+v"(A_.lo), "+v"(A_.hi), "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
+                   : "n"(LEFT));
+    else
+      asm volatile("s_waitcnt lgkmcnt(%6)"
+                   : "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
+                   : "n"(LEFT));
+    const u32x4w av = {A_.lo.x, A_.lo.y, A_.hi.x, A_.hi.y};
+    const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+    if constexpr (KY == 0) {
+      if (want_b) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) bsum += (float)af[jj];
+      }
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const u32x4w xv = {B_.lo[kx].x, B_.lo[kx].y, B_.hi[kx].x, B_.hi[kx].y};
+      acc[KY * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, xv), acc[KY * 3 + kx], 0, 0, 0);
+    }
+  };
+  using Yes = std::true_type;
+  using No = std::false_type;
   ESS_TR(1);
-  for (int k = 0; k < ntl; ++k) {
-    const int st = k % NST;
+  if (ntl > 0) {
+    __builtin_amdgcn_s_barrier();  // B_0
+    rd(std::integral_constant<int, 0>{}, a_addr, x_addr);
+    rd(std::integral_constant<int, 1>{}, a_addr, x_addr);
+  }
+  for (int k = 0; k + 1 < ntl; ++k) {  // every tile but the last
     if (k < 30) ESS_TR(3 + k);
-    __builtin_amdgcn_s_barrier();  // B_k
-    const unsigned a_addr = lds0 + (unsigned)st * G::STAGE + a_lane;
-    const unsigned x_addr = lds0 + (unsigned)st * G::STAGE + x_lane;
-    FA fa[2];
-    FB fb[3];
-    auto rd = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (KY == 0) {
-        lds_read_tr<KS * 256>(fa[KS & 1].lo, a_addr);
-        lds_read_tr<KS * 256 + 64>(fa[KS & 1].hi, a_addr);
-      }
-      constexpr int XO = (KS + KY) * G::RW * 16;
-      lds_read_tr<XO + 0>(fb[U % 3].lo[0], x_addr);
-      lds_read_tr<XO + 64>(fb[U % 3].hi[0], x_addr);
-      lds_read_tr<XO + 16>(fb[U % 3].lo[1], x_addr);
-      lds_read_tr<XO + 80>(fb[U % 3].hi[1], x_addr);
-      lds_read_tr<XO + 32>(fb[U % 3].lo[2], x_addr);
-      lds_read_tr<XO + 96>(fb[U % 3].hi[2], x_addr);
-    };
-    auto unit = [&](auto uc) {
-      constexpr int U = decltype(uc)::value, KS = U / 3, KY = U % 3;
-      if constexpr (U + 2 < 24) rd(std::integral_constant<int, U + 2>{});
-      constexpr int LEFT = (U + 1 < 24 ? 6 + ((U + 1) % 3 == 0 ? 2 : 0) : 0) + (U + 2 < 24 ? 6 + ((U + 2) % 3 == 0 ? 2 : 0) : 0);
-      FA& A_ = fa[KS & 1];
-      FB& B_ = fb[U % 3];
-      if constexpr (KY == 0)
-        asm volatile("s_waitcnt lgkmcnt(%8)"
-                     : "+v"(A_.lo), "+v"(A_.hi), "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      else
-        asm volatile("s_waitcnt lgkmcnt(%6)"
-                     : "+v"(B_.lo[0]), "+v"(B_.hi[0]), "+v"(B_.lo[1]), "+v"(B_.hi[1]), "+v"(B_.lo[2]), "+v"(B_.hi[2])
-                     : "n"(LEFT));
-      const u32x4w av = {A_.lo.x, A_.lo.y, A_.hi.x, A_.hi.y};
-      const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
-      if constexpr (KY == 0) {
-        if (want_b) {
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) bsum += (float)af[jj];
-        }
-      }
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const u32x4w xv = {B_.lo[kx].x, B_.lo[kx].y, B_.hi[kx].x, B_.hi[kx].y};
-        acc[KY * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, xv), acc[KY * 3 + kx], 0, 0, 0);
-      }
-    };
-    rd(std::integral_constant<int, 0>{});
-    rd(std::integral_constant<int, 1>{});
-    static_for<0, 24>(unit);
+    const unsigned nst = (unsigned)((k + 1) % NST) * G::STAGE;
+    a_next = lds0 + nst + a_lane;
+    x_next = lds0 + nst + x_lane;
+    static_for<0, 22>([&](auto uc) { unit(uc, No{}); });
+    __builtin_amdgcn_s_barrier();  // B_{k+1}: tile k + 1 is complete in LDS; this wave has no read of tile k - 1 left
+    unit(std::integral_constant<int, 22>{}, Yes{});
+    unit(std::integral_constant<int, 23>{}, Yes{});
+    a_addr = a_next;
+    x_addr = x_next;
+  }
+  if (ntl > 0) {
+    if (ntl - 1 < 30) ESS_TR(3 + ntl - 1);
+    static_for<0, 24>([&](auto uc) { unit(uc, No{}); });
   }
   ESS_TR(34);
   // ---- slab: ws[split][tap][co][ci]; one base pointer, 32-bit element offsets
@@ -1008,44 +609,17 @@ static void wgrad_c8_go(const WgradBArgs& b, int sx, int lds_bytes, dim3 grid, h
   hipLaunchKernelGGL((wgrad_c8_kernel<TAPS, TWL>), grid, dim3(256), lds_bytes, st, b, sx);
 }
 
-template <int KG>
-static void wgrad_c8_dma_go(const WgradBArgs& b, dim3 grid, hipStream_t st) {
-  constexpr int lds = DmaGeom::STAGE * 2 * KG + (KG == 2 ? 4096 : 0);   // (KG = 2: the accumulator hand-over needs 4 x 145 x 256 B)
-  static_assert(lds * (KG == 1 ? 2 : 1) <= 160 * 1024 && (KG == 1 || lds >= (4 * 144 + 4) * 256), "LDS budget of a CU");
-  (void)hipFuncSetAttribute((const void*)wgrad_c8_dma_kernel<KG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((wgrad_c8_dma_kernel<KG>), grid, dim3(256 * KG), lds, st, b);
-}
-
 int wgrad_c8_launch(const WgradBArgs& b, int taps, int sx, int lds_bytes, dim3 grid, hipStream_t st) {
-  if (b.w.twl != 4 && b.w.twl != 5) { ess_set_error("wgrad(BF16_C8): pixel tiles are 16 or 32 wide"); return ESS_EINVAL; }
-  static const int abl = [] { const char* e = getenv("ESS_WG_ABL"); return e ? atoi(e) : 0; }();
-  static const bool dma = [] { const char* e = getenv("ESS_WG_DMA"); return !e || atoi(e) != 0; }();
-  if (taps == 9 && sx == 1 && dma && b.w.twl == 4 && b.ctile == 32) {  // (32-channel pairs: one wave per pixel tile)
-    constexpr int lds = 8 * 4 * (DmaGeom::DPL + DmaGeom::XPL);
-    static_assert(lds <= 160 * 1024, "four waves x two stages");
-    (void)hipFuncSetAttribute((const void*)wgrad_c8_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(wgrad_c8_wave_kernel, grid, dim3(256), lds, st, b);
-    return ess_launch_status("conv2d_wgrad(BF16_C8, LDS-DMA, wave-private tiles)");
-  }
-  static const int wsn = [] { const char* e = getenv("ESS_WG_WS"); return e ? atoi(e) : 3; }();
-  if (taps == 9 && sx == 1 && dma && b.w.twl == 4 && wsn >= 3) {
-    if (wsn == 4) {
-      (void)hipFuncSetAttribute((const void*)wgrad_c8_ws_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * DmaGeom::STAGE);
-      hipLaunchKernelGGL((wgrad_c8_ws_kernel<4>), grid, dim3(512), 4 * DmaGeom::STAGE, st, b);
-    } else {
-      (void)hipFuncSetAttribute((const void*)wgrad_c8_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DmaGeom::STAGE);
-      hipLaunchKernelGGL((wgrad_c8_ws_kernel<3>), grid, dim3(512), 3 * DmaGeom::STAGE, st, b);
-    }
+  if (taps == 9) {  // 3x3 / stride 1: the LDS-DMA kernel with loader waves (16 x 8 pixel tiles)
+    if (b.w.twl != 4 || sx != 1) { ess_set_error("wgrad(BF16_C8, 3x3): stride 1, 16-wide pixel tiles"); return ESS_EINVAL; }
+    constexpr int NST = 4, lds = NST * DmaGeom::STAGE;
+    static_assert(lds <= 160 * 1024, "LDS stages of the weight-gradient kernel");
+    (void)hipFuncSetAttribute((const void*)wgrad_c8_ws_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((wgrad_c8_ws_kernel<NST>), grid, dim3(512), lds, st, b);
     return ess_launch_status("conv2d_wgrad(BF16_C8, LDS-DMA, loader waves)");
   }
-  if (taps == 9 && sx == 1 && dma && b.w.twl == 4) {
-    static const int kgr = [] { const char* e = getenv("ESS_WG_KG"); return e ? atoi(e) : 2; }();
-    if (kgr == 2) wgrad_c8_dma_go<2>(b, grid, st); else wgrad_c8_dma_go<1>(b, grid, st);
-    return ess_launch_status("conv2d_wgrad(BF16_C8, LDS-DMA)");
-  }
-  sx |= abl << 8;
-  if (taps == 1) { if (b.w.twl == 5) wgrad_c8_go<1, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<1, 4>(b, sx, lds_bytes, grid, st); }
-  else { if (b.w.twl == 5) wgrad_c8_go<9, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<9, 4>(b, sx, lds_bytes, grid, st); }
+  if (b.w.twl != 4 && b.w.twl != 5) { ess_set_error("wgrad(BF16_C8): pixel tiles are 16 or 32 wide"); return ESS_EINVAL; }
+  if (b.w.twl == 5) wgrad_c8_go<1, 5>(b, sx, lds_bytes, grid, st); else wgrad_c8_go<1, 4>(b, sx, lds_bytes, grid, st);
   return ess_launch_status("conv2d_wgrad(BF16_C8)");
 }
 

@@ -49,7 +49,6 @@ __device__ __forceinline__ u32x4w shift_right1(u32x4w lo, u32x4w hi) {  // windo
 
 struct WgradBArgs {
   WgradArgs w;
-  int ctile;   // channel tile of the (co, ci) pairs: 64, or 32 for the wave-private 3x3 kernel
   int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
 };
 
