@@ -43,6 +43,18 @@ def _fp32(t):
     return t
 
 
+def _fp32_any(t):
+    """fp32 values of `t`: the tensor itself, or -- when only its BF16_C8 copy was produced -- the copy converted back."""
+    if t is None:
+        return None
+    if getattr(t, 'ess_fp32_unwritten', False):
+        c8 = _c8_of(t)
+        if c8 is None:
+            return _fp32(t)  # (raises)
+        return hip.from_bf16_c8(c8, t.shape[1])
+    return t
+
+
 def _c8_of(t):
     """The staging copy of `t`, unless `t` was modified in place since the producing kernel wrote both."""
     c8 = getattr(t, 'ess_c8', None)
@@ -54,8 +66,7 @@ class _Fold:
     and cached until one of the source tensors changes."""
 
     def __init__(self):
-        self._ver = None
-        self._val = (None, None)
+        self._cache = {}  # spec.key -> (source versions, (packed scale, packed shift)): a module may be called with several shapes per step
 
     def get(self, spec, bias, norm_kind, norm_layer):
         src = [bias]
@@ -63,8 +74,9 @@ class _Fold:
             src += [norm_layer.running_mean, norm_layer.running_var]
         if norm_kind == 'BN':
             src += [norm_layer.weight, norm_layer.bias]
-        ver = (spec.key,) + tuple((id(t), t._version, t.data_ptr()) for t in src if t is not None)
-        if ver != self._ver:
+        ver = tuple((id(t), t._version, t.data_ptr()) for t in src if t is not None)
+        ent = self._cache.get(spec.key)
+        if ent is None or ent[0] != ver:
             with torch.no_grad():
                 scale = shift = None
                 if norm_kind == 'BN':  # y = (x - rm) / sqrt(rv + eps) * g + b
@@ -77,8 +89,11 @@ class _Fold:
                     shift = bias * scale + shift if scale is not None else bias
                 ps = hip.pack_rows(spec, scale.contiguous(), fill=1.0) if scale is not None else None
                 pb = hip.pack_rows(spec, shift.contiguous()) if shift is not None else None
-            self._ver, self._val = ver, (ps, pb)
-        return self._val
+            if len(self._cache) >= 8:
+                self._cache.clear()
+            ent = (ver, (ps, pb))
+            self._cache[spec.key] = ent
+        return ent[1]
 
 
 def _norm_container(norm, ch):
@@ -201,7 +216,9 @@ class UpsampleConvLayer(nn.Module):
             self.norm_layer = nl
         self._fold = _Fold()
 
-    def _conv(self, up0, up1=None):
+    def _conv(self, up0, up1=None, c8_only=False):
+        """c8_only (bf16 arithmetic, BF16_C8 staging): the output leaves as a BF16_C8 copy only -- for a decoder whose output is
+        consumed by the next decoder's upsampling pass and nothing else (the returned fp32 tensor is a placeholder)."""
         c = self.conv2d
         c8 = hip.is_c8(up0)
         N, C0, H, W = up0.shape[0], (up0.shape[1] * 8 if c8 else up0.shape[1]), up0.shape[2], up0.shape[3]
@@ -210,34 +227,45 @@ class UpsampleConvLayer(nn.Module):
                              act=_ACT[self.activation])
         scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=up0.device)
-        return hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=out,
-                                src_fmt=hip.FMT_BF16_C8 if c8 else hip.FMT_F32_NCHW)
+        copy = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, up0.device) if (c8_only and c8) else None
+        hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=None if copy is not None else out,
+                         out_bf=copy, src_fmt=hip.FMT_BF16_C8 if c8 else hip.FMT_F32_NCHW)
+        if copy is not None:
+            _attach_c8(out, copy)
+            _mark_fp32_unwritten(out)
+        return out
 
     def _up(self, x, skip=None):
         """bilinear x2 of (x [+ skip]).  bf16 arithmetic: written as the BF16_C8 tensor the convolution stages (it would round
-        the fp32 tensor to exactly these values anyway; half the bytes written, contiguous pixel vectors read back)."""
+        the fp32 tensor to exactly these values anyway; half the bytes written, contiguous pixel vectors read back) -- and READ
+        from the sources' BF16_C8 copies when their producers left them (resblock / previous decoder output, recurrent state)."""
         k = self.conv2d.kernel_size[0]
         if hip.get_compute() == 'bf16' and x.shape[1] % 8 == 0 and not (x.shape[3] & 1) and \
                 hip.c8_stageable(k, self.conv2d.stride[0], self.conv2d.padding[0]):
-            return hip.upsample_bilinear2x_add_c8(x, skip)
-        return hip.upsample_bilinear2x_add(x, skip)
+            x8, s8 = _c8_of(x), (None if skip is None else _c8_of(skip))
+            if x8 is not None and skip is not None and s8 is None:
+                s8 = hip.to_bf16_c8(_fp32(skip))
+            if x8 is not None:
+                return hip.upsample_bilinear2x_add_c8_from_c8(x8, s8)
+            return hip.upsample_bilinear2x_add_c8(_fp32_any(x), _fp32_any(skip))
+        return hip.upsample_bilinear2x_add(_fp32_any(x), _fp32_any(skip))  # (odd widths, channel counts that are no multiple of 8)
 
-    def forward(self, x):
+    def forward(self, x, c8_only=False):
         _inference_only(x)
         _check_eval(self, self.norm)
-        return self._conv(self._up(x))
+        return self._conv(self._up(x), c8_only=c8_only)
 
-    def forward_sum(self, x, skip):
+    def forward_sum(self, x, skip, c8_only=False):
         """decoder(skip_sum(x, skip)) with the sum fused into the upsampling pass (unet.py:12-13,176)."""
         _inference_only(x, skip)
         _check_eval(self, self.norm)
-        return self._conv(self._up(x, skip))
+        return self._conv(self._up(x, skip), c8_only=c8_only)
 
-    def forward_cat(self, x, skip):
+    def forward_cat(self, x, skip, c8_only=False):
         """decoder(skip_concat(x, skip)): bilinear commutes with the channel concat."""
         _inference_only(x, skip)
         _check_eval(self, self.norm)
-        return self._conv(self._up(x), self._up(skip))
+        return self._conv(self._up(x), self._up(skip), c8_only=c8_only)
 
 
 class ConvLSTM(nn.Module):
@@ -423,13 +451,32 @@ class ResidualBlock(nn.Module):
         self.downsample = downsample
         self._f1, self._f2 = _Fold(), _Fold()
 
-    def forward(self, x):
+    def forward(self, x, c8_only=False):
+        """c8_only (bf16 arithmetic, fused norms, x carries a BF16_C8 copy): both convolutions read and write BF16_C8 tensors --
+        the block's output exists as a copy only (for a consumer that stages from it: the next block, a decoder's upsampling
+        pass); bf16-rounded where the fp32 form kept the accumulator."""
         _inference_only(x)
         N, C, H, W = x.shape
         bn = self.norm == 'BN'
         if bn and self.training:
             raise NotImplementedError('E2VID BatchNorm only exists in eval mode here; call .eval() on the encoder')
         fused = self.norm != 'IN'
+        x8 = _c8_of(x) if (c8_only and fused and hip.get_compute() == 'bf16' and C % 8 == 0 and hip.c8_stageable(3, 1, 1)) else None
+        if x8 is not None:
+            s1 = hip.conv_spec(N, H, W, C, 0, self.conv1.out_channels, 3, 1, 1, act=hip.ACT_RELU)
+            s2 = hip.conv_spec(N, H, W, self.conv1.out_channels, 0, self.conv2.out_channels, 3, 1, 1, act=hip.ACT_RELU)
+            sc1, sh1 = self._f1.get(s1, self.conv1.bias, 'BN' if bn else None, getattr(self, 'bn1', None))
+            sc2, sh2 = self._f2.get(s2, self.conv2.bias, 'BN' if bn else None, getattr(self, 'bn2', None))
+            o8 = hip.bf16_c8_empty(N, self.conv1.out_channels, H, W, x.device)
+            hip.conv_forward(s1, x8, None, packed_weight(s1, self.conv1.weight), sc1, sh1, out=o8, src_fmt=hip.FMT_BF16_C8,
+                             out_fmt=hip.FMT_BF16_C8)
+            out8 = hip.bf16_c8_empty(N, self.conv2.out_channels, H, W, x.device)
+            hip.conv_forward(s2, o8, None, packed_weight(s2, self.conv2.weight), sc2, sh2, x8, out=out8, src_fmt=hip.FMT_BF16_C8,
+                             out_fmt=hip.FMT_BF16_C8)
+            out = torch.empty(N, self.conv2.out_channels, H, W, dtype=torch.float32, device=x.device)
+            _attach_c8(out, out8)
+            _mark_fp32_unwritten(out)
+            return out
         s1 = hip.conv_spec(N, H, W, C, 0, self.conv1.out_channels, 3, 1, 1, act=hip.ACT_RELU if fused else hip.ACT_NONE)
         s2 = hip.conv_spec(N, H, W, self.conv1.out_channels, 0, self.conv2.out_channels, 3, 1, 1,
                            act=hip.ACT_RELU if fused else hip.ACT_NONE)

@@ -25,6 +25,7 @@ class BaseUNet(nn.Module):
         self.skip_type = skip_type
         self.activation = activation
         self.norm = norm
+        self.use_upsample_conv = use_upsample_conv
         self.UpsampleLayer = UpsampleConvLayer if use_upsample_conv else TransposedConvLayer
         self.num_encoders = num_encoders
         self.base_num_channels = base_num_channels
@@ -47,18 +48,24 @@ class BaseUNet(nn.Module):
         self.pred = ConvLayer(mul * self.base_num_channels, self.num_output_channels, 1, activation=None, norm=self.norm)
 
     # ---- shared tail: residual blocks -> decoders (with skips) -> prediction + output activation
-    def _skip_decode(self, decoder, x, skip):
+    def _skip_decode(self, decoder, x, skip, c8_only=False):
+        kw = {'c8_only': True} if c8_only else {}
         if self.skip_type == 'sum':
-            return decoder.forward_sum(x, skip)
+            return decoder.forward_sum(x, skip, **kw)
         if hasattr(decoder, 'forward_cat'):
-            return decoder.forward_cat(x, skip)
+            return decoder.forward_cat(x, skip, **kw)
         return decoder(torch.cat([x, skip], dim=1))
 
     def _tail(self, x, blocks, head):
+        # bf16 arithmetic with upsample-conv decoders: the resblock outputs and every decoder output but the last are consumed by
+        # an upsampling pass only, which reads BF16_C8 copies -- those tensors are produced as copies and nothing else
+        c8_chain = hip.get_compute() == 'bf16' and self.use_upsample_conv and self.skip_type in ('sum', 'concat') and \
+            hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 1, 2)
         for resblock in self.resblocks:
-            x = resblock(x)
+            x = resblock(x, c8_only=True) if c8_chain else resblock(x)
         for i, decoder in enumerate(self.decoders):
-            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1])
+            last = i == len(self.decoders) - 1
+            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1], c8_only=c8_chain and not last)
         # pred(skip(x, head)) + output activation fused into the 1x1 conv epilogue
         saved = self.pred.activation
         self.pred.activation = self.activation

@@ -44,6 +44,7 @@ EXPORTS = [
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
+    'ess_upsample_bilinear2x_add_c8_from_c8',
 ]
 
 
@@ -122,6 +123,7 @@ def lib():
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
             'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
             'ess_upsample_bilinear2x_add_c8': [P, P, P, I, I, I, I, P],
+            'ess_upsample_bilinear2x_add_c8_from_c8': [P, P, P, I, I, I, I, P],
         }
         for name, argtypes in sig.items():
             fn = getattr(L, name)
@@ -427,6 +429,15 @@ def upsample_bilinear2x_add_c8(a, b=None):
     y = bf16_c8_empty(N, C, 2 * H, 2 * W, a.device)
     _check(lib().ess_upsample_bilinear2x_add_c8(ptr(a), ptr(b), ptr(y, torch.bfloat16), N, C, H, W, stream()),
            'ess_upsample_bilinear2x_add_c8')
+    return y
+
+
+def upsample_bilinear2x_add_c8_from_c8(a8, b8=None):
+    """bilinear_x2(a + b) from BF16_C8 sources to a BF16_C8 tensor."""
+    N, CB, H, W, _ = a8.shape
+    y = torch.empty(N, CB, 2 * H, 2 * W, 8, dtype=torch.bfloat16, device=a8.device)
+    _check(lib().ess_upsample_bilinear2x_add_c8_from_c8(ptr(a8, torch.bfloat16), ptr(b8, torch.bfloat16), ptr(y, torch.bfloat16), N,
+                                                        CB * 8, H, W, stream()), 'ess_upsample_bilinear2x_add_c8_from_c8')
     return y
 
 

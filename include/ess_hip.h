@@ -202,6 +202,12 @@ int ess_upsample_bilinear2x_add(const float* a, const float* b, float* y, int32_
  * the frozen encoder: identical MFMA operands, half the bytes).  a, b: fp32 [N][C][H][W]; W even.                          */
 int ess_upsample_bilinear2x_add_c8(const float* a, const float* b, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
                                    ess_stream_t stream);
+
+/* The same map from BF16_C8 SOURCES a (and b, or NULL), [N][ceil(C/8)][H][W][8] bfloat16: what the frozen encoder's kernels leave
+ * as staging copies.  Bit-identical to ess_upsample_bilinear2x_add_c8 applied to the sources' values.
+ * Replaces: the same reference lines (e2vid/model/submodules.py:83-93, unet.py:12-13,176). */
+int ess_upsample_bilinear2x_add_c8_from_c8(const void* a, const void* b, void* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                           ess_stream_t stream);
 /* 2x2 sum pooling = backward of nearest x2 upsampling (F.interpolate, models/style_networks.py:77).
  * accumulate != 0 adds into y.                                                                      */
 int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int32_t W_out, int32_t accumulate,

@@ -317,3 +317,19 @@ def test_l1_and_layout_roundtrip_c8(H):
     assert abs(loss.item() - ref.item()) < 1e-6 * ref.item() + 1e-8
     gs = bfr(torch.tensor(0.7 / a.numel()))
     assert torch.equal(un8(H, da, 16), torch.sign(a - b) * gs)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 6, 10), (1, 24, 7, 12), (2, 8, 1, 2)])
+def test_upsample_bilinear_from_c8_sources(H, shape):
+    """bilinear x2 of (a + b) from BF16_C8 sources == the fp32-source kernel fed the sources' bf16 values (bit-identical: same
+    expression, same order), and == F.interpolate on them up to the output's bf16 rounding.  Reference: e2vid/model/submodules.py:83-93."""
+    g = torch.Generator().manual_seed(21)
+    N, C, Hh, Ww = shape
+    a, b = bfr(torch.randn(N, C, Hh, Ww, generator=g)), bfr(torch.randn(N, C, Hh, Ww, generator=g))
+    a8, b8 = c8(H, a), c8(H, b)
+    for second in (b8, None):
+        got = H.upsample_bilinear2x_add_c8_from_c8(a8, second)
+        want = H.upsample_bilinear2x_add_c8(a.cuda(), None if second is None else b.cuda())
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        ref = F.interpolate(a + (b if second is not None else 0), scale_factor=2, mode='bilinear', align_corners=False)
+        assert_bf16_close(un8(H, got, C), bfr(ref), 'bilinear from BF16_C8 sources', ulps=1.0)
