@@ -157,9 +157,19 @@ class ConvLayer(nn.Module):
         k = c.kernel_size[0]
         x8 = _c8_of(x) if bf and x1 is None and hip.c8_stageable(k, c.stride[0], c.padding[0]) else None
         skip_fp32 = c8_only and c8 is not None
+        # copy-only outputs without a residual leave through the BF16_C8-OUTPUT epilogue (16-byte stores, 32-bit offsets) instead of
+        # the fp32 epilogue's optional copy (8-byte stores): the same values (acc * scale + shift, ReLU, round to nearest even)
+        as_out = skip_fp32 and residual is None and self.activation in (None, 'relu')
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
-            hip.conv_forward(spec, x8, None, packed_weight(spec, wt), scale, shift, residual,
-                             out=None if skip_fp32 else out, out_bf=c8, src_fmt=hip.FMT_BF16_C8)
+            if as_out:
+                hip.conv_forward(spec, x8, None, packed_weight(spec, wt), scale, shift, None, out=c8, src_fmt=hip.FMT_BF16_C8,
+                                 out_fmt=hip.FMT_BF16_C8)
+            else:
+                hip.conv_forward(spec, x8, None, packed_weight(spec, wt), scale, shift, residual,
+                                 out=None if skip_fp32 else out, out_bf=c8, src_fmt=hip.FMT_BF16_C8)
+        elif as_out:
+            hip.conv_forward(spec, _fp32(x), None if x1 is None else _fp32(x1), packed_weight(spec, wt), scale, shift, None, out=c8,
+                             out_fmt=hip.FMT_BF16_C8)
         else:
             hip.conv_forward(spec, _fp32(x), None if x1 is None else _fp32(x1), packed_weight(spec, wt), scale, shift,
                              residual, out=None if skip_fp32 else out, out_bf=c8)
