@@ -238,8 +238,12 @@ class UpsampleConvLayer(nn.Module):
         scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=up0.device)
         copy = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, up0.device) if (c8_only and c8) else None
-        hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=None if copy is not None else out,
-                         out_bf=copy, src_fmt=hip.FMT_BF16_C8 if c8 else hip.FMT_F32_NCHW)
+        if copy is not None and self.activation in (None, 'relu'):  # (the BF16_C8-output epilogue: see ConvLayer.forward)
+            hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=copy, src_fmt=hip.FMT_BF16_C8,
+                             out_fmt=hip.FMT_BF16_C8)
+        else:
+            hip.conv_forward(spec, up0, up1, packed_weight(spec, c.weight), scale, shift, out=None if copy is not None else out,
+                             out_bf=copy, src_fmt=hip.FMT_BF16_C8 if c8 else hip.FMT_F32_NCHW)
         if copy is not None:
             _attach_c8(out, copy)
             _mark_fp32_unwritten(out)
