@@ -305,11 +305,15 @@ __device__ unsigned long long g_wg_trace[1024 * 8 * 40];
 // (counted vmcnt: the younger tile stays in flight), the MFMA waves two units before the end of the current one -- their fragment
 // reads run two units ahead of the MFMAs (counted lgkmcnt) and continue into the next tile behind that barrier.
 // Measured (B = 8): 256 -> 256 @ 60x80 101 us (register-staged kernel of this file's first version) -> 56 us incl. the 8 us
-// reduce; 2930 cycles per tile = 79 % of the MFMA rate in the loop.  The rest is one wave's issue stream: an MFMA wave cannot
-// issue its 20 ds_reads per 9 MFMAs under its own MFMAs (2304 + 24 x ~26); a second MFMA wave per SIMD needs <= 170 registers
-// (16x16x32 tiles, 72 accumulators): not done.  Two K-groups of four waves issuing their own DMA (1.37 us per tile, but 34 us
-// of tile-independent time) and 32 x 32 pair tiles with a wave-private pixel range (4x smaller slabs, 2x the L2 -> LDS traffic,
-// 20 DMA issues per tile and wave) were measured and dropped.
+// reduce; 2930 cycles per tile = 79 % of the MFMA rate in the loop.  What bounds it is the L2 -> LDS FILL RATE: a tile is 40 KB
+// of DMA per 2304 MFMA cycles, i.e. 26-30 GB/s per CU, and the chip's LDS-DMA fill rate is ~6.4-6.8 TB/s = 25-26 GB/s per CU
+// (MI355X_MICROARCH.md, ldsdma-fill).  Three changes to the MFMA waves' side that all measured +-0 say the same: fragment reads
+// pipelined across tile boundaries (kept), two MFMA waves per SIMD on 16x16x32 tiles (142 registers, 12 waves), 45 % fewer LDS
+// reads by assembling the three filter columns of a row from 12 pixels read once (v_alignbyte; note: hipcc realigns an odd
+// register quad through SCRATCH unless it is moved explicitly -- 3.5x slower until it was).  More flops per DMA byte needs a
+// 128 x 64 pair tile = 295 KB of accumulators, i.e. no registers left for loader waves.  Two K-groups of four waves issuing their
+// own DMA (1.37 us per tile, but 34 us of tile-independent time) and 32 x 32 pair tiles with a wave-private pixel range (4x
+// smaller slabs, 2x the L2 -> LDS traffic, 20 DMA issues per tile and wave) were measured and dropped as well.
 template <int NST>
 __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   using G = DmaGeom;
