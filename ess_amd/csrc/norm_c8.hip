@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
                                                         const u32x4n* __restrict__ dy, const float* __restrict__ stats,
                                                         double* sums, int hw, int nseg, int seg_stride, int CB, int C,
                                                         int per_sample_stats, int relu, int relu_from_y) {
-  __shared__ double redd[16];
+  __shared__ double redd[4 * 16];
   const int g = blockIdx.x, nsl = gridDim.y, sl = blockIdx.y;
   const int len = (hw + nsl - 1) / nsl;
   const int i0 = sl * len, i1 = min(hw, i0 + len);
@@ -273,27 +273,36 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
       }
     }
   }
+  // the 16 block sums with ONE barrier (per value: wave sum, then the waves in order -- the order block_sum_d uses; 16 calls of
+  // it were 32 barriers at the end of a kernel that streams its slice in about the same time)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const double a = block_sum_d(s0[j], redd), b = block_sum_d(s1[j], redd);
-    if (threadIdx.x == 0) {
-      sums[(((size_t)g * nsl + sl) * 8 + j) * 2] = a;
-      sums[(((size_t)g * nsl + sl) * 8 + j) * 2 + 1] = b;
-    }
+    const double a = wave_sum_d(s0[j]), b = wave_sum_d(s1[j]);
+    if (lane == 0) { redd[w * 16 + 2 * j] = a; redd[w * 16 + 2 * j + 1] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0;
+    for (int i = 0; i < 4; ++i) t += redd[i * 16 + threadIdx.x];
+    sums[((size_t)g * nsl + sl) * 16 + threadIdx.x] = t;
   }
 }
 
-// totals of a group's partials for its 8 channels (wave-uniform addresses: scalar loads), in slice order
+// totals of a group's partials for its 8 channels, in slice order: sixteen lanes walk the slices (one 128-byte line per slice),
+// the workgroup picks the totals up from LDS.  (The first version let every thread total all 16 x nsl doubles through scalar
+// loads: up to 1024 dependent-latency loads in front of every workgroup of the apply kernels.)  blockDim.x >= 64.
 __device__ __forceinline__ void group_total8(const double* sums, int g, int nsl, double (&t0)[8], double (&t1)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { t0[j] = 0; t1[j] = 0; }
-  for (int k = 0; k < nsl; ++k) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      t0[j] += sums[(((size_t)g * nsl + k) * 8 + j) * 2];
-      t1[j] += sums[(((size_t)g * nsl + k) * 8 + j) * 2 + 1];
-    }
+  __shared__ double tot[16];
+  if (threadIdx.x < 16) {
+    const double* p = sums + (size_t)g * nsl * 16 + threadIdx.x;
+    double t = 0;
+    for (int k = 0; k < nsl; ++k) t += p[(size_t)k * 16];
+    tot[threadIdx.x] = t;
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { t0[j] = tot[2 * j]; t1[j] = tot[2 * j + 1]; }
 }
 
 // InstanceNorm forward map (grid: (N*CB, chunks))
