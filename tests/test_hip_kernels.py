@@ -362,6 +362,9 @@ def test_glue(H):
                                                                    align_corners=False)) < 1e-6
     x = torch.randn(2, 3, 8, 12, generator=g)
     assert relerr(H.sumpool2x2(dev(x)), F.avg_pool2d(x, 2) * 4) < 1e-6
+    from ess_amd.models.submodules import InterpolationLayer  # standalone nearest x2 (reference models/submodules.py:7-24)
+    with torch.no_grad():
+        assert torch.equal(InterpolationLayer(scale_factor=2, mode='nearest')(dev(x)).cpu(), F.interpolate(x, scale_factor=2, mode='nearest'))
     assert torch.equal(H.add(dev(a), dev(b)).cpu(), a + b)
     for ev in (torch.randn(2, 2, 24, 40, generator=g) * (torch.rand(2, 2, 24, 40, generator=g) < 0.1).float(),
                torch.zeros(1, 5, 4, 6), torch.randn(1, 3, 5, 7, generator=g)):
