@@ -302,13 +302,15 @@ def main():
         torch.cuda.synchronize()
 
     graph_note = 'eager'
-    if world == 1 and not args.no_graph:
+    if not args.no_graph:
         try:
             trainer.enable_step_graph(batch, warmup=2)
-            graph_note = 'hipGraph replay (whole step captured once)'
+            graph_note = 'hipGraph replay (whole step captured once)' if world == 1 else \
+                'hipGraph replay (forward + backward) | flat-gradient all-reduce | hipGraph replay (optimisers)'
         except Exception as e:  # noqa: BLE001  (the eager step is the same computation; say so in the record)
             graph_note = f'eager (capture failed: {type(e).__name__}: {e})'
             trainer._g = None
+            trainer._g_tail = None
     for _ in range(args.warmup):
         trainer.train_step(batch)
     sync()

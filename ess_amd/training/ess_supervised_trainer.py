@@ -65,10 +65,14 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
             return self._replay_step(input_batch)
         return self._train_step_eager(input_batch)
 
-    def _train_step_eager(self, input_batch):
+    def _train_step_eager(self, input_batch, optimise=True):
+        """optimise=False (recording the data-parallel step: BaseTrainer.enable_step_graph): stop behind the backward pass."""
         opt = self.optimizers_dict['optimizer_back']
         opt.zero_grad()
         d_final_loss, d_losses, d_outputs = self.task_train_step(input_batch)
+        if not optimise:
+            Fn.unit_backward([d_final_loss])
+            return d_losses, d_outputs, d_final_loss
         self.grad_reducer.arm(opt, n_buckets=3)  # data parallel: bucketed all-reduce issued from inside the backward
         Fn.unit_backward([d_final_loss])  # == d_final_loss.backward(), without the gradient-times-one pass
         self.grad_reducer.wait()

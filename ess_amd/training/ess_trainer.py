@@ -121,7 +121,8 @@ class ESSModel(base_trainer.BaseTrainer):
             return self._replay_step(input_batch)
         return self._train_step_eager(input_batch)
 
-    def _train_step_eager(self, input_batch):
+    def _train_step_eager(self, input_batch, optimise=True):
+        """optimise=False (recording the data-parallel step: BaseTrainer.enable_step_graph): stop behind the backward passes."""
         losses, outputs = {}, {}
         opt_front, opt_back = self.optimizers_dict['optimizer_front_sensor_a'], self.optimizers_dict['optimizer_back']
         opt_back.zero_grad()
@@ -157,15 +158,20 @@ class ESSModel(base_trainer.BaseTrainer):
             # (the weight-gradient kernels add into .grad themselves: no AccumulateGrad leaf tells the engine to join B)
             torch.cuda.current_stream().wait_stream(self._side_stream)
         else:
+            overlap = optimise  # (recording the data-parallel step: no collective inside the capture, the reduce follows the graph)
             Fn.unit_backward(self._e_terms)  # image encoder only: the decoder was frozen while this graph was recorded
-            self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
-            self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
+            if overlap:
+                self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
+                self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
             Fn.unit_backward(self._t_terms)  # decoder only
-            self.grad_reducer.flush()
+            if overlap:
+                self.grad_reducer.flush()
         final_loss = final_loss + e_loss.detach() + t_loss.detach()
         losses.update(event_losses)
         outputs.update(event_outputs)
 
+        if not optimise:
+            return losses, outputs, final_loss
         self.grad_reducer.wait()
         opt_back.step()
         opt_front.step()

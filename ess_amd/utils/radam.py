@@ -17,6 +17,8 @@ from ..functional import repack
 
 
 class RAdam(Optimizer):
+    _SLOTS = 8  # pinned staging slots of the step scalars (prepare_step)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
@@ -90,11 +92,22 @@ class RAdam(Optimizer):
         n_sma, step_size = self.rectification(self._step, beta1, beta2)
         if self._hyper is None:
             self._hyper = torch.zeros(2, dtype=torch.float32, device=self.flat_param.device)
-            self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+            # a ring of pinned staging slots: the copy below is asynchronous, and a caller that replays captured steps without
+            # synchronising runs several steps ahead of the device -- one slot would be overwritten with step t+1's scalars
+            # before the copy of step t has read it
+            self._hyper_host = torch.zeros(self._SLOTS, 2, dtype=torch.float32).pin_memory()
+            self._hyper_done = [None] * self._SLOTS
+        slot = self._step % self._SLOTS
+        if self._hyper_done[slot] is not None:
+            self._hyper_done[slot].synchronize()  # (the copy issued _SLOTS steps ago)
         f32 = lambda v: float(torch.tensor(float(v), dtype=torch.float32))  # noqa: E731  (the C ABI of ess_radam_step took floats)
-        self._hyper_host[0] = -f32(step_size) * f32(group['lr'])  # product in double, rounded once on assignment
-        self._hyper_host[1] = 1.0 if n_sma >= 5 else 0.0
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._hyper_host[slot, 0] = -f32(step_size) * f32(group['lr'])  # product in double, rounded once on assignment
+        self._hyper_host[slot, 1] = 1.0 if n_sma >= 5 else 0.0
+        self._hyper.copy_(self._hyper_host[slot], non_blocking=True)
+        if self._hyper.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_done[slot] = ev
         self._prepared = True
 
     def step(self, closure=None):
