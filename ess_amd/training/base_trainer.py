@@ -104,12 +104,15 @@ class BaseTrainer(object):
         self._fork_branches = os.environ.get('ESS_GRAPH_FORK', '1') != '0'  # independent branches on forked streams (trainers that have them)
         self._capturing = True
         try:
-            with torch.cuda.graph(self._g):
+            # (under a process group: thread-local error mode -- the collective backend's watchdog thread queries events while this
+            # thread captures, which the default global mode treats as a capture violation)
+            mode = {'capture_error_mode': 'thread_local'} if dp else {}
+            with torch.cuda.graph(self._g, **mode):
                 losses, outputs, final = self._train_step_eager(static_batch, optimise=not dp)
                 self._g_keys = sorted(losses)
                 self._g_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._g_keys] + [final.detach().float().reshape(())])
             if dp:
-                with torch.cuda.graph(self._g_tail, pool=self._g.pool()):
+                with torch.cuda.graph(self._g_tail, pool=self._g.pool(), **mode):
                     for o in opts:
                         o.step()
         finally:
