@@ -117,8 +117,9 @@ class BaseTrainer(object):
                         o.step()
         finally:
             self._capturing = False
-        for o in opts:
-            o._step -= 1  # capture records the launches without running them: the step prepared above did not happen
+            for o in opts:
+                o._step -= 1  # capture records the launches without running them: the step prepared above did not happen
+                o._prepared = False
         self._g_like, self._g_outputs = example_batch, outputs
         return self
 
