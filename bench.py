@@ -311,6 +311,30 @@ def main():
             graph_note = f'eager (capture failed: {type(e).__name__}: {e})'
             trainer._g = None
             trainer._g_tail = None
+        if world > 1:
+            # Data parallel: the captured step's collectives sit between two graph replays; the eager step overlaps bucketed
+            # collectives with its backward.  Which one is faster depends on the collective backend -- measured here, 3 steps each
+            # (max over ranks), and every rank takes the same decision; the pick and both times go into the record.
+            def probe(n=3):
+                trainer.train_step(batch)  # (untimed: first step in this issue mode)
+                sync()
+                t = time.perf_counter()
+                for _ in range(n):
+                    trainer.train_step(batch)
+                sync()
+                tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return tt.item() / n * 1e3
+            captured = trainer._g is not None
+            ms_graph = probe() if captured else float('inf')
+            g, gt, trainer._g, trainer._g_tail = trainer._g, getattr(trainer, '_g_tail', None), None, None
+            ms_eager = probe()
+            if captured and ms_graph <= ms_eager:
+                trainer._g, trainer._g_tail = g, gt
+            else:
+                graph_note = 'eager' if not captured else f'eager (bucketed all-reduce inside the backward; probe: eager {ms_eager:.1f} ms vs captured {ms_graph:.1f} ms per step)'
+            if trainer._g is not None:
+                graph_note += f' (probe: captured {ms_graph:.1f} ms vs eager {ms_eager:.1f} ms per step)'
     for _ in range(args.warmup):
         trainer.train_step(batch)
     sync()

@@ -134,8 +134,13 @@ class BaseTrainer(object):
             o.prepare_step()
         self._g.replay()
         if self._g_tail is not None:  # data parallel: average the flat gradients over the ranks, then the optimiser graph
-            for o in opts:
-                self.grad_reducer.launch(o.flat_grad)
+            if not D.stream_ordered_collectives():
+                # gloo stages device tensors through the host on its own threads: left to wait for a busy stream itself it took
+                # 0.5-1 s per step (two ranks on one GPU); RCCL collectives are stream-ordered and need no host synchronisation
+                torch.cuda.current_stream().synchronize()
+            for o in opts:  # (a few collectives of <= 8 MB each, all in flight together, like the eager step's buckets)
+                for part in o.flat_grad.split(1 << 21):
+                    self.grad_reducer.launch(part)
             self.grad_reducer.wait()
             self._g_tail.replay()
         vec = self._g_vec.clone()  # the graph's own buffers are overwritten by the next replay

@@ -32,6 +32,11 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def stream_ordered_collectives():
+    """True for the RCCL ('nccl') backend: collectives are enqueued behind the current HIP stream's work and need no host sync."""
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
+
+
 class GradAllReducer:
     """Asynchronous averaged all-reduce of flat gradient buffers.
 
