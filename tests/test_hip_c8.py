@@ -333,3 +333,43 @@ def test_upsample_bilinear_from_c8_sources(H, shape):
         assert torch.equal(got.view(torch.int16), want.view(torch.int16))
         ref = F.interpolate(a + (b if second is not None else 0), scale_factor=2, mode='bilinear', align_corners=False)
         assert_bf16_close(un8(H, got, C), bfr(ref), 'bilinear from BF16_C8 sources', ulps=1.0)
+
+
+@pytest.mark.parametrize('shape', [(8, 256, 0, 256, 60, 80, 0), (8, 64, 64, 64, 240, 320, 1), (8, 64, 0, 32, 480, 640, 1)])
+def test_conv_wgrad_c8_full_size_properties(H, shape):
+    """BASELINE.json sizes (B = 8, the decoder's 60x80 / 240x320 / 480x640 layers): the BF16_C8 weight gradient (LDS-DMA tiles,
+    transposing LDS reads) against the fp32-NCHW-staged bf16 kernel on the same bf16-representable operands -- identical products,
+    fp32 accumulation in a different order -- plus linearity in dY and the accumulate form."""
+    N, C0, C1, Cout, Hv, Wv, m0 = shape
+    H.set_compute('bf16')
+    try:
+        dev = torch.device('cuda')
+        g = torch.Generator(device='cuda').manual_seed(11)
+        rnd = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16).float()  # noqa: E731
+        d0 = 2 if m0 else 1
+        x0, x1 = rnd(N, C0, Hv // d0, Wv // d0), (rnd(N, C1, Hv, Wv) if C1 else None)
+        dya, dyb = rnd(N, Cout, Hv, Wv), rnd(N, Cout, Hv, Wv)
+        spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, 3, 1, 1, H.SRC_NEAREST_UP2 if m0 else H.SRC_DIRECT, H.SRC_DIRECT)
+        x08, x18 = H.to_bf16_c8(x0), (H.to_bf16_c8(x1) if C1 else None)
+
+        def wg(dy, c8form):
+            dw, db = torch.empty(Cout, C0 + C1, 3, 3, device=dev), torch.empty(Cout, device=dev)
+            if c8form:
+                H.conv_wgrad(spec, x08, x18, H.to_bf16_c8(dy), dw, db)
+            else:
+                H.conv_wgrad(spec, x0, x1, dy, dw, db)
+            return dw, db
+        (wa, ba), (wr, br) = wg(dya, True), wg(dya, False)
+        scale = wr.abs().max()
+        assert ((wa - wr).abs().max() / scale).item() < 3e-5
+        assert ((ba - br).abs().max() / br.abs().max()).item() < 3e-5
+        # linearity: dW(dYa) + dW(dYb) == dW(dYa + dYb) up to the rounding of the sum to bf16 (a bf16-representable sum is needed:
+        # dYb := 2 dYa - dYa' would not be; use dYb = -dYa / 2, exact in bf16)
+        wh, _ = wg(-0.5 * dya, True)
+        assert ((wh + 0.5 * wa).abs().max() / scale).item() < 1e-6
+        wb, _ = wg(dyb, True)
+        acc = wa.clone()
+        H.conv_wgrad(spec, x08, x18, H.to_bf16_c8(dyb), acc, None, accumulate=True)
+        assert ((acc - (wa + wb)).abs().max() / scale).item() < 1e-6
+    finally:
+        H.set_compute('fp32')
