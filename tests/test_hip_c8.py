@@ -373,3 +373,37 @@ def test_conv_wgrad_c8_full_size_properties(H, shape):
         assert ((acc - (wa + wb)).abs().max() / scale).item() < 1e-6
     finally:
         H.set_compute('fp32')
+
+
+@pytest.mark.parametrize('shape', [(8, 256, 0, 256, 60, 80, 0, True, True), (8, 64, 64, 64, 240, 320, 1, False, False),
+                                   (8, 64, 0, 32, 480, 640, 1, True, False)])
+def test_conv_c8_full_size_against_fp32_form(H, shape):
+    """BASELINE.json sizes: the BF16_C8 -> BF16_C8 convolution (bias [+ residual] [+ ReLU], lean epilogue, accumulators started from
+    the bias) against the fp32-NCHW form of the same launch on the same bf16-representable operands: the stored values must be the
+    bf16 rounding of the fp32 result (one ulp where the fp32 sums differ in order)."""
+    N, C0, C1, Cout, Hv, Wv, m0, res, relu = shape
+    H.set_compute('bf16')
+    try:
+        dev = torch.device('cuda')
+        g = torch.Generator(device='cuda').manual_seed(13)
+        rnd = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16).float()  # noqa: E731
+        d0 = 2 if m0 else 1
+        x0, x1 = rnd(N, C0, Hv // d0, Wv // d0), (rnd(N, C1, Hv, Wv) if C1 else None)
+        w = torch.randn(Cout, C0 + C1, 3, 3, device=dev, generator=g) / math.sqrt(9 * (C0 + C1))
+        b = torch.randn(Cout, device=dev, generator=g)
+        r = rnd(N, Cout, Hv, Wv) if res else None
+        spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, 3, 1, 1, H.SRC_NEAREST_UP2 if m0 else H.SRC_DIRECT, H.SRC_DIRECT,
+                           act=H.ACT_RELU if relu else H.ACT_NONE)
+        pw, pb = H.pack_weights(spec, w), H.pack_rows(spec, b)
+        o = torch.empty(N, Cout, Hv, Wv, device=dev)
+        H.conv_forward(spec, x0, x1, pw, None, pb, r, out=o)
+        q = H.bf16_c8_empty(N, Cout, Hv, Wv, dev)
+        H.conv_forward(spec, H.to_bf16_c8(x0), H.to_bf16_c8(x1) if C1 else None, pw, None, pb, H.to_bf16_c8(r) if res else None, out=q,
+                       src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_BF16_C8)
+        got, ref = H.from_bf16_c8(q, Cout), o.to(torch.bfloat16).float()
+        # one bf16 ulp of the value -- or of the larger summand where bias / residual cancel the accumulator
+        tol = 2.0 ** -7 * ref.abs().clamp(min=2.0 ** -6)
+        bad = (got - ref).abs() > tol
+        assert int(bad.sum()) <= 1e-5 * bad.numel(), f'{int(bad.sum())} of {bad.numel()} elements off by more than a bf16 ulp'
+    finally:
+        H.set_compute('fp32')
