@@ -157,6 +157,10 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   const int mb = pl.cout_tile / 32;
   const bool c8 = a.fmt0 == ESS_FMT_BF16_C8;
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
+  if (is_paired(d) && !c8 && !a.residual && conv_bf16_head_applies(d, pl)) {  // 2-channel 5x5 head: K = the filter rows
+    conv_bf16_launch_head(d, pl, st, a);
+    return ess_launch_status("conv2d_forward(bf16, 5x5 head)");
+  }
   if (is_paired(d)) {  // 5x5: tap-paired wave-specialised kernel (the plan and the weight pack are specific to it)
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;
     ESS_CHECK_ARG(lds2 <= 160 * 1024, "conv(bf16, 5x5): two stages of %d B exceed the 160 KiB LDS", pl.lds_bytes);

@@ -1,0 +1,167 @@
+// 5x5 / stride-1 convolution of a 1- or 2-channel fp32 image on the bf16 matrix cores: the head of the recurrent encoder
+// (reference e2vid/model/unet.py:118 -- ConvLayer(num_bins, 32, kernel_size=5, padding=2) on every time step's voxel grid).
+//
+// The tap-paired kernel (conv_bf16_pair.hip) runs this layer as ONE 8-channel chunk with 6 of the 8 channels zero: all prologue
+// and epilogue, 167 us at B=8 / 480x640 against a ~35 us floor of its 157 MB output.  Here the K dimension is the filter itself:
+// row r = c * 5 + ky (10 rows for 2 channels) x 8 column slots (kx = 0..4, three zero weights), i.e. five 32x32x16 MFMAs per 32
+// pixels with K-step s, lane half h <-> row 2s + h.  A lane's B operand for one K-step is 8 CONSECUTIVE pixels of one input row
+// starting at its own pixel: four ds_read2_b32 from an fp32 tile (4-byte aligned at any x), converted to bf16 in registers.
+// The weights are read from the tap-paired pack the plan already prescribes for this descriptor (no format of its own) and
+// rearranged once per workgroup.  Epilogue: scale / shift / ReLU, BF16_C8 vectors (16-byte stores) and / or fp32 NCHW planes.
+#include "conv_bf16_common.h"
+
+namespace {
+
+using namespace essconv;
+
+constexpr int HT_W = 32, HT_H = 32, HT_IW = 40, HT_IH = HT_H + 4;
+
+template <bool SC>
+__global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a, int tiles_x, int tiles_y) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+  __shared__ float tile[2 * HT_IH * HT_IW];
+  __shared__ __attribute__((aligned(16))) u32x4 wfrag[5 * 2 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ct = logical % a.n_cout_tiles;
+  const int sp = logical / a.n_cout_tiles;
+  const int n_tiles = tiles_x * tiles_y;
+  const int t = sp % n_tiles, n = sp / n_tiles;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int y0 = ty * HT_H, x0 = tx * HT_W;
+  const unsigned HW = (unsigned)(a.Hout * a.Wout);
+
+  // ---- weights: tap-paired pack [tile][chunk 0][pair][tap parity][cout 32][channel 8] -> A fragments [K-step][half][cout][8 slots]
+  const unsigned short* wp = (const unsigned short*)a.wpk + (size_t)ct * (13 * 2 * 32 * 8);
+  for (int i = tid; i < 320; i += 256) {
+    const int m = i & 31, r = i >> 5;
+    const int c = r / 5, ky = r - 5 * c;
+    unsigned v[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) v[kx] = wp[(size_t)((ky * 5 + kx) * 32 + m) * 8 + c];  // (pair * 2 + parity = tap)
+    const u32x4 f = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4], 0u};
+    wfrag[r * 32 + m] = f;  // row r = 2 s + h
+  }
+  // ---- input tile: both channels, 2-pixel halo, zero outside the image (and for an absent second channel)
+  {
+    const ess_rsrc r_in = ess_make_rsrc(a.src0 + (size_t)n * a.C0 * a.Hin * a.Win, (size_t)a.C0 * a.Hin * a.Win * 4);
+    constexpr int NLD = (2 * HT_IH * HT_IW + 255) / 256;
+    float ld[NLD];  // every load is in flight before the first LDS write
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 256;
+      const int c = i / (HT_IH * HT_IW), rem = i - c * (HT_IH * HT_IW);
+      const int iy = rem / HT_IW, ix = rem - iy * HT_IW;
+      const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
+      const bool ok = (i < 2 * HT_IH * HT_IW) & (c < a.C0) & (gy >= 0) & (gy < a.Hin) & (gx >= 0) & (gx < a.Win);
+      ld[k] = ess_bload(r_in, ok ? (unsigned)((c * a.Hin + gy) * a.Win + gx) * 4u : ESS_OOB, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 256;
+      if (i < 2 * HT_IH * HT_IW) tile[i] = ld[k];
+    }
+  }
+  // per-channel scale / shift of this lane's rows (the packed vectors are padded to the 32-row tile)
+  float sc[16], sh[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c0 = ct * 32 + j * 8 + 4 * half;
+    const float4 s4 = SC ? *(const float4*)(a.scale + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 h4 = a.shift ? *(const float4*)(a.shift + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[4 * j] = s4.x; sc[4 * j + 1] = s4.y; sc[4 * j + 2] = s4.z; sc[4 * j + 3] = s4.w;
+    sh[4 * j] = h4.x; sh[4 * j + 1] = h4.y; sh[4 * j + 2] = h4.z; sh[4 * j + 3] = h4.w;
+  }
+  __syncthreads();
+  u32x4 af[5];
+  int roff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int r = 2 * s + half, c = r / 5, ky = r - 5 * c;
+    af[s] = wfrag[r * 32 + p];
+    roff[s] = (c * HT_IH + ky) * HT_IW + p;
+  }
+  const bool relu = a.act == ESS_ACT_RELU;
+  const bool out8 = a.fmt_out == ESS_FMT_BF16_C8;
+  const int nb_all = (a.Cout + 7) >> 3;
+  void* dst8 = out8 ? (void*)a.out : a.out_bf;
+  float* dst32 = out8 ? nullptr : a.out;
+  const ess_rsrc r_8 = ess_make_rsrc(dst8 ? (const char*)dst8 + (size_t)n * nb_all * HW * 16 : (const char*)a.src0, dst8 ? (size_t)nb_all * HW * 16 : 0);
+  const ess_rsrc r_32 = ess_make_rsrc(dst32 ? (const char*)(dst32 + (size_t)n * a.Cout * HW) : (const char*)a.src0, dst32 ? (size_t)a.Cout * HW * 4 : 0);
+  const int x = x0 + p;
+#pragma unroll 2
+  for (int rr = 0; rr < HT_H / 4; ++rr) {
+    const int ly = wave * (HT_H / 4) + rr;
+    const int y = y0 + ly;
+    if (y >= a.Hout) break;  // (wave-uniform)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const float* src = tile + ly * HT_IW + roff[s];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[j];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, pack8(v)), acc, 0, 0, 0);
+    }
+    const bool inb = x < a.Wout;
+    const unsigned pix = (unsigned)(y * a.Wout + x);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v[r] = SC ? acc[r] * sc[r] + sh[r] : acc[r] + sh[r];
+      if (relu) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (dst32) {  // (uniform) accumulator register r = 4 j + i <-> channel ct*32 + 8 j + 4 half + i
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ct * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        ess_bstore(v[r], r_32, (inb && c < a.Cout) ? ((unsigned)c * HW + pix) * 4u : ESS_OOB, 0);
+      }
+    }
+    if (dst8) {  // (uniform)
+#pragma unroll
+      for (int jp = 0; jp < 4; jp += 2) {
+        uint2 pk[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          bf16x4 b;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = ct * 32 + 8 * (jp + jj) + 4 * half + i;
+            b[i] = (__bf16)(c < a.Cout ? v[4 * (jp + jj) + i] : 0.f);
+          }
+          pk[jj] = __builtin_bit_cast(uint2, b);
+        }
+        // exchange halves: lanes 0-31 end up with the whole vector of block jp, lanes 32-63 with that of block jp + 1
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
+        const int myblk = ct * 4 + jp + half;
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_8, (int)((inb && myblk < nb_all) ? ((unsigned)myblk * HW + pix) * 16u : ESS_OOB), 0, 0);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace essconv {
+
+bool conv_bf16_head_applies(const EssConvDesc* d, const EssConvPlan& pl) {
+  static const bool on = [] { const char* e = getenv("ESS_CONV_HEAD"); return !(e && e[0] == '0'); }();
+  return on && d->compute == ESS_COMPUTE_BF16 && d->ksize == 5 && d->stride == 1 && d->pad == 2 && d->C1 == 0 && d->C0 <= 2 &&
+         d->mode0 == ESS_SRC_DIRECT && d->fmt0 == ESS_FMT_F32_NCHW && d->epilogue == ESS_EPI_LINEAR && d->out_split == 0 &&
+         (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU) && pl.cout_tile == 32 && pl.n_chunks == 1 && pl.ck == 8;
+}
+
+void conv_bf16_launch_head(const EssConvDesc* d, const EssConvPlan& pl, hipStream_t st, const ConvKArgs& a) {
+  const int tiles_x = ceil_div(d->W_out, HT_W), tiles_y = ceil_div(d->H_out, HT_H);
+  const dim3 grid((unsigned)(tiles_x * tiles_y * pl.n_cout_tiles * d->N));
+  if (a.scale) hipLaunchKernelGGL(conv_bf16_head5_kernel<true>, grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+  else hipLaunchKernelGGL(conv_bf16_head5_kernel<false>, grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+}
+
+}  // namespace essconv

@@ -749,3 +749,39 @@ def test_augment_image_label_vs_oracle(H, shape):
     o2, l2 = H.augment_image_label(dev(img), dev(lab), dev(ident), Ho, Wo, None)
     r2, rl2 = O.augment_image_label(img, lab, ident, Ho, Wo, None)
     assert torch.equal(l2.cpu(), rl2) and torch.equal((o2.cpu() * 255).round(), (r2 * 255).round())
+
+
+@pytest.mark.parametrize('case', [(2, 2, 32, 37, 70, 1, 'fp32'), (1, 2, 32, 64, 96, 1, 'c8'), (2, 1, 32, 33, 41, 0, 'both'),
+                                  (1, 2, 24, 40, 64, 1, 'c8'), (1, 2, 64, 35, 33, 1, 'both'), (2, 2, 20, 16, 31, 0, 'fp32')])
+def test_conv_head5x5_bf16(H, case):
+    """The recurrent encoder's head (reference e2vid/model/unet.py:118: 5x5, padding 2, 1-2 input channels) on its dedicated bf16
+    kernel (conv_bf16_head.hip): exact (to accumulation order) against an fp32 conv of bf16-rounded operands; outputs as fp32
+    planes, as a BF16_C8 tensor, or as planes + BF16_C8 copy -- ragged sizes, channel tails, two channel tiles."""
+    N, C, Cout, Hv, Wv, act, form = case
+    g = torch.Generator().manual_seed(7 + Cout + Hv)
+    x = torch.randn(N, C, Hv, Wv, generator=g)
+    w = torch.randn(Cout, C, 5, 5, generator=g) / math.sqrt(25 * C)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(_bf(x), _bf(w), b, 1, 2)
+    ref = torch.relu(ref) if act else ref
+    spec = H.conv_spec(N, Hv, Wv, C, 0, Cout, 5, 1, 2, act=act, compute=H.COMPUTE_BF16)
+    pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+    out = torch.full(ref.shape, float('nan')).cuda()
+    q = H.bf16_c8_empty(N, Cout, Hv, Wv, torch.device('cuda'))
+    q.view(torch.int16).fill_(0x7fc0)  # NaN: every vector must be written
+    if form == 'fp32':
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=out)
+    elif form == 'c8':
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=q, out_fmt=H.FMT_BF16_C8)
+    else:
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=out, out_bf=q)
+    if form != 'c8':
+        assert relerr(out, ref) < 2e-5
+    if form != 'fp32':
+        got = H.from_bf16_c8(q, Cout).cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+        if form == 'both':  # the copy is the rounding of the planes
+            assert torch.equal(got, out.cpu().bfloat16().float())
+        pad = q.view(torch.int16).view(N, -1, Hv, Wv, 8)[:, -1, :, :, (Cout % 8) or 8:]
+        assert int(pad.abs().max() if pad.numel() else 0) == 0  # tail channels of the last block stay zero
