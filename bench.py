@@ -325,7 +325,11 @@ def main():
                 tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=device)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 return tt.item() / n * 1e3
-            captured = trainer._g is not None
+            ok = torch.tensor([1.0 if trainer._g is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # a capture that failed on ANY rank: every rank runs eager
+            captured = ok.item() > 0
+            if not captured:
+                trainer._g = trainer._g_tail = None
             ms_graph = probe() if captured else float('inf')
             g, gt, trainer._g, trainer._g_tail = trainer._g, getattr(trainer, '_g_tail', None), None, None
             ms_eager = probe()

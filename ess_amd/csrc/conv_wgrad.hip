@@ -775,9 +775,11 @@ __global__ __launch_bounds__(256) void wgrad_small1x1_mfma_kernel(const WgradArg
 //   <64, 1>: everything else (few weights, many splits): one tap per workgroup (blockIdx.y), 16 split groups of 64 lanes
 //            (1024 threads) -- there the slab reads are all that matters and they want as many loads in flight as possible.
 // Blocks past nblk_w (blockIdx.y == 0 only) reduce the bias slabs ws_b[split][co] the same way (one "tap").
+// tm (mapped != 0; 3x3 only): slab tap t lands in tap tm.m[t] of dw, or nowhere (< 0) -- the parity phases of a stride-2 filter
+struct TapMap { int mapped; signed char m[12]; };
 template <int E, int NT, int THREADS>
 __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, const float* ws_b, float* dw, float* db, int nsplit, int T,
-                                                           int CC, int Cout, int nblk_w, int accumulate) {
+                                                           int CC, int Cout, int nblk_w, int accumulate, const TapMap tm) {
   constexpr int G = THREADS / E, PITCH = E * NT + 1, U = NT == 1 ? 8 : 4;
   __shared__ float part[G * PITCH];
   int blk = blockIdx.x, t0 = blockIdx.y * NT, nt = min(NT, T - t0);
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, 
     if (blockIdx.y) return;
     blk -= nblk_w; ws = ws_b; dw = db; T = 1; CC = Cout; nt = 1;
   }
+  const bool mapped = tm.mapped && T == 9;
   const int el = threadIdx.x % E, g = threadIdx.x / E;
   const int e = blk * E + el;
   float acc[NT];
@@ -824,7 +827,9 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* ws, 
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < G; ++w) t += part[w * PITCH + idx];
-      float* dst = dw + (size_t)(blk * E + l) * T + t0 + u;
+      const int td = mapped ? tm.m[t0 + u] : t0 + u;
+      if (td < 0) continue;
+      float* dst = dw + (size_t)(blk * E + l) * T + td;
       *dst = accumulate ? *dst + t : t;
     }
   }
@@ -836,6 +841,20 @@ struct WPlan {
   int pyv, pxv, rv;
   size_t slab_floats;
 };
+
+// 3x3 / stride 2 / pad 1 on BF16_C8 tensors (ResNet layer2/3 entry convs): four launches of the stride-1 LDS-DMA kernel, one per
+// pixel-parity phase X_pq[y][x] = X[2y+p][2x+q] of the input (gathered by the DMA: WgradArgs.ps) -- tap (ky, kx) of the stride-2
+// filter is tap (ky', kx') of a stride-1 3x3 correlation of dY with phase (p, q): p = 0 <-> ky = 1 = ky'; p = 1 <-> ky = 0 = ky'
+// or ky = 2, ky' = 1 (same in x).  Each phase's reduce writes its 1 / 2 / 2 / 4 taps straight into dw (TapMap).
+inline bool s2_phases(const EssConvDesc* d) {
+  return d->fmt0 == ESS_FMT_BF16_C8 && d->fmt_out == ESS_FMT_BF16_C8 && d->ksize == 3 && d->stride == 2 && d->pad == 1 && d->C1 == 0 &&
+         d->mode0 == ESS_SRC_DIRECT && d->H_in == 2 * d->H_out && d->W_in == 2 * d->W_out;
+}
+inline EssConvDesc s2_phase_desc(const EssConvDesc* d) {
+  EssConvDesc p = *d;
+  p.stride = 1; p.H_in = d->H_out; p.W_in = d->W_out;
+  return p;
+}
 
 int wvalidate(const EssConvDesc* d) {
   ESS_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
@@ -851,8 +870,9 @@ int wvalidate(const EssConvDesc* d) {
     ESS_CHECK_ARG(d->C1 == 0 || d->fmt1 == d->fmt0, "wgrad: both sources of a concat must use the same format");
     ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "wgrad: the first BF16_C8 source of a concat must have a multiple of 8 channels");
     if (xc8 && dc8)
-      ESS_CHECK_ARG((d->ksize == 3 && d->stride == 1 && d->pad == 1) || (d->ksize == 1 && d->pad == 0 && d->mode0 == ESS_SRC_DIRECT && d->C1 == 0),
-                    "wgrad(BF16_C8): 3x3 / stride 1 / pad 1 and 1x1 / pad 0 convolutions only");
+      ESS_CHECK_ARG((d->ksize == 3 && d->stride == 1 && d->pad == 1) || (d->ksize == 1 && d->pad == 0 && d->mode0 == ESS_SRC_DIRECT && d->C1 == 0) ||
+                        s2_phases(d),
+                    "wgrad(BF16_C8): 3x3 / stride 1 / pad 1, 3x3 / stride 2 / pad 1 on even extents (one direct source) and 1x1 / pad 0 convolutions only");
     else if (xc8)
       ESS_CHECK_ARG(d->ksize == 1 && d->stride == 1 && d->pad == 0 && d->C1 == 0 && d->mode0 == ESS_SRC_DIRECT && d->C_out <= 32 && cin <= 32,
                     "wgrad(BF16_C8 X, fp32 dY): the 1x1 head only (C_in, C_out <= 32)");
@@ -941,7 +961,8 @@ int raise_lds(K kernel, int bytes) {
 
 extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   if (wvalidate(d)) return 0;
-  const WPlan w = wplan(d);
+  const EssConvDesc dp = s2_phases(d) ? s2_phase_desc(d) : *d;
+  const WPlan w = wplan(&dp);
   return (size_t)w.nsplit * w.slab_floats * 4;
 }
 
@@ -952,6 +973,45 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && dy && dw && workspace, "wgrad: null pointer");
   ESS_CHECK_ARG(d->C1 == 0 || src1, "wgrad: second source missing");
+  if (s2_phases(d)) {
+    const EssConvDesc dp = s2_phase_desc(d);
+    const WPlan w = wplan(&dp);
+    ESS_CHECK_ARG(workspace_bytes >= (size_t)w.nsplit * w.slab_floats * 4, "wgrad: workspace too small");
+    ESS_CHECK_ARG((((uintptr_t)src0 | (uintptr_t)dy) & 15) == 0, "wgrad: BF16_C8 tensors must be 16-byte aligned");
+    const int cin = d->C0, CC = d->C_out * cin;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(w.co_tiles * w.ci_tiles * w.nsplit));
+    for (int ph = 0; ph < 4; ++ph) {
+      const int p = ph >> 1, q = ph & 1;
+      WgradBArgs bb{};
+      WgradArgs& a = bb.w;
+      a.src0 = src0; a.src1 = nullptr; a.dy = dy; a.ws = (float*)workspace;
+      a.ws_b = (db && ph == 0) ? a.ws + (size_t)w.nsplit * 9 * CC : nullptr;
+      a.N = d->N; a.Hin = dp.H_in; a.Win = dp.W_in; a.C0 = d->C0; a.C1 = 0; a.mode0 = ESS_SRC_DIRECT; a.mode1 = ESS_SRC_DIRECT;
+      a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = 1;
+      a.twl = w.twl; a.tiles_x = w.tiles_x; a.tiles_y = w.tiles_y; a.ntiles = w.ntiles;
+      a.IH = w.IH; a.IW = w.IW; a.plx = w.plx; a.ci_tiles = w.ci_tiles; a.npairs = w.co_tiles * w.ci_tiles; a.nsplit = w.nsplit;
+      a.dy_c8 = 1; a.ps = 1; a.pp = p; a.pq = q;
+      bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
+      if ((rc = wgrad_c8_launch(bb, 9, 1, 2 * w.lds_bytes, grid, st))) return rc;
+      TapMap tm{};
+      tm.mapped = 1;
+      for (int t = 0; t < 9; ++t) {
+        const int kyp = t / 3, kxp = t % 3;
+        const int ky = p == 0 ? (kyp == 1 ? 1 : -1) : (kyp == 0 ? 0 : kyp == 1 ? 2 : -1);
+        const int kx = q == 0 ? (kxp == 1 ? 1 : -1) : (kxp == 0 ? 0 : kxp == 1 ? 2 : -1);
+        tm.m[t] = (signed char)((ky < 0 || kx < 0) ? -1 : ky * 3 + kx);
+      }
+      const int nblk_w = ceil_div(CC, 64), nblk_b = a.ws_b ? ceil_div(d->C_out, 64) : 0;
+      if (CC >= 32768)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 9, 256>), dim3((unsigned)(nblk_w + nblk_b)), dim3(256), 0, st, a.ws, a.ws_b, dw, db, w.nsplit, 9,
+                           CC, d->C_out, nblk_w, accumulate, tm);
+      else
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1, 1024>), dim3((unsigned)(nblk_w + nblk_b), 9u), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
+                           w.nsplit, 9, CC, d->C_out, nblk_w, accumulate, tm);
+    }
+    return ess_launch_status("conv2d_wgrad(3x3 stride 2 by phases)");
+  }
   const WPlan w = wplan(d);
   ESS_CHECK_ARG(workspace_bytes >= (size_t)w.nsplit * w.slab_floats * 4, "wgrad: workspace too small");
   ESS_CHECK_ARG(w.lds_bytes <= 160 * 1024, "wgrad: LDS tile %d B too large", w.lds_bytes);
@@ -1022,9 +1082,9 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
   const int nblk_w = ceil_div(CC, E), nblk_b = (db && a.ws_b) ? ceil_div(d->C_out, E) : 0;
   if (wide)
     hipLaunchKernelGGL((wgrad_reduce_kernel<64, 9, 256>), dim3((unsigned)(nblk_w + nblk_b)), dim3(256), 0, st, a.ws, a.ws_b, dw, db, w.nsplit, T,
-                       CC, d->C_out, nblk_w, accumulate);
+                       CC, d->C_out, nblk_w, accumulate, TapMap{});
   else
     hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1, 1024>), dim3((unsigned)(nblk_w + nblk_b), (unsigned)T), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
-                       w.nsplit, T, CC, d->C_out, nblk_w, accumulate);
+                       w.nsplit, T, CC, d->C_out, nblk_w, accumulate, TapMap{});
   return ess_launch_status("conv2d_wgrad_reduce");
 }

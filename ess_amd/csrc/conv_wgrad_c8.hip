@@ -339,8 +339,8 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     const bool z0 = a.mode0 == ESS_SRC_ZERO_UP2, z1 = a.mode1 == ESS_SRC_ZERO_UP2;
     const int nbo = (a.Cout + 7) >> 3, nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
     const unsigned HWo16 = (unsigned)a.Hout * a.Wout * 16u;
-    const int W0 = a.Win >> sh0, W1 = a.Win >> sh1;
-    const unsigned HW0_16 = (unsigned)(a.Hin >> sh0) * W0 * 16u, HW1_16 = (unsigned)(a.Hin >> sh1) * W1 * 16u;
+    const int W0 = (a.Win << a.ps) >> sh0, W1 = a.Win >> sh1;  // (ps: parity-phase gather of the first source, see WgradArgs)
+    const unsigned HW0_16 = (unsigned)((a.Hin << a.ps) >> sh0) * W0 * 16u, HW1_16 = (unsigned)(a.Hin >> sh1) * W1 * 16u;
     int d_r[2], d_c[2], x_r[G::XP], x_c[G::XP];
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int pi = q * 64 + lane; d_r[q] = pi >> G::TWL; d_c[q] = pi & (G::TW - 1); }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
         const int gy = y0 - 1 + x_r[q], gx = x0 - 1 + x_c[q];
         const bool in = ((unsigned)gy < (unsigned)a.Hin) & ((unsigned)gx < (unsigned)a.Win);
         const bool odd = (gy | gx) & 1;
-        vx0[q] = (in & !(z0 & odd)) ? (unsigned)((gy >> sh0) * W0 + (gx >> sh0)) * 16u : OOBW;
+        vx0[q] = (in & !(z0 & odd)) ? (unsigned)((((gy << a.ps) + a.pp) >> sh0) * W0 + (((gx << a.ps) + a.pq) >> sh0)) * 16u : OOBW;
         vx1[q] = (in & !(z1 & odd)) ? (unsigned)((gy >> sh1) * W1 + (gx >> sh1)) * 16u : OOBW;
       }
 #pragma unroll

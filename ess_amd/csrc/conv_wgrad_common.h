@@ -15,6 +15,9 @@ struct WgradArgs {
   int IH, IW, plx;  // X tile rows/cols, per-channel pitch (odd)
   int ci_tiles, npairs, nsplit;
   int dy_c8;      // dY is a BF16_C8 tensor (7x7 stem variant)
+  // stride-2 3x3 through the stride-1 LDS-DMA kernel: ps = 1 reads the first source at pixel (2 y + pp, 2 x + pq) -- one parity
+  // phase of it, gathered by the DMA itself; Hin / Win are then the phase's extents (= the output's).  ps = 0: plain.
+  int ps, pp, pq;
 };
 
 constexpr unsigned OOBW = 0x80000000u;  // beyond any buffer: bounds-checked loads return 0

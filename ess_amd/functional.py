@@ -282,7 +282,9 @@ class Conv2dFn(torch.autograd.Function):
             if need1:
                 d1 = hip.sumpool2x2(dv1) if mode1 == hip.SRC_NEAREST_UP2 else dv1
         s2_1x1 = s == 2 and k == 1 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1)
-        direct = needw and _direct(weight) and not (s == 2 and k == 3)
+        # 3x3 / stride 2 on BF16_C8 tensors: the library runs the parity phases itself (DMA gather, taps routed by the reduce)
+        s2_lib = s == 2 and k == 3 and p == 1 and c8in and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1)
+        direct = needw and _direct(weight) and (not (s == 2 and k == 3) or s2_lib)
         if direct:
             bias = ctx.bias_ref() if ctx.bias_ref is not None else None
             db_t = bias.grad if (needb and bias is not None and _direct(bias)) else None
@@ -300,7 +302,7 @@ class Conv2dFn(torch.autograd.Function):
         elif needw or needb:
             dw = torch.empty_like(weight)
             db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if ctx.has_bias else None
-            if s == 2 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1) and \
+            if s == 2 and C1 == 0 and mode0 == hip.SRC_DIRECT and not (Hv & 1) and not (Wv & 1) and not s2_lib and \
                     ((k == 3 and p == 1) or (k == 1 and p == 0 and not c8in)):
                 _wgrad_stride2_by_phases(x0, dy, dw, db, k)
             else:

@@ -239,6 +239,9 @@ WGRAD_C8_CASES = [
     (2, 128, 0, 128, 12, 20, 1, 1, 0, 0, 0, False),     # 1x1 / stride 1
     (1, 24, 0, 40, 17, 30, 3, 1, 1, 0, 0, True),        # ragged channel blocks, odd extents
     (2, 64, 0, 64, 6, 10, 3, 1, 1, 0, 0, True),         # smaller than one pixel tile
+    (2, 64, 0, 128, 24, 40, 3, 2, 1, 0, 0, True),       # ResNet layer2 entry: 3x3 / stride 2 by parity phases (DMA gather)
+    (1, 128, 0, 256, 20, 36, 3, 2, 1, 0, 0, False),     # layer3 entry, output smaller than / ragged against the 16 x 8 tile
+    (2, 24, 0, 40, 10, 12, 3, 2, 1, 0, 0, True),        # ragged channel blocks
 ]
 
 
