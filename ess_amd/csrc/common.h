@@ -52,11 +52,28 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // Gate non-linearities of the fused epilogues on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
 // libm's expf/tanhf cost ~25-40 VALU instructions per call, which made the ConvLSTM epilogue as expensive as the K loop
 // of the 8-chunk level-0 gate conv.  Absolute error <= ~3e-7 on outputs in (0,1) / (-1,1).
-__device__ __forceinline__ float ess_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ess_tanh(float x) {
-  const float t = __expf(-2.0f * fabsf(x));  // in (0, 1]: no overflow for any x
-  return copysignf((1.0f - t) * __frcp_rn(1.0f + t), x);
+// Gate activations.  FAST = false: `__frcp_rn`, the IEEE-exact division sequence (two v_div_scale, v_rcp, five FMAs, v_div_fmas,
+// v_div_fixup -- 14 VALU instructions per sigmoid) for the exact-fp32 configuration, whose parity contract is 1e-3 on logits with
+// exact argmax.  FAST = true (the bf16 configuration's translation units define ESS_FAST_ACT): v_rcp_f32, 1 ulp, 4 instructions --
+// the ConvLSTM epilogue evaluates five activations per hidden value and cycle stamps put 12.7 k of its 19.8 k cycles in that
+// arithmetic; the operands there are bf16 products to begin with.
+template <bool FAST>
+__device__ __forceinline__ float ess_rcp_t(float x) {
+  if constexpr (FAST) return __builtin_amdgcn_rcpf(x);
+  else return __frcp_rn(x);
 }
+template <bool FAST>
+__device__ __forceinline__ float ess_sigmoid_t(float x) { return ess_rcp_t<FAST>(1.0f + __expf(-x)); }
+template <bool FAST>
+__device__ __forceinline__ float ess_tanh_t(float x) {
+  const float t = __expf(-2.0f * fabsf(x));  // in (0, 1]: no overflow for any x
+  return copysignf((1.0f - t) * ess_rcp_t<FAST>(1.0f + t), x);
+}
+#ifndef ESS_FAST_ACT
+#define ESS_FAST_ACT false
+#endif
+#define ess_sigmoid(x_) ess_sigmoid_t<ESS_FAST_ACT>(x_)
+#define ess_tanh(x_) ess_tanh_t<ESS_FAST_ACT>(x_)
 
 // wave64 all-lanes sum (butterfly through DPP/shuffles)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -2,6 +2,7 @@
 // translation unit exports to the dispatcher in conv_bf16.hip.  The three kernel families live in separate files so that the
 // in-tree build compiles them in parallel.
 #pragma once
+#define ESS_FAST_ACT true  // (common.h: 1-ulp reciprocal in the gate activations of the bf16 kernels)
 #include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>

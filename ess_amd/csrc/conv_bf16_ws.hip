@@ -1,4 +1,11 @@
 // Wave-specialised 3x3 / stride-1 convolution on the bf16 matrix cores (see conv_bf16.hip for the dispatcher).
+#ifdef ESS_CV_TRACE
+__device__ unsigned long long g_cv_trace[2048 * 8 * 48];
+#define ESS_CT(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#define ESS_EPI_STAMP(i_) ESS_CT(i_)
+#else
+#define ESS_CT(i_) do { } while (0)
+#endif
 #include "conv_bf16_common.h"
 
 namespace {
@@ -15,12 +22,6 @@ using namespace essconv;
 // OUT8: the output(s) are BF16_C8 tensors (LINEAR epilogue): an instantiation of its own that contains conv_epilogue_c8 and
 // nothing of the fp32 epilogue variants -- the all-variants kernel is ~57k instructions with ~300 spilled registers in its
 // epilogues, this one a tenth of that.
-#ifdef ESS_CV_TRACE
-__device__ unsigned long long g_cv_trace[2048 * 8 * 48];
-#define ESS_CT(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ESS_CT(i_) do { } while (0)
-#endif
 template <int MB, int EPI, bool SRCBF, bool OUT8 = false>
 __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];

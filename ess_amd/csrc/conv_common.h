@@ -40,6 +40,9 @@ struct ConvKArgs {
 // wave-uniform channel plane.  No 64-bit per-element addresses (the first version needed ~2 VGPRs per store), no bounds
 // branches (an out-of-tile pixel / out-of-range channel gets an offset past the descriptor: its load returns 0 and
 // its store is dropped), and every read of a block is issued before the block's first store.
+#ifndef ESS_EPI_STAMP
+#define ESS_EPI_STAMP(i_) do { } while (0)  // (cycle-stamp builds of conv_bf16_ws.hip define it)
+#endif
 typedef __amdgpu_buffer_rsrc_t ess_rsrc;
 constexpr unsigned ESS_OOB = 0x80000000u;
 __device__ __forceinline__ ess_rsrc ess_make_rsrc(const void* p, size_t bytes) {
@@ -484,6 +487,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
             cprev[mb][nb][jj] = ess_bload(r_prev, vo(mb, nb, jj), (unsigned)((ct * MB + mb) * 8 + jj) * plane_b);
+#ifdef ESS_CV_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ESS_EPI_STAMP(43);
+#endif
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
         const int rowbase = ct * COT + mb * 32;
@@ -597,6 +604,8 @@ inline int pick_mb(const EssConvDesc* d) {
     static const int m = [] { const char* e = getenv("ESS_PAIR_S2_MB"); return e ? atoi(e) : 1; }();
     if (m == 1) return 1;
   }
+  static const int force = [] { const char* e = getenv("ESS_CONV_MB_FORCE"); return e ? atoi(e) : 0; }();  // (tuning experiments)
+  if (force && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && d->epilogue == ESS_EPI_LINEAR) return force;
   return d->C_out > 32 ? 2 : 1;
 }
 
