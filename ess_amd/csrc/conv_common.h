@@ -480,13 +480,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
       float cprev[MB][NBW][4];
       // soffset is outside the hardware range check: a hidden channel past the end is folded into voffset
       auto vo = [&](int mb, int nb, int jj) { return (ct * MB + mb) * 8 + 4 * half + jj < a.hid ? voff[nb] : ESS_OOB; };
+      // ESS_FMT_F32_C8 cell states (between the lean time steps): [N][hid/8][H][W][8] fp32 -- this lane's 4 channels of a pixel are
+      // 16 contiguous bytes, a pixel block of the wave 1 KiB: one 16-byte access where the planes take four 4-byte ones
+      const int nbh = (a.hid + 7) >> 3;
+      const bool cin8 = a.fmt_res == ESS_FMT_F32_C8, cout8 = a.fmt_out == ESS_FMT_F32_C8;
+      const ess_rsrc r_prev8 = ess_make_rsrc((cin8 && a.aux0) ? a.aux0 + (size_t)n * nbh * 8 * HW : a.out2, (cin8 && a.aux0) ? (size_t)nbh * HW * 32 : 0);
+      const ess_rsrc r_out28 = ess_make_rsrc(a.out2 + (size_t)n * nbh * 8 * HW, cout8 ? (size_t)nbh * HW * 32 : 0);
+      const ess_rsrc r_out8 = ess_make_rsrc(a.out ? a.out + (size_t)n * nbh * 8 * HW : a.out2, (cout8 && a.out) ? (size_t)nbh * HW * 32 : 0);
+      auto vo8 = [&](int mb, int nb) {  // byte offset of (block ct*MB+mb, this lane's pixel, channels 4*half..+3)
+        return (pixi[nb] >= 0 && ct * MB + mb < nbh) ? ((unsigned)(ct * MB + mb) * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
+      };
+      if (cin8) {  // (uniform)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
+          for (int nb = 0; nb < NBW; ++nb) {
+            typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+            const u32x4c v = __builtin_amdgcn_raw_buffer_load_b128(r_prev8, (int)vo8(mb, nb), 0, 0);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            cprev[mb][nb][jj] = ess_bload(r_prev, vo(mb, nb, jj), (unsigned)((ct * MB + mb) * 8 + jj) * plane_b);
+            for (int jj = 0; jj < 4; ++jj) cprev[mb][nb][jj] = __builtin_bit_cast(float, (unsigned)v[jj]);
+          }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              cprev[mb][nb][jj] = ess_bload(r_prev, vo(mb, nb, jj), (unsigned)((ct * MB + mb) * 8 + jj) * plane_b);
+      }
 #ifdef ESS_CV_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ESS_EPI_STAMP(43);
@@ -501,7 +523,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           for (int jj = 0; jj < 4; ++jj) sh[4 * g + jj] = biased ? 0.f : ess_bload(r_sh, 16u * half, (unsigned)(rowbase + 8 * g + jj) * 4u);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-          float hq[4];
+          float hq[4], cq[4];
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
             const float gi = ess_sigmoid(acc[mb][nb][jj] + sh[jj]);
@@ -511,9 +533,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             const float cn = gf * cprev[mb][nb][jj] + gi * gc;
             const unsigned so = (unsigned)((ct * MB + mb) * 8 + jj) * plane_b;  // hidden channel (+ 4*half in voff)
             const float hn = go * ess_tanh(cn);
-            ess_bstore(cn, r_out2, vo(mb, nb, jj), so);
-            if (a.out) ess_bstore(hn, r_out, vo(mb, nb, jj), so);  // (NULL: only the BF16_C8 copy of h' is wanted)
-            hq[jj] = (ct * MB + mb) * 8 + 4 * half + jj < a.hid ? hn : 0.f;
+            if (!cout8) {
+              ess_bstore(cn, r_out2, vo(mb, nb, jj), so);
+              if (a.out) ess_bstore(hn, r_out, vo(mb, nb, jj), so);  // (NULL: only the BF16_C8 copy of h' is wanted)
+            }
+            const bool real = (ct * MB + mb) * 8 + 4 * half + jj < a.hid;
+            hq[jj] = real ? hn : 0.f;
+            cq[jj] = real ? cn : 0.f;
+          }
+          if (cout8) {  // (uniform)
+            typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+            const u32x4c cv = {__builtin_bit_cast(unsigned, cq[0]), __builtin_bit_cast(unsigned, cq[1]), __builtin_bit_cast(unsigned, cq[2]), __builtin_bit_cast(unsigned, cq[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(cv, r_out28, (int)vo8(mb, nb), 0, 0);
+            if (a.out) {
+              const u32x4c hv = {__builtin_bit_cast(unsigned, hq[0]), __builtin_bit_cast(unsigned, hq[1]), __builtin_bit_cast(unsigned, hq[2]), __builtin_bit_cast(unsigned, hq[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(hv, r_out8, (int)vo8(mb, nb), 0, 0);
+            }
           }
           if (a.out_bf && pixi[nb] >= 0 && ct * MB + mb < ((a.hid + 7) >> 3))  // hidden block ct*MB+mb, channels 4*half..+3
             ess_store_bf16x4(a.out_bf, (size_t)n * ((a.hid + 7) >> 3), ct * MB + mb, HW, pixi[nb], half, hq[0], hq[1], hq[2], hq[3]);
@@ -708,6 +743,13 @@ inline int validate(const EssConvDesc* d) {
       ESS_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "conv: BF16_C8 sources are staged by the 1x1, 3x3 and 5x5 kernels");
     ESS_CHECK_ARG(d->C1 == 0 || d->fmt0 == d->fmt1, "conv: both sources of a concat must use the same format");
     ESS_CHECK_ARG(d->C1 == 0 || (d->C0 % 8) == 0, "conv: the first BF16_C8 source of a concat must have a multiple of 8 channels");
+  }
+  if (d->epilogue == ESS_EPI_LSTM) {
+    // channel-blocked fp32 cell states: fmt_res describes aux0 (c), fmt_out describes out / out2 (h', c')
+    ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_F32_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_F32_C8),
+                  "conv(LSTM): state tensors are ESS_FMT_F32_NCHW or ESS_FMT_F32_C8");
+    ESS_CHECK_ARG((int64_t)((d->hidden + 7) / 8) * 8 * d->H_out * d->W_out * 4 < (int64_t)1 << 31, "conv(LSTM): one sample of a state must stay below 2 GiB");
+    return ESS_OK;
   }
   ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_BF16_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),
                 "conv: bad output / residual format");

@@ -8,6 +8,8 @@ children are parameter containers only: every forward is a fused libess_hip.so l
 under no_grad in ESS (training/ess_trainer.py:52-54,277-280), so these modules are inference-only:
 asking autograd to differentiate through them raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import init
@@ -306,7 +308,7 @@ class ConvLSTM(nn.Module):
             # adds exact zeros -- run the gate conv over x alone with the x columns of the weight: bit-identical, half the MFMA
             # work of this launch, and no zero state tensors (the reference caches them, submodules.py:196-207)
             hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
-            return self._first_step(input_, hidden, torch.empty_like(hidden), lean)
+            return self._first_step(input_, hidden, None, lean)
         prev_hidden, prev_cell = prev_state
         spec = hip.conv_spec(N, H, W, C, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
         b = self.Gates.bias
@@ -314,7 +316,6 @@ class ConvLSTM(nn.Module):
         if ver != self._bias_ver:
             self._bias_ver, self._bias = ver, hip.pack_rows(spec, b.detach())
         hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
-        cell = torch.empty_like(hidden)
         # bf16 arithmetic: stage x and h from their BF16_C8 copies when the producers left them (the encoder conv and
         # the previous step of this kernel do), and leave one of h' for the next time step.  Bit-identical to staging
         # from the fp32 tensors -- the copies hold exactly the bf16 operands the MFMA would be fed anyway -- but the
@@ -325,17 +326,29 @@ class ConvLSTM(nn.Module):
         x8, h8 = (_c8_of(input_), _c8_of(prev_hidden)) if stage8 else (None, None)
         new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
         skip_fp32 = lean and new8 is not None and stage8
+        # a lean step's cell state travels to the next time step only: channel-blocked fp32 (FMT_F32_C8 -- the epilogue reads and
+        # writes a lane's 4 channels of a pixel as ONE 16-byte access instead of four 4-byte ones into four planes)
+        cell, sfmt = _new_cell(N, hid, H, W, input_.device, skip_fp32)
+        cfmt = hip.FMT_F32_C8 if prev_cell is not None and prev_cell.dim() == 5 else hip.FMT_F32_NCHW
         if bf and x8 is not None and h8 is not None:
             hip.conv_forward(spec, x8, h8, packed_weight(spec, self.Gates.weight), None, self._bias, aux0=prev_cell,
-                             out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
+                             out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8, out_fmt=sfmt,
+                             aux_fmt=cfmt)
         else:
             hip.conv_forward(spec, _fp32(input_), _fp32(prev_hidden), packed_weight(spec, self.Gates.weight), None, self._bias,
-                             aux0=prev_cell, out=None if skip_fp32 else hidden, out2=cell, out_bf=new8)
+                             aux0=prev_cell, out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, out_fmt=sfmt, aux_fmt=cfmt)
         if new8 is not None:
             _attach_c8(hidden, new8)
         if skip_fp32:
             _mark_fp32_unwritten(hidden)
         return hidden, cell
+
+
+def _new_cell(N, hid, H, W, device, blocked):
+    """-> (cell tensor, its state format): FMT_F32_C8 for a lean step (switch ESS_CELL_C8=0: always fp32 NCHW planes)."""
+    if blocked and os.environ.get('ESS_CELL_C8', '1')[:1] != '0':
+        return hip.f32_c8_empty(N, hid, H, W, device), hip.FMT_F32_C8
+    return torch.empty(N, hid, H, W, dtype=torch.float32, device=device), hip.FMT_F32_NCHW
 
 
 def _convlstm_first_step(self, input_, hidden, cell, lean):
@@ -355,12 +368,13 @@ def _convlstm_first_step(self, input_, hidden, cell, lean):
     x8 = _c8_of(input_) if stage8 else None
     new8 = hip.bf16_c8_empty(N, hid, H, W, input_.device) if bf else None
     skip_fp32 = lean and new8 is not None and stage8
+    cell, sfmt = _new_cell(N, hid, H, W, input_.device, skip_fp32)
     if x8 is not None:
         hip.conv_forward(spec, x8, None, packed_weight(spec, self._wx), None, self._bias0, aux0=None,
-                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8)
+                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, src_fmt=hip.FMT_BF16_C8, out_fmt=sfmt)
     else:
         hip.conv_forward(spec, _fp32(input_), None, packed_weight(spec, self._wx), None, self._bias0, aux0=None,
-                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8)
+                         out=None if skip_fp32 else hidden, out2=cell, out_bf=new8, out_fmt=sfmt)
     if new8 is not None:
         _attach_c8(hidden, new8)
     if skip_fp32:

@@ -19,7 +19,7 @@ EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED = 0, 1
 COMPUTE_FP32, COMPUTE_BF16 = 0, 1
-FMT_F32_NCHW, FMT_BF16_C8 = 0, 1
+FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8 = 0, 1, 2
 
 _default_compute = COMPUTE_FP32
 
@@ -239,13 +239,14 @@ def pack_rows(spec, v, v2=None, fill=0.0):
 
 
 def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None,
-                 out2=None, out_bf=None, src_fmt=FMT_F32_NCHW, out_fmt=FMT_F32_NCHW):
+                 out2=None, out_bf=None, src_fmt=FMT_F32_NCHW, out_fmt=FMT_F32_NCHW, aux_fmt=FMT_F32_NCHW):
     """src_fmt FMT_BF16_C8: src0/src1 are bf16 [N][C/8][H][W][8] tensors (see bf16_c8_empty);
+    LSTM epilogue: out_fmt / aux_fmt FMT_F32_C8: out, out2 / aux0 are fp32 [N][hid/8][H][W][8] state tensors (f32_c8_empty);
     out_bf: additionally receives `out` in that format (the frozen encoder's staging copies);
     out_fmt FMT_BF16_C8: `out` / `out2` (and `residual`, if any) ARE BF16_C8 tensors, no fp32 tensor is written."""
     sdt = torch.bfloat16 if src_fmt == FMT_BF16_C8 else torch.float32
     odt = torch.bfloat16 if out_fmt == FMT_BF16_C8 else torch.float32
-    res_fmt = out_fmt if residual is not None else FMT_F32_NCHW
+    res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else (out_fmt if residual is not None else FMT_F32_NCHW)
     desc = spec.desc if (src_fmt, out_fmt, res_fmt) == (FMT_F32_NCHW,) * 3 else spec.desc_fmt(src_fmt, out_fmt, res_fmt)
     _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt),
                                     ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, odt), ptr(aux0), ptr(aux1),
@@ -267,6 +268,11 @@ def c8_stageable(ksize, stride, pad):
 def bf16_c8_empty(N, C, H, W, device):
     """Uninitialised BF16_C8 tensor for a logical [N, C, H, W] activation: bf16 [N][ceil(C/8)][H][W][8]."""
     return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+
+
+def f32_c8_empty(N, C, H, W, device):
+    """Uninitialised FMT_F32_C8 tensor (ConvLSTM states between time steps): fp32 [N][ceil(C/8)][H][W][8]."""
+    return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.float32, device=device)
 
 
 def to_bf16_c8(x):

@@ -49,7 +49,8 @@ enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
  * fp32 NCHW output (out_bf16 of ess_conv2d_forward, or ess_to_bf16_c8): bfloat16 [N][ceil(C/8)][H][W][8], i.e. the
  * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv
  * stages it with plain 16-byte copies: 4x fewer cache-line touches and half the bytes of the fp32 NCHW path.      */
-enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1 };
+enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1,
+       ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / hidden states between time steps (LSTM epilogue only) */ };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -85,7 +86,10 @@ typedef struct EssConvDesc {
                            ARE BF16_C8 tensors and no fp32 tensor is written: the stored form of the trainable
                            networks' activations and activation gradients in the bf16 configuration.  With
                            ESS_ACT_SUMPOOL2 the first output is the pooled BF16_C8 tensor.  out_split % 8 == 0.       */
-  int32_t fmt_res;      /* format of `residual` (BF16_C8 only together with a BF16_C8 output)                         */
+  int32_t fmt_res;      /* format of `residual` (BF16_C8 only together with a BF16_C8 output).
+                           LSTM epilogue: fmt_res = format of aux0 (the cell state c), fmt_out = format of out / out2
+                           (h', c'): ESS_FMT_F32_NCHW or ESS_FMT_F32_C8 (a lane's 4 channels of a pixel are one 16-byte
+                           access; for states that only travel to the next time step)                                  */
 } EssConvDesc;
 
 typedef struct EssConvPlan {

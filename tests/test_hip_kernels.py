@@ -785,3 +785,38 @@ def test_conv_head5x5_bf16(H, case):
             assert torch.equal(got, out.cpu().bfloat16().float())
         pad = q.view(torch.int16).view(N, -1, Hv, Wv, 8)[:, -1, :, :, (Cout % 8) or 8:]
         assert int(pad.abs().max() if pad.numel() else 0) == 0  # tail channels of the last block stay zero
+
+
+@pytest.mark.parametrize('case', [(2, 16, 64, 12, 20, 'bf16'), (1, 8, 12, 9, 13, 'bf16'), (2, 8, 16, 6, 10, 'fp32')])
+def test_conv_lstm_blocked_states(H, case):
+    """FMT_F32_C8 cell / hidden states ([N][hid/8][H][W][8] fp32, what travels between the lean time steps) against fp32 NCHW
+    planes: the same arithmetic, so the values are identical -- as input (aux0), as output (out / out2), and both."""
+    N, C, hid, Hh, Ww, comp = case
+    compute = H.COMPUTE_BF16 if comp == 'bf16' else H.COMPUTE_FP32
+    g = torch.Generator().manual_seed(hid)
+    x, h, c = [torch.randn(N, ch, Hh, Ww, generator=g).cuda() for ch in (C, hid, hid)]
+    w = (torch.randn(4 * hid, C + hid, 3, 3, generator=g) / math.sqrt(9 * (C + hid))).cuda()
+    b = torch.randn(4 * hid, generator=g).cuda()
+    spec = H.conv_spec(N, Hh, Ww, C, hid, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=compute)
+    pw, pb = H.pack_weights(spec, w), H.pack_rows(spec, b)
+    nb = (hid + 7) // 8
+
+    def blocked(t):
+        p = torch.zeros(N, nb * 8, Hh, Ww, device='cuda')
+        p[:, :hid] = t
+        return p.view(N, nb, 8, Hh, Ww).permute(0, 1, 3, 4, 2).contiguous()
+
+    def planes(t8):
+        return t8.permute(0, 1, 4, 2, 3).reshape(N, nb * 8, Hh, Ww)[:, :hid].contiguous()
+
+    def run(cin_blocked, out_blocked):
+        ho = (H.f32_c8_empty(N, hid, Hh, Ww, 'cuda') if out_blocked else torch.empty_like(h)).fill_(float('nan'))
+        co = torch.empty_like(ho).fill_(float('nan'))
+        H.conv_forward(spec, x, h, pw, None, pb, aux0=blocked(c) if cin_blocked else c, out=ho, out2=co,
+                       out_fmt=H.FMT_F32_C8 if out_blocked else H.FMT_F32_NCHW, aux_fmt=H.FMT_F32_C8 if cin_blocked else H.FMT_F32_NCHW)
+        return (planes(ho), planes(co)) if out_blocked else (ho, co)
+    h0, c0 = run(False, False)
+    assert torch.isfinite(h0).all() and torch.isfinite(c0).all()
+    for cin_b, out_b in ((True, False), (False, True), (True, True)):
+        h1, c1 = run(cin_b, out_b)
+        assert torch.equal(h1, h0) and torch.equal(c1, c0), (cin_b, out_b)
