@@ -3,7 +3,10 @@
 __device__ unsigned long long g_cv_trace[2048 * 8 * 48];
 #define ESS_CT(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #define ESS_EPI_STAMP(i_) ESS_CT(i_)
+// wall clock (100 MHz, the same on every CU -- s_memtime is not): slot 46 at workgroup start, slot 43 at its end (non-LSTM kernels)
+#define ESS_CW(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = wall_clock64(); } while (0)
 #else
+#define ESS_CW(i_) do { } while (0)
 #define ESS_CT(i_) do { } while (0)
 #endif
 #include "conv_bf16_common.h"
@@ -42,6 +45,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   const int y0 = ty * TH, x0 = tx * TW;
   const int bufsz = CB8 * a.plane + WSZ;  // one stage: input tile + weight slab (16-byte units)
   ESS_CT(0);
+  ESS_CW(46);
 
   if (role == 1 && SRCBF) {
     // ------------------------------------------------------------------ producer, BF16_C8 sources
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   ESS_CT(47);
+  if constexpr (EPI != ESS_EPI_LSTM) ESS_CW(43);
 }
 
 
