@@ -49,10 +49,9 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-// Gate non-linearities of the fused epilogues on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each):
-// libm's expf/tanhf cost ~25-40 VALU instructions per call, which made the ConvLSTM epilogue as expensive as the K loop
-// of the 8-chunk level-0 gate conv.  Absolute error <= ~3e-7 on outputs in (0,1) / (-1,1).
-// Gate activations.  FAST = false: `__frcp_rn`, the IEEE-exact division sequence (two v_div_scale, v_rcp, five FMAs, v_div_fmas,
+// Gate activations of the fused epilogues on the hardware exp2 unit (v_exp_f32, ~1 ulp; libm's expf / tanhf cost 25-40 VALU
+// instructions per call, which made the ConvLSTM epilogue as expensive as the K loop of the 8-chunk level-0 gate conv).
+// FAST = false: `__frcp_rn`, the IEEE-exact division sequence (two v_div_scale, v_rcp, five FMAs, v_div_fmas,
 // v_div_fixup -- 14 VALU instructions per sigmoid) for the exact-fp32 configuration, whose parity contract is 1e-3 on logits with
 // exact argmax.  FAST = true (the bf16 configuration's translation units define ESS_FAST_ACT): v_rcp_f32, 1 ulp, 4 instructions --
 // the ConvLSTM epilogue evaluates five activations per hidden value and cycle stamps put 12.7 k of its 19.8 k cycles in that
