@@ -628,7 +628,8 @@ inline int pick_mb(const EssConvDesc* d) {
   // bf16 3x3/s1 (wave-specialised kernel): 128-channel tiles where there are enough output channels -- halves the
   // activation staging and the weight re-fetch per MFMA
   // (measured: pays only for the deepest layer -- 512 -> 1024 @ 60x80: 779 -> 859 TFLOP/s; one workgroup per CU hurts the rest)
-  if (ws_enabled() && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= 512) {
+  static const int mb4_min_cin = [] { const char* e = getenv("ESS_CONV_MB4_MIN_CIN"); return e ? atoi(e) : 512; }();  // (tuning experiments)
+  if (ws_enabled() && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= mb4_min_cin) {
     static const bool mb4 = [] { const char* e = getenv("ESS_CONV_MB4"); return !(e && e[0] == '0'); }();
     if (mb4) return 4;
   }
