@@ -388,3 +388,19 @@ def test_augmentation_params_and_oracle_semantics():
     fl[:, 2] = 0
     out, ol = O.augment_image_label(img, lab, fl, 6, 8)
     assert torch.equal((out[:, 0] * 255).round(), img.flip(-1)) and torch.equal(ol, lab.flip(-1))
+
+
+def test_header_enums_match_the_binding():
+    """Every enumerator of include/ess_hip.h that ess_amd/hip.py mirrors (ESS_X = n <-> hip.X) carries the same value."""
+    header = open(os.path.join(ROOT, 'include', 'ess_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', ' ', header, flags=re.S)
+    from ess_amd import hip
+    pairs = {}
+    for body in re.findall(r'enum\s*\{(.*?)\}', header, flags=re.S):
+        for name, val in re.findall(r'ESS_([A-Z0-9_]+)\s*=\s*(-?\d+)', body):
+            pairs[name] = int(val)
+    mirrored = {n: v for n, v in pairs.items() if hasattr(hip, n)}
+    assert len(mirrored) >= 15, sorted(mirrored)
+    assert {'FMT_F32_NCHW', 'FMT_BF16_C8', 'FMT_F32_C8', 'EPI_LSTM', 'SRC_ZERO_UP2', 'ACT_SUMPOOL2'} <= set(mirrored)
+    wrong = {n: (v, getattr(hip, n)) for n, v in mirrored.items() if getattr(hip, n) != v}
+    assert not wrong, wrong
