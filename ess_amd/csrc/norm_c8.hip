@@ -289,20 +289,30 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
   }
 }
 
-// totals of a group's partials for its 8 channels, in slice order: sixteen lanes walk the slices (one 128-byte line per slice),
-// the workgroup picks the totals up from LDS.  (The first version let every thread total all 16 x nsl doubles through scalar
-// loads: up to 1024 dependent-latency loads in front of every workgroup of the apply kernels.)  blockDim.x >= 64.
+// totals of a group's partials for its 8 channels.  blockDim.x / 16 lane groups each walk every (blockDim.x / 16)-th slice (one
+// 128-byte line per slice and group, all loads of a group independent), the 16 group sums are combined in group order through
+// LDS: one or two memory round trips in front of the apply kernels' stream instead of nsl dependent ones (the second version:
+// 16 lanes walking all slices -- 64 serial L2 round trips = ~6 us ahead of a 40 us kernel; the first let every thread total all
+// 16 x nsl doubles through scalar loads).  Fixed summation order.  blockDim.x a multiple of 64, <= 1024.
 __device__ __forceinline__ void group_total8(const double* sums, int g, int nsl, double (&t0)[8], double (&t1)[8]) {
+  __shared__ double part[64 * 16];
   __shared__ double tot[16];
-  if (threadIdx.x < 16) {
-    const double* p = sums + (size_t)g * nsl * 16 + threadIdx.x;
+  const int j = threadIdx.x & 15, k0 = threadIdx.x >> 4, ng = blockDim.x >> 4;
+  {
+    const double* p = sums + (size_t)g * nsl * 16 + j;
     double t = 0;
-    for (int k = 0; k < nsl; ++k) t += p[(size_t)k * 16];
+    for (int k = k0; k < nsl; k += ng) t += p[(size_t)k * 16];
+    part[k0 * 16 + j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double t = 0;
+    for (int i = 0; i < ng; ++i) t += part[i * 16 + threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { t0[j] = tot[2 * j]; t1[j] = tot[2 * j + 1]; }
+  for (int jj = 0; jj < 8; ++jj) { t0[jj] = tot[2 * jj]; t1[jj] = tot[2 * jj + 1]; }
 }
 
 // InstanceNorm forward map (grid: (N*CB, chunks))
