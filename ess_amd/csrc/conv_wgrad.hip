@@ -928,7 +928,7 @@ WPlan wplan(const EssConvDesc* d) {
     w.small1x1_mfma = cin <= 32 && ((d->H_out * d->W_out) % 64) == 0;
     if (w.small1x1_c8) {
       w.small1x1_mfma = false;
-      if (w.nsplit > 512) w.nsplit = 512;
+      if (w.nsplit > 1024) w.nsplit = 1024;  // (33 KB of LDS per workgroup: four per CU)
     }
     if (w.small1x1_mfma) {  // one slab per workgroup of 4 waves, two workgroups per CU
       const int groups = d->N * (d->H_out * d->W_out / 64);
