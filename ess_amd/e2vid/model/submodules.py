@@ -158,6 +158,13 @@ class ConvLayer(nn.Module):
             c8 = hip.bf16_c8_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
         k = c.kernel_size[0]
         x8 = _c8_of(x) if bf and x1 is None and hip.c8_stageable(k, c.stride[0], c.padding[0]) else None
+        if bf and x1 is not None and (C0 % 8) == 0 and hip.c8_stageable(k, c.stride[0], c.padding[0]):
+            # both concat sources from their producers' BF16_C8 copies (the prediction layer over decoder output + head: half the
+            # bytes of the two fp32 tensors, and the decoder output need not exist in fp32 at all); bit-identical operands
+            a8, b8 = _c8_of(x), _c8_of(x1)
+            if a8 is not None and b8 is not None:
+                hip.conv_forward(spec, a8, b8, packed_weight(spec, wt), scale, shift, residual, out=out, src_fmt=hip.FMT_BF16_C8)
+                return out
         skip_fp32 = c8_only and c8 is not None
         # copy-only outputs without a residual leave through the BF16_C8-OUTPUT epilogue (16-byte stores, 32-bit offsets) instead of
         # the fp32 epilogue's optional copy (8-byte stores): the same values (acc * scale + shift, ReLU, round to nearest even)

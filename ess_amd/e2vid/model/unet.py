@@ -63,9 +63,12 @@ class BaseUNet(nn.Module):
             hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 1, 2)
         for resblock in self.resblocks:
             x = resblock(x, c8_only=True) if c8_chain else resblock(x)
+        # ... and the last one too when the prediction layer can stage both of its sources (decoder output, head) from copies
+        from .submodules import _c8_of
+        pred_c8 = c8_chain and _c8_of(head) is not None and hip.c8_stageable(1, 1, 0) and self.base_num_channels % 8 == 0
         for i, decoder in enumerate(self.decoders):
             last = i == len(self.decoders) - 1
-            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1], c8_only=c8_chain and not last)
+            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1], c8_only=c8_chain and (pred_c8 or not last))
         # pred(skip(x, head)) + output activation fused into the 1x1 conv epilogue
         saved = self.pred.activation
         self.pred.activation = self.activation
