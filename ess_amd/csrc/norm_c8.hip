@@ -11,6 +11,7 @@
 //   * larger planes and BatchNorm (few channel blocks, reduction over N x H x W): pass 1 writes one fp64 partial per
 //     (group, slice, channel) -- no atomics, fixed summation order --, pass 2 totals them and applies the map.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -539,6 +540,11 @@ inline int chunks_for8(int groups, int hw) {
   if (c > maxc) c = maxc;
   return c < 1 ? 1 : c;
 }
+// fused 1024-thread InstanceNorm forward: one workgroup per (n, channel block) -- worth it only with enough groups to cover the CUs
+inline int in1024_min_groups() {
+  static const int v = [] { const char* e = getenv("ESS_IN1024_MIN_GROUPS"); return e ? atoi(e) : 256; }();  // (B=8: 64 / 128 groups at 120x160 measured 34 / 37 us fused against 28 / 34 us split)
+  return v;
+}
 inline int need_ws(void* ws, size_t need, size_t have, const char* what) {
   if (!ws || have < need) { ess_set_error("%s: workspace too small (%zu < %zu)", what, have, need); return ESS_EINVAL; }
   return ESS_OK;
@@ -565,7 +571,7 @@ extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void
     hipLaunchKernelGGL(in_fwd_c8_kernel<256>, dim3(groups), dim3(256), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
     return ess_launch_status("instnorm_forward_c8");
   }
-  if (hw <= 1024 * 19 && groups >= 64) {
+  if (hw <= 1024 * 19 && groups >= in1024_min_groups()) {
     hipLaunchKernelGGL(in_fwd_c8_kernel<1024>, dim3(groups), dim3(1024), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
     return ess_launch_status("instnorm_forward_c8");
   }
