@@ -153,7 +153,8 @@ IN_CASES = [
     # N, C, H, W, relu, residual
     (2, 16, 12, 20, 1, False),     # fused, 256 threads
     (2, 24, 12, 20, 0, True),      # IN(x) + residual (INSResBlock tail), whole blocks
-    (8, 64, 80, 100, 1, False),    # fused, 1024 threads (64 groups)
+    (8, 64, 80, 100, 1, False),    # 64 groups of 8000 vectors: split (reduce + apply)
+    (4, 512, 72, 72, 1, False),    # fused, 1024 threads (256 groups of 5184 vectors)
     (1, 16, 160, 168, 1, False),   # split (reduce + apply)
     (2, 8, 7, 9, 1, True),         # tiny odd plane
 ]
