@@ -157,6 +157,10 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   const int mb = pl.cout_tile / 32;
   const bool c8 = a.fmt0 == ESS_FMT_BF16_C8;
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
+  if (!c8 && !a.residual && conv_bf16_stem_applies(d, pl)) {  // 1-channel 7x7 / stride 2 stem: K = the filter rows
+    conv_bf16_launch_stem(d, pl, st, a);
+    return ess_launch_status("conv2d_forward(bf16, 7x7 stem)");
+  }
   if (is_paired(d) && !c8 && !a.residual && conv_bf16_head_applies(d, pl)) {  // 2-channel 5x5 head: K = the filter rows
     conv_bf16_launch_head(d, pl, st, a);
     return ess_launch_status("conv2d_forward(bf16, 5x5 head)");

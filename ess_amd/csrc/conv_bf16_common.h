@@ -30,6 +30,9 @@ void conv_bf16_launch_ws(int mb, int epi, bool c8, dim3 grid, size_t lds, hipStr
 // conv_bf16_head.hip: 5x5 / stride 1 on a 1- or 2-channel fp32 image (the recurrent encoder's head), reads the tap-paired pack
 bool conv_bf16_head_applies(const EssConvDesc* d, const EssConvPlan& pl);
 void conv_bf16_launch_head(const EssConvDesc* d, const EssConvPlan& pl, hipStream_t st, const ConvKArgs& a);
+// 7x7 / stride 2 on one fp32 channel (the image encoder's stem), reads the generic bf16 pack
+bool conv_bf16_stem_applies(const EssConvDesc* d, const EssConvPlan& pl);
+void conv_bf16_launch_stem(const EssConvDesc* d, const EssConvPlan& pl, hipStream_t st, const ConvKArgs& a);
 // conv_bf16_pair.hip
 void conv_bf16_launch_pair(int stride, int mb, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
 

@@ -820,3 +820,39 @@ def test_conv_lstm_blocked_states(H, case):
     for cin_b, out_b in ((True, False), (False, True), (True, True)):
         h1, c1 = run(cin_b, out_b)
         assert torch.equal(h1, h0) and torch.equal(c1, c0), (cin_b, out_b)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 50, 70, 1, 'c8'), (1, 64, 64, 96, 0, 'fp32'), (2, 32, 33, 41, 1, 'both'), (1, 24, 40, 64, 0, 'c8'),
+                                  (1, 128, 20, 36, 1, 'both')])
+def test_conv_stem7x7_bf16(H, case):
+    """The image encoder's stem (7x7 / stride 2 / pad 3 on one fp32 channel; reference models/style_networks.py:114-116) on its
+    dedicated bf16 kernel: exact (to accumulation order) against an fp32 conv of bf16-rounded operands; fp32 planes, BF16_C8, or
+    both; ragged / odd sizes, channel tails, one and two 64-channel tiles."""
+    N, Cout, Hv, Wv, act, form = case
+    g = torch.Generator().manual_seed(3 + Cout + Hv)
+    x = torch.randn(N, 1, Hv, Wv, generator=g)
+    w = torch.randn(Cout, 1, 7, 7, generator=g) / 7.0
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(_bf(x), _bf(w), b, 2, 3)
+    ref = torch.relu(ref) if act else ref
+    spec = H.conv_spec(N, Hv, Wv, 1, 0, Cout, 7, 2, 3, act=act, compute=H.COMPUTE_BF16)
+    Ho, Wo = spec.H_out, spec.W_out
+    assert tuple(ref.shape[2:]) == (Ho, Wo)
+    pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+    out = torch.full(ref.shape, float('nan')).cuda()
+    q = H.bf16_c8_empty(N, Cout, Ho, Wo, torch.device('cuda'))
+    q.view(torch.int16).fill_(0x7fc0)
+    if form == 'fp32':
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=out)
+    elif form == 'c8':
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=q, out_fmt=H.FMT_BF16_C8)
+    else:
+        H.conv_forward(spec, dev(x), None, pw, None, pb, None, out=out, out_bf=q)
+    if form != 'c8':
+        assert relerr(out, ref) < 2e-5
+    if form != 'fp32':
+        got = H.from_bf16_c8(q, Cout).cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+        if form == 'both':
+            assert torch.equal(got, out.cpu().bfloat16().float())
