@@ -43,6 +43,9 @@ def parse():
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--classes', type=int, default=11)
     ap.add_argument('--trainer', default='ess', choices=['ess', 'ess_supervised'])
+    ap.add_argument('--recurrent', default='convlstm', choices=['convlstm', 'convgru'],
+                    help='recurrent block of the frozen E2VID encoder (reference e2vid/model/submodules.py:175-273); BASELINE config 5 '
+                         'names the ConvGRU variant')
     ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32'],
                     help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3) or exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -177,6 +180,37 @@ def roofline_blocks(args, device):
         fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)
         gate_levels.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
         gate_ms += ms; gate_fl += fl
+    # ---- fused ConvGRU step: (update, reset) kernel + candidate kernel, three encoder levels of one time step
+    gru_ms = gru_fl = 0.0
+    gru_levels = []
+    for lvl, hid in enumerate((64, 128, 256)):
+        H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
+        s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
+        s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+        wu, wr, wo = [(torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device) for _ in range(3)]
+        bu, br, bo = [torch.randn(hid, generator=g).to(device) for _ in range(3)]
+        x, h = [torch.randn(B, hid, H, W, generator=g).to(device) for _ in range(2)]
+        pw1, pw2 = hip.pack_weights(s1, wu, wr), hip.pack_weights(s2, wo)
+        pb1, pb2 = hip.pack_rows(s1, bu, br), hip.pack_rows(s2, bo)
+        if bf16:
+            # exactly the product launches of the time steps t < T-1 (ConvGRU.forward, lean): BF16_C8 x / h / r*h, channel-blocked
+            # fp32 h_prev / u / h', BF16_C8 copy of h'
+            x8, h8 = hip.to_bf16_c8(x), hip.to_bf16_c8(h)
+            hb = h.view(B, hid // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+            u, hn = hip.f32_c8_empty(B, hid, H, W, device), hip.f32_c8_empty(B, hid, H, W, device)
+            rh8, hn8 = hip.bf16_c8_empty(B, hid, H, W, device), hip.bf16_c8_empty(B, hid, H, W, device)
+            f1 = lambda: hip.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=hip.FMT_BF16_C8,
+                                          out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
+            f2 = lambda: hip.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=hip.FMT_BF16_C8,
+                                          out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
+        else:
+            u, rh, hn = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+            f1 = lambda: hip.conv_forward(s1, x, h, pw1, None, pb1, aux0=h, out=u, out2=rh)
+            f2 = lambda: hip.conv_forward(s2, x, rh, pw2, None, pb2, aux0=h, aux1=u, out=hn)
+        ms1, ms2 = _timed(ev, stream, f1), _timed(ev, stream, f2)
+        fl = 2.0 * B * H * W * 9 * (2 * hid) * (3 * hid)
+        gru_levels.append({'level': lvl, 'hidden': hid, 'ms_ur': round(ms1, 4), 'ms_out': round(ms2, 4), 'tflops': round(fl / (ms1 + ms2) / 1e9, 1)})
+        gru_ms += ms1 + ms2; gru_fl += fl
     tag = f'{args.compute}/{B}/{args.height}x{args.width}'
     conv_t = conv_fl / conv_ms / 1e9
     return {'bound': 'mfma',
@@ -188,6 +222,9 @@ def roofline_blocks(args, device):
                 'convlstm_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
                                   'achieved': round(gate_fl / gate_ms / 1e9, 1), 'frac': round(gate_fl / gate_ms / 1e9 / peak, 4),
                                   'per_level': gate_levels, 'traffic': _traffic_from_profiles('gate/' + tag)},
+                'convgru_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, GRU_UR | GRU_OUT, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,GRU_UR | GRU_OUT,8>',
+                                 'achieved': round(gru_fl / gru_ms / 1e9, 1), 'frac': round(gru_fl / gru_ms / 1e9 / peak, 4),
+                                 'per_level': gru_levels, 'traffic': _traffic_from_profiles('gru/' + tag)},
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           'ms_per_launch_set': round(wg_ms, 4)}},
@@ -203,6 +240,10 @@ def executed_flops_per_step(args):
     P, C, K, T, B = args.height * args.width, args.C, args.classes, args.T, args.batch
     m_eenc, m_e, m_d, m_a = (800 * C + 259584) * P, (800 * C + 450080) * P, (165888 + 32 * K) * P, 103184 * P
     macs = (T - 1) * m_eenc - 110592 * P
+    if args.recurrent == 'convgru':
+        # three 2hid -> hid convolutions instead of one 2hid -> 4hid (3/4 of 3 x 73728 P per step); first step: x columns only
+        # (update + reset rows: 18432 P, candidate: 9216 P per level) instead of 55296 P
+        macs += -T * 55296 * P + 110592 * P - 82944 * P
     if args.trainer == 'ess':
         macs += m_e + 8 * m_d + 4 * m_a
     else:
@@ -293,7 +334,7 @@ def main():
 
     torch.manual_seed(6)
     st = synthetic_settings(args.trainer, 'DSEC_events', (args.height, args.width), args.classes, args.batch, args.T, args.C,
-                            device_index=dev_index)
+                            device_index=dev_index, e2vid={'recurrent_block_type': args.recurrent})
     from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
     from ess_amd.training.ess_trainer import ESSModel
     trainer = ESSModel(st) if args.trainer == 'ess' else ESSSupervisedModel(st)
@@ -399,7 +440,7 @@ def main():
             'final_loss': final_loss,
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
                                    f'{"DSEC" if args.width == 640 else "DDD17" if args.width == 352 else "custom"}-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
-                                   f'E2VID convlstm+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
+                                   f'E2VID {args.recurrent}+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
                                    f'conv contractions {args.compute} MFMA operands, fp32 accumulate; {storage}',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'ranks': world, 'step_issue': graph_note,
                        'collective_backend': (dist.get_backend() if world > 1 else None)},

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     boff[nb] = half * a.plane + ly[nb] * a.row_pitch + lx;
   }
   f32x16 acc[MB][NBW];
-  // bias-only epilogues (the ConvLSTM gates; BF16_C8 outputs without a scale): the accumulators start from the bias
-  const bool biased = (EPI == ESS_EPI_LSTM || (OUT8 && a.scale == nullptr)) && a.shift != nullptr;
+  // bias-only epilogues (the ConvLSTM / ConvGRU gates; BF16_C8 outputs without a scale): the accumulators start from the bias
+  const bool biased = (EPI != ESS_EPI_LINEAR || (OUT8 && a.scale == nullptr)) && a.shift != nullptr;
   if (biased) {
     conv_bias_init<MB>(a, acc, ct, half);
   } else {

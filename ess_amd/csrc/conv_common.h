@@ -88,10 +88,8 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
       ess_make_rsrc(split > 0 ? a.out2 + (size_t)n * (c_out - split) * HW : a.out, (size_t)(c_out - split) * plane_b);
   const ess_rsrc r_sc = ess_make_rsrc(SC ? a.scale : a.out, SC ? (size_t)c_out * 4 : 0);
   const ess_rsrc r_sh = ess_make_rsrc(a.shift ? a.shift : a.out, a.shift ? (size_t)c_out * 4 : 0);
-  const float* in0 = EPI == ESS_EPI_LINEAR ? a.residual : a.aux0;
-  const ess_rsrc r_in0 = ess_make_rsrc(IN ? in0 + (size_t)n * c_out * HW : a.out, IN ? (size_t)c_out * plane_b : 0);
-  const ess_rsrc r_in1 = ess_make_rsrc(EPI == ESS_EPI_GRU_OUT ? a.aux1 + (size_t)n * c_out * HW : a.out,
-                                       EPI == ESS_EPI_GRU_OUT ? (size_t)c_out * plane_b : 0);
+  static_assert(EPI == ESS_EPI_LINEAR, "the recurrent epilogues have their own functions");
+  const ess_rsrc r_in0 = ess_make_rsrc(IN ? a.residual + (size_t)n * c_out * HW : a.out, IN ? (size_t)c_out * plane_b : 0);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int rowbase = ct * COT + mb * 32;
@@ -106,14 +104,13 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
     }
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
-      float in0v[IN ? 16 : 1], in1v[EPI == ESS_EPI_GRU_OUT ? 16 : 1];
+      float in0v[IN ? 16 : 1];
       if constexpr (IN) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int cu = rowbase + (r & 3) + 8 * (r >> 2);
           const unsigned vo = cu + 4 * half < c_out ? voff[nb] : ESS_OOB;
           in0v[r] = ess_bload(r_in0, vo, (unsigned)cu * plane_b);
-          if constexpr (EPI == ESS_EPI_GRU_OUT) in1v[r] = ess_bload(r_in1, vo, (unsigned)cu * plane_b);
         }
       }
       float q[4];
@@ -123,14 +120,10 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
         float v = acc[mb][nb][r];
         if constexpr (SC) v *= sc[r];
         v += sh[r];
-        if constexpr (EPI == ESS_EPI_LINEAR) {
-          if constexpr (IN) v += in0v[r];
-          if (act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
-          else if (act == ESS_ACT_TANH) v = ess_tanh(v);
-        } else {  // GRU candidate: h' = h (1-u) + tanh(.) u
-          v = in0v[r] * (1.f - in1v[r]) + ess_tanh(v) * in1v[r];
-        }
+        if constexpr (IN) v += in0v[r];
+        if (act == ESS_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ESS_ACT_SIGMOID) v = ess_sigmoid(v);
+        else if (act == ESS_ACT_TANH) v = ess_tanh(v);
         const int co = cu + 4 * half;
         if (has_bf) {  // wave-uniform
           q[r & 3] = co < c_out ? v : 0.f;  // tail channels of the last block are zero
@@ -244,6 +237,153 @@ __device__ __forceinline__ void conv_epilogue_pool(const ConvKArgs& a, f32x16 (&
         } else if (co < c_out) {
           ess_bstore(v[nb], r_out2, pix_h[nb] == ESS_OOB ? ESS_OOB : pix_h[nb] + (unsigned)(co - split) * plane_b, 0);
         }
+      }
+    }
+  }
+}
+
+// ---- ConvGRU epilogues (reference e2vid/model/submodules.py:255-273).  The state-like fp32 tensors -- h_prev (aux0), u (out of the
+// first kernel, aux1 of the second), r*h (out2), h' (out) -- are `hid` channel planes (ESS_FMT_F32_NCHW) or channel-blocked
+// (ESS_FMT_F32_C8: [N][hid/8][H][W][8] fp32, this lane's 4 channels of a pixel are ONE 16-byte access where the planes take four
+// 4-byte ones into four planes).  fmt_res describes the inputs (aux0, aux1), fmt_out the fp32 outputs (out, out2).  out_bf is a
+// BF16_C8 tensor: r*h in the first kernel (what the candidate convolution stages -- it would round the fp32 tensor to exactly these
+// values), a copy of h' in the second (what the next time step's convolutions stage).
+struct EssStateIO {
+  ess_rsrc r;
+  bool c8;
+  unsigned HW;
+  int hid, nbh;
+};
+__device__ __forceinline__ EssStateIO ess_state_io(const float* base, const void* dummy, int n, int hid, unsigned HW, bool c8) {
+  EssStateIO s;
+  s.c8 = c8; s.HW = HW; s.hid = hid; s.nbh = (hid + 7) >> 3;
+  const size_t per = c8 ? (size_t)s.nbh * 8 * HW : (size_t)hid * HW;  // floats of one sample
+  s.r = ess_make_rsrc(base ? (const void*)(base + (size_t)n * per) : dummy, base ? per * 4 : 0);  // absent tensor: reads as zeros
+  return s;
+}
+// this lane's 4 channels (4*half .. +3) of 8-channel block hb at its pixel; voff = byte offset of (channel 4*half, pixel) in planes
+__device__ __forceinline__ void ess_state_load4(const EssStateIO& s, int hb, int pix, int half, unsigned voff, float (&v)[4]) {
+  if (s.c8) {  // (uniform)
+    typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+    const unsigned o = (pix >= 0 && hb < s.nbh) ? ((unsigned)hb * s.HW + (unsigned)pix) * 32u + 16u * half : ESS_OOB;
+    const u32x4c t = __builtin_amdgcn_raw_buffer_load_b128(s.r, (int)o, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) v[jj] = __builtin_bit_cast(float, (unsigned)t[jj]);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)  // soffset is outside the hardware range check: the channel bound is folded into voffset
+      v[jj] = ess_bload(s.r, hb * 8 + 4 * half + jj < s.hid ? voff : ESS_OOB, (unsigned)(hb * 8 + jj) * (s.HW * 4u));
+  }
+}
+__device__ __forceinline__ void ess_state_store4(const EssStateIO& s, int hb, int pix, int half, unsigned voff, const float (&v)[4]) {
+  if (s.c8) {
+    typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+    const unsigned o = (pix >= 0 && hb < s.nbh) ? ((unsigned)hb * s.HW + (unsigned)pix) * 32u + 16u * half : ESS_OOB;
+    u32x4c t;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) t[jj] = hb * 8 + 4 * half + jj < s.hid ? __builtin_bit_cast(unsigned, v[jj]) : 0u;  // tail channels: zeros
+    __builtin_amdgcn_raw_buffer_store_b128(t, s.r, (int)o, 0, 0);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      ess_bstore(v[jj], s.r, hb * 8 + 4 * half + jj < s.hid ? voff : ESS_OOB, (unsigned)(hb * 8 + jj) * (s.HW * 4u));
+  }
+}
+
+// (update, reset) gates: packed row 8*q + j of a 32-row block = gate q&1 (0 update, 1 reset) of hidden hb16*16 + (q>>1)*8 + j, so
+// accumulator register 8*q2 + jj is the update and 8*q2 + 4 + jj the reset gate of hidden (ct*MB+mb)*16 + q2*8 + 4*half + jj.
+// u = sigmoid(.) -> out;  (sigmoid(.) * h_prev) -> out2 (fp32) and / or out_bf (BF16_C8).  h_prev NULL reads as zeros; with
+// neither out2 nor out_bf the reset gate is not evaluated (first time step of a sequence: r*h = 0 whatever r is).
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_gru_ur(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                     const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned HW, bool biased) {
+  constexpr int COT = MB * 32;
+  const bool in8 = a.fmt_res == ESS_FMT_F32_C8, out8 = a.fmt_out == ESS_FMT_F32_C8;
+  const EssStateIO h_io = ess_state_io(a.aux0, a.wpk, n, a.hid, HW, in8);
+  const EssStateIO u_io = ess_state_io(a.out, a.wpk, n, a.hid, HW, out8);
+  const EssStateIO rh_io = ess_state_io(a.out2, a.wpk, n, a.hid, HW, out8);
+  const ess_rsrc r_sh = ess_make_rsrc(a.shift, (size_t)(a.n_cout_tiles * COT) * 4);
+  const bool need_r = a.out2 != nullptr || a.out_bf != nullptr;
+  const int nbh = (a.hid + 7) >> 3;
+  float hp[MB][NBW][2][4];
+  if (need_r) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) ess_state_load4(h_io, (ct * MB + mb) * 2 + q2, pixi[nb], half, voff[nb], hp[mb][nb][q2]);
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+    float sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh[r] = biased ? 0.f : ess_bload(r_sh, 16u * half, (unsigned)(rowbase + (r & 3) + 8 * (r >> 2)) * 4u);
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int hb = (ct * MB + mb) * 2 + q2;
+        float u[4], rh[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) u[jj] = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + sh[8 * q2 + jj]);
+        ess_state_store4(u_io, hb, pixi[nb], half, voff[nb], u);
+        if (need_r) {  // (uniform)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            rh[jj] = ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj] + sh[8 * q2 + 4 + jj]) * hp[mb][nb][q2][jj];
+            if (hb * 8 + 4 * half + jj >= a.hid) rh[jj] = 0.f;
+          }
+          if (a.out2) ess_state_store4(rh_io, hb, pixi[nb], half, voff[nb], rh);
+          if (a.out_bf && pixi[nb] >= 0 && hb < nbh)
+            ess_store_bf16x4(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, rh[0], rh[1], rh[2], rh[3]);
+        }
+      }
+    }
+  }
+}
+
+// candidate: packed row = hidden channel, so accumulator register 4*j + jj belongs to hidden (ct*MB+mb)*32 + 8*j + 4*half + jj.
+// h' = h_prev (1 - u) + tanh(.) u -> out (fp32, may be NULL when only the copy is wanted) and / or out_bf (BF16_C8 copy).
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                      const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned HW, bool biased) {
+  constexpr int COT = MB * 32;
+  const bool in8 = a.fmt_res == ESS_FMT_F32_C8, out8 = a.fmt_out == ESS_FMT_F32_C8;
+  const EssStateIO h_io = ess_state_io(a.aux0, a.wpk, n, a.hid, HW, in8);
+  const EssStateIO u_io = ess_state_io(a.aux1, a.wpk, n, a.hid, HW, in8);
+  const EssStateIO o_io = ess_state_io(a.out, a.wpk, n, a.hid, HW, out8);
+  const ess_rsrc r_sh = ess_make_rsrc(a.shift, (size_t)(a.n_cout_tiles * COT) * 4);
+  const int nbh = (a.hid + 7) >> 3;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+    asm volatile("" ::: "memory");  // one 32-channel block of state reads in flight at a time (registers)
+    float sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh[r] = biased ? 0.f : ess_bload(r_sh, 16u * half, (unsigned)(rowbase + (r & 3) + 8 * (r >> 2)) * 4u);
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      float hv[4][4], uv[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ess_state_load4(h_io, (ct * MB + mb) * 4 + j, pixi[nb], half, voff[nb], hv[j]);
+        ess_state_load4(u_io, (ct * MB + mb) * 4 + j, pixi[nb], half, voff[nb], uv[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hb = (ct * MB + mb) * 4 + j;
+        float hn[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float o = ess_tanh(acc[mb][nb][4 * j + jj] + sh[4 * j + jj]);
+          hn[jj] = hv[j][jj] * (1.f - uv[j][jj]) + o * uv[j][jj];
+          if (hb * 8 + 4 * half + jj >= a.hid) hn[jj] = 0.f;
+        }
+        if (a.out) ess_state_store4(o_io, hb, pixi[nb], half, voff[nb], hn);
+        if (a.out_bf && pixi[nb] >= 0 && hb < nbh)
+          ess_store_bf16x4(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, hn[0], hn[1], hn[2], hn[3]);
       }
     }
   }
@@ -450,8 +590,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     voff[nb] = inb ? ((unsigned)pixi[nb] + 4u * half * HW) * 4u : ESS_OOB;
   }
   if constexpr (EPI == ESS_EPI_GRU_OUT) {
-    if (a.scale) conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
-    else conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
+    conv_epilogue_gru_out<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
+  } else if constexpr (EPI == ESS_EPI_GRU_UR) {
+    conv_epilogue_gru_ur<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
     if constexpr (ALLOW8) {
       if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB>(a, acc, ct, n, half, x, y0, ly); return; }
@@ -552,43 +693,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
           }
           if (a.out_bf && pixi[nb] >= 0 && ct * MB + mb < ((a.hid + 7) >> 3))  // hidden block ct*MB+mb, channels 4*half..+3
             ess_store_bf16x4(a.out_bf, (size_t)n * ((a.hid + 7) >> 3), ct * MB + mb, HW, pixi[nb], half, hq[0], hq[1], hq[2], hq[3]);
-        }
-      }
-    } else {  // ESS_EPI_GRU_UR
-      // packed row 8*q + j: gate q&1 (0 update, 1 reset) of hidden hb*16 + (q>>1)*8 + j
-      float hp[MB][NBW][8];
-      auto vo = [&](int mb, int nb, int q2, int jj) {
-        return (ct * MB + mb) * 16 + q2 * 8 + 4 * half + jj < a.hid ? voff[nb] : ESS_OOB;
-      };
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-              hp[mb][nb][4 * q2 + jj] =
-                  ess_bload(r_prev, vo(mb, nb, q2, jj), (unsigned)((ct * MB + mb) * 16 + q2 * 8 + jj) * plane_b);
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int rowbase = ct * COT + mb * 32;
-        float sh[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sh[r] = ess_bload(r_sh, 16u * half, (unsigned)(rowbase + (r & 3) + 8 * (r >> 2)) * 4u);
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-#pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              // accumulator register r holds packed row (r&3) + 8(r>>2) + 4 half: update gate r = 8 q2 + jj, reset r + 4
-              const float u = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + sh[8 * q2 + jj]);
-              const float rr = ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj] + sh[8 * q2 + 4 + jj]);
-              const unsigned so = (unsigned)((ct * MB + mb) * 16 + q2 * 8 + jj) * plane_b;
-              ess_bstore(u, r_out, vo(mb, nb, q2, jj), so);
-              ess_bstore(rr * hp[mb][nb][4 * q2 + jj], r_out2, vo(mb, nb, q2, jj), so);
-            }
         }
       }
     }
@@ -750,6 +854,13 @@ inline int validate(const EssConvDesc* d) {
     ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_F32_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_F32_C8),
                   "conv(LSTM): state tensors are ESS_FMT_F32_NCHW or ESS_FMT_F32_C8");
     ESS_CHECK_ARG((int64_t)((d->hidden + 7) / 8) * 8 * d->H_out * d->W_out * 4 < (int64_t)1 << 31, "conv(LSTM): one sample of a state must stay below 2 GiB");
+    return ESS_OK;
+  }
+  if (d->epilogue == ESS_EPI_GRU_UR || d->epilogue == ESS_EPI_GRU_OUT) {
+    // fmt_res describes h_prev (aux0) and, in the candidate kernel, u (aux1); fmt_out the fp32 outputs (u and r*h | h')
+    ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_F32_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_F32_C8),
+                  "conv(GRU): state tensors are ESS_FMT_F32_NCHW or ESS_FMT_F32_C8");
+    ESS_CHECK_ARG((int64_t)((d->hidden + 7) / 8) * 8 * d->H_out * d->W_out * 4 < (int64_t)1 << 31, "conv(GRU): one sample of a state must stay below 2 GiB");
     return ESS_OK;
   }
   ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_BF16_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),

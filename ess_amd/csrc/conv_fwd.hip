@@ -229,16 +229,17 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   int rc = validate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
-  ESS_CHECK_ARG(out || (out_bf16 && d->out_split == 0 && (d->epilogue == ESS_EPI_LINEAR || d->epilogue == ESS_EPI_LSTM)),
-                "conv: `out` may only be NULL when the BF16_C8 copy is requested (LINEAR / LSTM epilogues)");
+  ESS_CHECK_ARG(out || (out_bf16 && d->out_split == 0 && (d->epilogue == ESS_EPI_LINEAR || d->epilogue == ESS_EPI_LSTM || d->epilogue == ESS_EPI_GRU_OUT)),
+                "conv: `out` may only be NULL when the BF16_C8 copy is requested (LINEAR / LSTM / GRU_OUT epilogues)");
   ESS_CHECK_ARG(d->C1 == 0 || src1, "conv: second source missing");
-  if (d->epilogue == ESS_EPI_LSTM || d->epilogue == ESS_EPI_GRU_UR)
-    ESS_CHECK_ARG(shift && out2, "conv: recurrent epilogue needs bias and second output");
-  if (d->epilogue == ESS_EPI_GRU_OUT) ESS_CHECK_ARG(aux0 && aux1, "conv: GRU_OUT needs h_prev and u");
+  if (d->epilogue != ESS_EPI_LINEAR) ESS_CHECK_ARG(shift && !scale && !residual, "conv: a recurrent epilogue takes a bias (shift) and no scale / residual");
+  if (d->epilogue == ESS_EPI_LSTM) ESS_CHECK_ARG(out2, "conv: the LSTM epilogue needs the second output (c')");
+  // GRU_UR: r*h goes to out2 (fp32) and / or out_bf16 (BF16_C8); with h_prev = NULL (zeros) it may be dropped altogether
+  if (d->epilogue == ESS_EPI_GRU_UR) ESS_CHECK_ARG(out2 || out_bf16 || !aux0, "conv: GRU_UR needs an output for r*h (out2 or out_bf16)");
+  if (d->epilogue == ESS_EPI_GRU_OUT) ESS_CHECK_ARG(aux1, "conv: GRU_OUT needs u (aux1); h_prev (aux0) may be NULL = zeros");
   if (d->out_split > 0) ESS_CHECK_ARG(out2, "conv: out_split needs out2");
   if (out_bf16)
-    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->out_split == 0 && d->epilogue != ESS_EPI_GRU_UR,
-                  "conv: the BF16_C8 output copy exists for bf16 compute, LINEAR / LSTM / GRU_OUT epilogues, no out_split");
+    ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16 && d->out_split == 0, "conv: the BF16_C8 output copy exists for bf16 compute, no out_split");
   if (d->act == ESS_ACT_SUMPOOL2)
     ESS_CHECK_ARG(out && !scale && !residual && !out_bf16, "conv: SUMPOOL2 takes no scale / residual / BF16_C8 copy");
   if (d->fmt_out == ESS_FMT_BF16_C8) {

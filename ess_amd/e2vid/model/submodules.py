@@ -393,7 +393,13 @@ ConvLSTM._first_step = _convlstm_first_step
 
 
 class ConvGRU(nn.Module):
-    """Two fused kernels: (update, reset) gates -> (u, r*h); candidate -> h'.  Reference: submodules.py:233-273."""
+    """Two fused kernels: (update, reset) gates -> (u, r*h); candidate -> h'.  Reference: submodules.py:233-273.
+
+    bf16 arithmetic keeps the recurrent state in three forms, as the ConvLSTM does with (h, c): the BF16_C8 copy the gate /
+    candidate convolutions stage (`.ess_c8`), the fp32 values the epilogues blend with (`h' = h (1 - u) + o u` stays an fp32
+    recurrence: channel-blocked fp32 `.ess_f32c8` between lean time steps, plain NCHW planes otherwise), and -- unless the step is
+    lean -- the fp32 NCHW tensor the reference returns.  u travels between the two kernels as channel-blocked fp32, r*h as the
+    BF16_C8 tensor the candidate convolution would round it to anyway; neither the concat nor an fp32 r*h exist in memory."""
 
     def __init__(self, input_size, hidden_size, kernel_size):
         super().__init__()
@@ -407,29 +413,84 @@ class ConvGRU(nn.Module):
         for g in (self.reset_gate, self.update_gate, self.out_gate):
             init.orthogonal_(g.weight)
             init.constant_(g.bias, 0.)
-        self._ver, self._b1, self._b2 = None, None, None
+        self._bias_cache = {}
 
-    def forward(self, input_, prev_state):
+    def _biases(self, s1, s2):
+        bu, br, bo = self.update_gate.bias, self.reset_gate.bias, self.out_gate.bias
+        ver = (bu._version, br._version, bo._version, bu.data_ptr(), br.data_ptr(), bo.data_ptr())
+        ent = self._bias_cache.get((s1.key, s2.key))
+        if ent is None or ent[0] != ver:
+            if len(self._bias_cache) >= 8:
+                self._bias_cache.clear()
+            ent = self._bias_cache[(s1.key, s2.key)] = (ver, hip.pack_rows(s1, bu.detach(), br.detach()), hip.pack_rows(s2, bo.detach()))
+        return ent[1], ent[2]
+
+    def _x_columns(self, C):
+        """The x columns of the three gate weights as their own (packable) tensors: the first step of a sequence (h = 0)."""
+        ws = (self.update_gate.weight, self.reset_gate.weight, self.out_gate.weight)
+        ver = tuple((w._version, w.data_ptr()) for w in ws) + (C,)
+        if getattr(self, '_wx_ver', None) != ver:
+            self._wx_ver, self._wx = ver, tuple(w.detach()[:, :C].contiguous() for w in ws)
+        return self._wx
+
+    def forward(self, input_, prev_state, lean=False):
+        """lean: (bf16 arithmetic, BF16_C8 path) do not write the fp32 NCHW state -- only its BF16_C8 copy and the channel-blocked
+        fp32 form; for a time step whose state is consumed by the next step of this module and nothing else."""
         _inference_only(input_)
         N, C, H, W = input_.shape
         hid = self.hidden_size
-        if prev_state is None:
-            prev_state = torch.zeros(N, hid, H, W, dtype=torch.float32, device=input_.device)
-        s1 = hip.conv_spec(N, H, W, C, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
-        s2 = hip.conv_spec(N, H, W, C, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
-        bu, br, bo = self.update_gate.bias, self.reset_gate.bias, self.out_gate.bias
-        ver = (s1.key, bu._version, br._version, bo._version, bu.data_ptr())
-        if ver != self._ver:
-            self._ver = ver
-            self._b1 = hip.pack_rows(s1, bu.detach(), br.detach())
-            self._b2 = hip.pack_rows(s2, bo.detach())
-        u = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
-        rh = torch.empty_like(u)
-        hip.conv_forward(s1, input_, prev_state, packed_weight(s1, self.update_gate.weight, self.reset_gate.weight), None,
-                         self._b1, aux0=prev_state, out=u, out2=rh)
+        dev = input_.device
+        first = prev_state is None
+        # first step of a sequence: h = 0, so r*h = 0 whatever r is and the h halves of all three contractions add exact zeros --
+        # both kernels run over x alone with the x columns of the weights (half the MFMA work, no zero tensors; the reset rows of
+        # the first kernel are computed and dropped)
+        C1 = 0 if first else hid
+        s1 = hip.conv_spec(N, H, W, C, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
+        s2 = hip.conv_spec(N, H, W, C, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+        b1, b2 = self._biases(s1, s2)
+        if first:
+            wu, wr, wo = self._x_columns(C)
+        else:
+            wu, wr, wo = self.update_gate.weight, self.reset_gate.weight, self.out_gate.weight
+        pw1, pw2 = packed_weight(s1, wu, wr), packed_weight(s2, wo)
+        bf = s1.desc.compute == hip.COMPUTE_BF16 and (C % 8) == 0 and (hid % 8) == 0 and hip.c8_stageable(3, 1, 1)
+        x8 = _c8_of(input_) if bf else None
+        h8 = _c8_of(prev_state) if (bf and not first) else None
+        if x8 is not None and (first or h8 is not None):
+            # ---- BF16_C8 path: x / h / r*h staged as 16-byte pixel vectors, fp32 state operands channel-blocked where they can be
+            hb = None if first else getattr(prev_state, 'ess_f32c8', None)  # channel-blocked fp32 h (left by a lean step)
+            if first or hb is not None:
+                h32, afmt = hb, hip.FMT_F32_C8
+            else:
+                h32, afmt = _fp32(prev_state), hip.FMT_F32_NCHW
+            u = hip.f32_c8_empty(N, hid, H, W, dev) if afmt == hip.FMT_F32_C8 else torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+            rh8 = None if first else hip.bf16_c8_empty(N, hid, H, W, dev)
+            hip.conv_forward(s1, x8, h8, pw1, None, b1, aux0=h32, out=u, out2=None, out_bf=rh8, src_fmt=hip.FMT_BF16_C8,
+                             out_fmt=afmt, aux_fmt=afmt)
+            new8 = hip.bf16_c8_empty(N, hid, H, W, dev)
+            new_state = torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+            if lean:
+                nb = hip.f32_c8_empty(N, hid, H, W, dev)
+                hip.conv_forward(s2, x8, rh8, pw2, None, b2, aux0=h32, aux1=u, out=nb, out_bf=new8, src_fmt=hip.FMT_BF16_C8,
+                                 out_fmt=hip.FMT_F32_C8, aux_fmt=afmt)
+                new_state.ess_f32c8 = nb
+                _mark_fp32_unwritten(new_state)
+            else:
+                hip.conv_forward(s2, x8, rh8, pw2, None, b2, aux0=h32, aux1=u, out=new_state, out_bf=new8, src_fmt=hip.FMT_BF16_C8,
+                                 out_fmt=hip.FMT_F32_NCHW, aux_fmt=afmt)
+            _attach_c8(new_state, new8)
+            return new_state
+        # ---- fp32 NCHW sources (exact-fp32 arithmetic; or a state that went through user code and lost its copies)
+        x = _fp32(input_)
+        h = None if first else _fp32(prev_state)
+        u = torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+        rh = None if first else torch.empty_like(u)
+        hip.conv_forward(s1, x, h, pw1, None, b1, aux0=h, out=u, out2=rh)
         new_state = torch.empty_like(u)
-        hip.conv_forward(s2, input_, rh, packed_weight(s2, self.out_gate.weight), None, self._b2, aux0=prev_state, aux1=u,
-                         out=new_state)
+        new8 = hip.bf16_c8_empty(N, hid, H, W, dev) if bf else None
+        hip.conv_forward(s2, x, rh, pw2, None, b2, aux0=h, aux1=u, out=new_state, out_bf=new8)
+        if new8 is not None:
+            _attach_c8(new_state, new8)
         return new_state
 
 
@@ -446,19 +507,20 @@ class RecurrentConvLayer(nn.Module):
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
 
     def forward(self, x, prev_state, lean=False):
-        lstm = self.recurrent_block_type == 'convlstm'
-        # the conv output never leaves this module: in bf16 arithmetic the ConvLSTM stages it from the BF16_C8 copy
+        # the conv output never leaves this module: in bf16 arithmetic the recurrent block stages it from the BF16_C8 copy
         # (a 64 | 128 | 256-channel tensor, always a whole number of 8-channel blocks), so its fp32 form is not written
-        x = self.conv(x, want_c8=lstm, c8_only=lstm and self.conv.conv2d.out_channels % 8 == 0 and hip.c8_stageable(3, 1, 1) and
+        x = self.conv(x, want_c8=True, c8_only=self.conv.conv2d.out_channels % 8 == 0 and hip.c8_stageable(3, 1, 1) and
                       self._prev_has_c8(prev_state))
-        state = self.recurrent_block(x, prev_state, lean=lean) if lstm else self.recurrent_block(x, prev_state)
+        state = self.recurrent_block(x, prev_state, lean=lean)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state
 
 
 def _rcl_prev_has_c8(self, prev_state):
-    """True when the ConvLSTM will take the BF16_C8 path for this step (zero state, or a state that still carries its copy)."""
-    return prev_state is None or _c8_of(prev_state[0]) is not None
+    """True when the recurrent block will take the BF16_C8 path for this step (zero state, or a state that still carries its copy)."""
+    if prev_state is None:
+        return True
+    return _c8_of(prev_state[0] if self.recurrent_block_type == 'convlstm' else prev_state) is not None
 
 
 RecurrentConvLayer._prev_has_c8 = _rcl_prev_has_c8

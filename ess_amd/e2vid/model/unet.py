@@ -127,7 +127,7 @@ class UNetRecurrent(BaseUNet):
         self.build_prediction_layer()
 
     def forward(self, x, prev_states, encoder_only=False, lean=False):
-        """lean (needs encoder_only; effective in bf16 arithmetic with ConvLSTM blocks): the step's only purpose is the
+        """lean (needs encoder_only; effective in bf16 arithmetic): the step's only purpose is the
         recurrent state for the NEXT step, so the fp32 forms of the head output and of the hidden states are not written
         (their BF16_C8 copies and the fp32 cell states are); `latent` is None.  Result-identical for the steps t < T-1 of
         a sequence: the next step stages x and h from the copies anyway."""

@@ -50,7 +50,7 @@ enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
  * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv
  * stages it with plain 16-byte copies: 4x fewer cache-line touches and half the bytes of the fp32 NCHW path.      */
 enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1,
-       ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / hidden states between time steps (LSTM epilogue only) */ };
+       ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / ConvGRU hidden states between time steps (recurrent epilogues only) */ };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -89,7 +89,9 @@ typedef struct EssConvDesc {
   int32_t fmt_res;      /* format of `residual` (BF16_C8 only together with a BF16_C8 output).
                            LSTM epilogue: fmt_res = format of aux0 (the cell state c), fmt_out = format of out / out2
                            (h', c'): ESS_FMT_F32_NCHW or ESS_FMT_F32_C8 (a lane's 4 channels of a pixel are one 16-byte
-                           access; for states that only travel to the next time step)                                  */
+                           access; for states that only travel to the next time step).
+                           GRU epilogues: fmt_res = format of aux0 (h_prev) and aux1 (u), fmt_out = format of the fp32
+                           outputs (GRU_UR: u, r*h; GRU_OUT: h'), each ESS_FMT_F32_NCHW or ESS_FMT_F32_C8               */
 } EssConvDesc;
 
 typedef struct EssConvPlan {
@@ -125,16 +127,19 @@ int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const float* v2, 
 
 /* src1 may be NULL when C1 == 0.  scale/shift: packed (ess_conv2d_pack_rows) or NULL.
  * residual: [N][C_out][H_out][W_out] or NULL (LINEAR).
- * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev ; aux1: GRU_OUT u.
- * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h | LINEAR split.  */
+ * aux0: LSTM c_prev | GRU_UR h_prev | GRU_OUT h_prev (NULL = zeros: first time step) ; aux1: GRU_OUT u.
+ * out : LINEAR y | LSTM h' | GRU_UR u | GRU_OUT h' ;   out2: LSTM c' | GRU_UR r*h (fp32) | LINEAR split.
+ * Recurrent epilogues take the bias as `shift`, no scale, no residual.                              */
 int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
                        const float* scale, const float* shift, const void* residual, const float* aux0,
                        const float* aux1, void* out, void* out2, void* out_bf16, ess_stream_t stream);
 /* out / out2 / residual: fp32 NCHW, or BF16_C8 tensors when d->fmt_out (d->fmt_res) says so.                    */
 /* src0/src1: fp32 NCHW or bf16 C8 per d->fmt0/fmt1.  out_bf16 (nullable): additionally receives `out` (LINEAR y,
  * LSTM h', GRU_OUT h') as a BF16_C8 tensor [N][ceil(C/8)][H_out][W_out][8] for the next convolution to stage from
- * (bf16 compute only; not with out_split).  With out_bf16 given, `out` may be NULL for the LINEAR and LSTM epilogues:
- * the fp32 tensor is then not written at all (a producer whose only consumer stages from the copy).               */
+ * (bf16 compute only; not with out_split).  With out_bf16 given, `out` may be NULL for the LINEAR, LSTM and GRU_OUT
+ * epilogues: the fp32 tensor is then not written at all (a producer whose only consumer stages from the copy).
+ * GRU_UR: out_bf16 receives r*h as a BF16_C8 tensor -- the second source of the candidate convolution (reference
+ * e2vid/model/submodules.py:268-270) -- and out2 may then be NULL; with aux0 == NULL both may be NULL (r*h = 0).    */
 
 /* fp32 NCHW -> BF16_C8 (round to nearest even; tail channels zero).  y: N*ceil(C/8)*H*W*8 bfloat16.        */
 int ess_to_bf16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);

@@ -20,14 +20,25 @@ def _e2vid(cfg, sd):
     return m.cuda().eval()
 
 
-def test_config5_T20_recurrent_state_drift_vs_oracle():
-    """T = 20 recurrent steps at 96x128 (B = 2, C = 2) against the oracle, step by step: the ConvLSTM hidden / cell states of
-    all three levels and the last step's latents + reconstruction.  fp32 arithmetic: 2e-4 at every step (the per-sequence
-    goldens state 1e-4 after 5 steps).  bf16 arithmetic (config 5 itself): the state drift is BOUNDED, not growing with T --
-    the gates are contractive (sigmoid / tanh) -- stated tolerance 2e-2 of the state scale at every step."""
+def _flat(states):
+    """state tensors of all levels: (h, c) pairs of a ConvLSTM, h of a ConvGRU"""
+    out = []
+    for s in states:
+        out += list(s) if isinstance(s, (tuple, list)) else [s]
+    return out
+
+
+@pytest.mark.parametrize('rtype', ['convlstm', 'convgru'])
+def test_config5_T20_recurrent_state_drift_vs_oracle(rtype):
+    """T = 20 recurrent steps at 96x128 (B = 2, C = 2) against the oracle, step by step: the ConvLSTM hidden / cell states
+    (ConvGRU: hidden states -- BASELINE config 5 names the ConvGRU variant) of all three levels and the last step's latents +
+    reconstruction.  fp32 arithmetic: 2e-4 at every step (the per-sequence goldens state 1e-4 after 5 steps).  bf16 arithmetic
+    (config 5 itself): the state drift is BOUNDED, not growing with T -- the gates are contractive (sigmoid / tanh) -- stated
+    tolerance 2e-2 of the state scale at every step.  The bf16 run is repeated with lean steps (t < T-1: no fp32 NCHW state is
+    written, the BF16_C8 copies and channel-blocked fp32 states carry the recurrence): bit-identical final outputs."""
     from ess_amd import hip
     B, T, C, H, W = 2, 20, 2, 96, 128
-    cfg = O.e2vid_config(num_bins=C)
+    cfg = O.e2vid_config(num_bins=C, recurrent_block_type=rtype)
     sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 71)
     ev, _, _, _ = O.synth_batch(B, T, C, H, W, 11, seed=13)
     # oracle trajectory
@@ -36,7 +47,7 @@ def test_config5_T20_recurrent_state_drift_vs_oracle():
         for t in range(T):
             x = O.event_normalize(ev[:, t * C:(t + 1) * C])
             img, states, lat = O.e2vid_step(sd, cfg, x, states, encoder_only=t < T - 1)
-            ref_states.append([(h.clone(), c.clone()) for h, c in states])
+            ref_states.append([s.clone() for s in _flat(states)])
     for mode, tol in (('fp32', 2e-4), ('bf16', 2e-2)):
         hip.set_compute(mode)
         try:
@@ -46,24 +57,32 @@ def test_config5_T20_recurrent_state_drift_vs_oracle():
                 for t in range(T):
                     x = hip.event_normalize(ev[:, t * C:(t + 1) * C].contiguous().cuda())
                     out, st, latent = model(x, st, encoder_only=t < T - 1)
-                    e = max(max(_relerr(h, rh), _relerr(c, rc)) for (h, c), (rh, rc) in zip(st, ref_states[t]))
+                    e = max(_relerr(a, b) for a, b in zip(_flat(st), ref_states[t]))
                     drift.append(e)
                     assert e < tol, (mode, t, e)
-            print(f'config5 T=20 {mode}: state drift step 1 {drift[0]:.2e}, step 5 {drift[4]:.2e}, step 10 {drift[9]:.2e}, '
+            print(f'config5 T=20 {rtype} {mode}: state drift step 1 {drift[0]:.2e}, step 5 {drift[4]:.2e}, step 10 {drift[9]:.2e}, '
                   f'step 20 {drift[19]:.2e}')
             assert _relerr(out, img) < tol
             for k in (2, 4, 8):
                 assert _relerr(latent[k], lat[k]) < tol, (mode, k)
             if mode == 'bf16':  # bounded, not accumulating: the second half of the sequence is no worse than 3x the first
                 assert max(drift[10:]) < 3 * max(drift[:10]) + 1e-3
+                st2 = None
+                with torch.no_grad():
+                    for t in range(T):
+                        x = hip.event_normalize(ev[:, t * C:(t + 1) * C].contiguous().cuda())
+                        out2, st2, latent2 = model(x, st2, encoder_only=t < T - 1, lean=t < T - 1)
+                assert torch.equal(out2, out) and all(torch.equal(latent2[k], latent[k]) for k in (2, 4, 8))
+                assert all(torch.equal(a, b) for a, b in zip(_flat(st2), _flat(st)))
         finally:
             hip.set_compute('fp32')
 
 
-def test_config5_T20_full_size_lean_steps_and_step():
-    """Config 5 shape on one GPU (B = 8, T = 20, 2x480x640, bf16): the 19 lean encoder-only steps + the full last step are
-    deterministic, finite, equal to the same sequence run with every fp32 state materialised, and one UDA train step over the
-    T = 20 sequence runs and moves the loss."""
+@pytest.mark.parametrize('rtype', ['convlstm', 'convgru'])
+def test_config5_T20_full_size_lean_steps_and_step(rtype):
+    """Config 5 shape on one GPU (B = 8, T = 20, 2x480x640, bf16; ConvLSTM and the ConvGRU variant the config names): the 19
+    lean encoder-only steps + the full last step are deterministic, finite, equal to the same sequence run with every fp32 state
+    materialised, and one UDA train step over the T = 20 sequence runs and moves the loss."""
     from ess_amd import hip
     from ess_amd.config.settings import synthetic_settings
     from ess_amd.training.ess_trainer import ESSModel
@@ -71,7 +90,7 @@ def test_config5_T20_full_size_lean_steps_and_step():
     B, T, C, H, W, K = 8, 20, 2, 480, 640, 11
     hip.set_compute('bf16')
     try:
-        cfg = O.e2vid_config(num_bins=C)
+        cfg = O.e2vid_config(num_bins=C, recurrent_block_type=rtype)
         sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 72)
         ev, img, lab_a, lab_b = make_batch(B, T, C, H, W, K, seed=900, device='cuda')
 
@@ -83,7 +102,7 @@ def test_config5_T20_full_size_lean_steps_and_step():
                     last = t == T - 1
                     x = hip.event_normalize(ev[:, t * C:(t + 1) * C].contiguous())
                     out, st, lat = model(x, st, encoder_only=not last, lean=lean and not last)
-            return [out] + [lat[k] for k in (2, 4, 8)] + [s[1] for s in st]
+            return [out] + [lat[k] for k in (2, 4, 8)] + [s[1] if isinstance(s, tuple) else s for s in st]
 
         a, b, c = run(True), run(True), run(False)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), 'not deterministic'
@@ -91,7 +110,7 @@ def test_config5_T20_full_size_lean_steps_and_step():
         assert all(torch.isfinite(x).all() for x in a)
         del a, b, c
         torch.manual_seed(6)
-        tr = ESSModel(synthetic_settings('ess', 'DSEC_events', (H, W), K, B, T, C))
+        tr = ESSModel(synthetic_settings('ess', 'DSEC_events', (H, W), K, B, T, C, e2vid={'recurrent_block_type': rtype}))
         l0 = tr.train_step([[img, lab_a], [ev, lab_b]])[2].item()
         l1 = tr.train_step([[img, lab_a], [ev, lab_b]])[2].item()
         assert l0 == l0 and l1 == l1 and abs(l0) < 1e6 and l0 != l1

@@ -822,6 +822,94 @@ def test_conv_lstm_blocked_states(H, case):
         assert torch.equal(h1, h0) and torch.equal(c1, c0), (cin_b, out_b)
 
 
+@pytest.mark.parametrize('case', [(2, 16, 64, 12, 20, 'bf16'), (1, 8, 12, 9, 13, 'bf16'), (2, 8, 16, 6, 10, 'fp32'), (1, 16, 256, 5, 7, 'bf16'),
+                                  (2, 24, 40, 17, 33, 'bf16')])
+def test_conv_gru_blocked_forms(H, case):
+    """The ConvGRU kernel pair (reference e2vid/model/submodules.py:255-273) in the forms the bf16 fast path uses -- BF16_C8 x / h
+    sources, channel-blocked fp32 h_prev / u / h' (FMT_F32_C8), r*h as a BF16_C8 tensor, BF16_C8 copy of h' -- against the same
+    pair on fp32 NCHW planes: the same arithmetic on the same operands, so every value is identical.  Also the first time step
+    (h_prev = NULL, x columns of the weights only) against an explicit zero state."""
+    N, C, hid, Hh, Ww, comp = case
+    bf = comp == 'bf16'
+    compute = H.COMPUTE_BF16 if bf else H.COMPUTE_FP32
+    g = torch.Generator().manual_seed(hid + C)
+    x, h = [torch.randn(N, ch, Hh, Ww, generator=g) for ch in (C, hid)]
+    if bf:  # operands that ARE bf16 values: the BF16_C8 sources then hold exactly what the planes path rounds to
+        x, h = _bf(x), _bf(h)
+    x, h = x.cuda(), h.cuda()
+    ws = [(torch.randn(hid, C + hid, 3, 3, generator=g) / math.sqrt(9 * (C + hid))).cuda() for _ in range(3)]
+    bs = [(torch.randn(hid, generator=g) * 0.1).cuda() for _ in range(3)]
+    nb = (hid + 7) // 8
+
+    def blocked(t):
+        p = torch.zeros(N, nb * 8, Hh, Ww, device='cuda')
+        p[:, :hid] = t
+        return p.view(N, nb, 8, Hh, Ww).permute(0, 1, 3, 4, 2).contiguous()
+
+    def planes(t8):
+        return t8.float().permute(0, 1, 4, 2, 3).reshape(N, nb * 8, Hh, Ww)[:, :hid].contiguous()
+
+    def run(first, form):
+        C1 = 0 if first else hid
+        s1 = H.conv_spec(N, Hh, Ww, C, C1, 2 * hid, 3, 1, 1, epi=H.EPI_GRU_UR, hidden=hid, compute=compute)
+        s2 = H.conv_spec(N, Hh, Ww, C, C1, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, hidden=hid, compute=compute)
+        wu, wr, wo = [w[:, :C].contiguous() for w in ws] if first else ws
+        pw1, pw2 = H.pack_weights(s1, wu, wr), H.pack_weights(s2, wo)
+        b1, b2 = H.pack_rows(s1, bs[0], bs[1]), H.pack_rows(s2, bs[2])
+        hp = None if first else h
+        if form == 'planes':
+            u = torch.full((N, hid, Hh, Ww), float('nan'), device='cuda')
+            rh = None if first else torch.full_like(u, float('nan'))
+            H.conv_forward(s1, x, hp, pw1, None, b1, aux0=hp, out=u, out2=rh)
+            hn = torch.full_like(u, float('nan'))
+            H.conv_forward(s2, x, rh, pw2, None, b2, aux0=hp, aux1=u, out=hn)
+            return u, rh, hn, None
+        # blocked forms (what ConvGRU.forward issues between lean time steps)
+        c8src = bf and C % 8 == 0 and hid % 8 == 0
+        sfmt = H.FMT_BF16_C8 if c8src else H.FMT_F32_NCHW
+        xs = H.to_bf16_c8(x) if c8src else x
+        hs = None if first else (H.to_bf16_c8(h) if c8src else h)
+        u = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda').fill_(float('nan'))
+        rh8 = None if (first or not bf) else H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda').fill_(float('nan'))
+        rh32 = None if (first or bf) else H.f32_c8_empty(N, hid, Hh, Ww, 'cuda').fill_(float('nan'))
+        H.conv_forward(s1, xs, hs, pw1, None, b1, aux0=None if first else blocked(h), out=u, out2=rh32, out_bf=rh8, src_fmt=sfmt,
+                       out_fmt=H.FMT_F32_C8, aux_fmt=H.FMT_F32_C8)
+        hn = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda').fill_(float('nan'))
+        h8 = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda').fill_(float('nan')) if bf else None
+        if c8src or first:
+            src1 = rh8 if c8src else None
+        else:  # fp32 NCHW sources: the candidate conv stages r*h from planes
+            src1 = planes(rh8) if bf else planes(rh32)
+        if first:
+            src1 = None
+        H.conv_forward(s2, xs, src1, pw2, None, b2, aux0=None if first else blocked(h), aux1=u, out=hn, out_bf=h8, src_fmt=sfmt,
+                       out_fmt=H.FMT_F32_C8, aux_fmt=H.FMT_F32_C8)
+        rh = None if first else (planes(rh8) if bf else planes(rh32))
+        return planes(u), rh, planes(hn), (None if h8 is None else planes(h8))
+
+    for first in (False, True):
+        u0, rh0, h0, _ = run(first, 'planes')
+        assert torch.isfinite(u0).all() and torch.isfinite(h0).all()
+        u1, rh1, h1, h1b = run(first, 'blocked')
+        assert torch.equal(u1, u0), first
+        if not first:
+            assert torch.equal(rh1, rh0.bfloat16().float() if bf else rh0)
+        assert torch.equal(h1, h0), first
+        if h1b is not None:
+            assert torch.equal(h1b, h0.bfloat16().float())
+    # first step == an explicit zero state through the full-width kernels
+    u0, _, h0, _ = run(True, 'planes')
+    h = torch.zeros_like(h)
+    uz, _, hz, _ = run(False, 'planes')
+    assert torch.equal(u0, uz) and torch.equal(h0, hz)
+    # fp32 arithmetic: the pair against the oracle's ConvGRU
+    if not bf:
+        sd = {}
+        for n, w, b in zip(('update_gate', 'reset_gate', 'out_gate'), ws, bs):
+            sd[f'r.{n}.weight'], sd[f'r.{n}.bias'] = w.cpu(), b.cpu()
+        assert relerr(h0, O.conv_gru(sd, 'r', x.cpu(), None)) < 2e-5
+
+
 @pytest.mark.parametrize('case', [(2, 64, 50, 70, 1, 'c8'), (1, 64, 64, 96, 0, 'fp32'), (2, 32, 33, 41, 1, 'both'), (1, 24, 40, 64, 0, 'c8'),
                                   (1, 128, 20, 36, 1, 'both')])
 def test_conv_stem7x7_bf16(H, case):
