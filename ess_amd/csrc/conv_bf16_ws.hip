@@ -79,15 +79,13 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       v_keep0[k] = in0 ? 0xffffffffu : 0u;
       v_keep1[k] = in1 ? 0xffffffffu : 0u;
     }
-    // Two chunks of loads in flight in two register sets: a load issued in iteration ch is committed to LDS in iteration
-    // ch + 2.  With BF16_C8 sources the producer is a pure load -> ds_write pipe (no conversion), and under full-machine load
-    // the L2 round trip exceeds one chunk of matrix work: with a single set the consumers waited at the barrier for the
-    // producers' vmcnt.
     struct Set { u32x4 pre[CB8][KPC]; u32x4 wpre[WV]; };
-    Set sa, sb;
+    Set sa;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
     auto load_chunk = [&](int ch, Set& r) {
-      if (a.deep & 4) return;  // (ablation switch ESS_WS_ABL: no global loads)
+#ifdef ESS_ABLATE
+      if (a.deep & 4) return;  // (ablation build only, switch ESS_WS_ABL: no global loads)
+#endif
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;                 // wave-uniform
@@ -102,7 +100,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; r.wpre[it] = wsrc[i < WSZ ? i : 0]; }
     };
     auto commit = [&](int ch, int buf, const Set& r) {
-      if (a.deep & 16) return;  // (ablation: no LDS writes)
+#ifdef ESS_ABLATE
+      if (a.deep & 16) return;  // (ablation build only: no LDS writes)
+#endif
       u32x4* in_t = smem16 + buf * bufsz;
       u32x4* w_t = in_t + CB8 * a.plane;
 #pragma unroll
@@ -122,27 +122,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
     };
     const int nch = a.n_chunks;
-    if (a.deep) {
-      load_chunk(0, sa);
-      if (nch > 1) load_chunk(1, sb);
-      commit(0, 0, sa);
-      if (nch > 2) load_chunk(2, sa);
-      __syncthreads();  // stage 0 is ready
-      for (int ch = 0; ch < nch; ch += 2) {
-        if (ch + 1 < nch) {
-          commit(ch + 1, 1, sb);
-          if (ch + 3 < nch) load_chunk(ch + 3, sb);
-        }
-        __syncthreads();
-        if (ch + 1 < nch) {
-          if (ch + 2 < nch) {
-            commit(ch + 2, 0, sa);
-            if (ch + 4 < nch) load_chunk(ch + 4, sa);
-          }
-          __syncthreads();
-        }
-      }
-    } else {
+    {
       ESS_CT(1);
       load_chunk(0, sa);
       commit(0, 0, sa);
@@ -306,7 +286,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                         \
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F_.a[mb]), __builtin_bit_cast(bf16x8, F_.b[nb]), acc[mb][nb], 0, 0, 0);
     constexpr int NR = MB + NBW;  // LDS reads per tap
-    if (a.deep & 2) { __syncthreads(); continue; }  // (ablation: no fragment reads, no MFMAs)
+#ifdef ESS_ABLATE
+    if (a.deep & 2) { __syncthreads(); continue; }  // (ablation build only: no fragment reads, no MFMAs)
+#endif
     ESS_READ_TAP(f0, 0)
     ESS_READ_TAP(f1, 1) ESS_WAIT(f0, NR) ESS_MMA(f0)
     ESS_READ_TAP(f0, 2) ESS_WAIT(f1, NR) ESS_MMA(f1)
@@ -325,7 +307,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   }
   ESS_CT(45);
   __builtin_amdgcn_s_setprio(0);
-  if (a.deep & 8) return;  // (ablation: no epilogue)
+#ifdef ESS_ABLATE
+  if (a.deep & 8) return;  // (ablation build only: no epilogue)
+#endif
   if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   ESS_CT(47);

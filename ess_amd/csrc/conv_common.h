@@ -29,7 +29,7 @@ struct ConvKArgs {
   int fmt0, fmt1;  // ESS_FMT_* of the sources
   int fmt_out;     // ESS_FMT_BF16_C8: `out` / `out2` ARE BF16_C8 tensors (LINEAR epilogue), nothing is written in fp32
   int fmt_res;     // format of `residual`
-  int deep;        // tuning (ESS_WS_DEEP=1, default off: measured -12 % on the decoder convs): two chunks of loads in flight in the BF16_C8 3x3 producers
+  int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
 };
 
 

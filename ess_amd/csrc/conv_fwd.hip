@@ -255,8 +255,9 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   a.src0 = (const float*)src0; a.src1 = (const float*)src1; a.wpk = packed_w;
   a.out_bf = out_bf16; a.fmt0 = d->fmt0; a.fmt1 = d->C1 ? d->fmt1 : d->fmt0; a.scale = scale; a.shift = shift; a.residual = (const float*)residual;
   a.aux0 = aux0; a.aux1 = aux1; a.out = (float*)out; a.out2 = (float*)out2; a.fmt_out = d->fmt_out; a.fmt_res = d->fmt_res;
-  { static const int deep = [] { const char* e = getenv("ESS_WS_DEEP"); const char* b = getenv("ESS_WS_ABL");
-                                 return ((e && e[0] == '1') ? 1 : 0) | (b ? atoi(b) & ~1 : 0); }(); a.deep = deep; }
+#ifdef ESS_ABLATE  // diagnostic builds only (-DESS_ABLATE): ESS_WS_ABL=<bits> lets the 3x3 kernel skip loads / LDS writes / MFMAs / epilogue
+  { static const int abl = [] { const char* b = getenv("ESS_WS_ABL"); return b ? atoi(b) & ~1 : 0; }(); a.deep = abl; }
+#endif
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;

@@ -323,6 +323,30 @@ extern "C" int ess_add(const float* a, const float* b, float* y, int64_t n, ess_
   return ess_launch_status("add");
 }
 
+// y = a + b (+ c) over bfloat16 tensors of any layout, 8 elements (one 16-byte vector) per thread and step: fp32 sum, ONE round to
+// nearest even.  The gradient of an activation with several consumers in the bf16 configuration (BF16_C8 gradients).
+__global__ void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, const uint4* __restrict__ c, uint4* __restrict__ y,
+                                int64_t nv) {
+  typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8v va = __builtin_bit_cast(bf16x8v, a[i]), vb = __builtin_bit_cast(bf16x8v, b[i]);
+    bf16x8v vc;
+    if (c) vc = __builtin_bit_cast(bf16x8v, c[i]);
+    bf16x8v r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((float)va[j] + (float)vb[j] + (c ? (float)vc[j] : 0.f));
+    y[i] = __builtin_bit_cast(uint4, r);
+  }
+}
+
+extern "C" int ess_add_bf16(const void* a, const void* b, const void* c, void* y, int64_t n_vectors, ess_stream_t stream) {
+  ESS_CHECK_ARG(a && b && y && n_vectors > 0, "add_bf16: bad arguments");
+  ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)y)) & 15) == 0, "add_bf16: tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n_vectors)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a, (const uint4*)b,
+                     (const uint4*)c, (uint4*)y, n_vectors);
+  return ess_launch_status("add_bf16");
+}
+
 extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && workspace && n > 0, "event_normalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;

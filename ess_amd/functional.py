@@ -199,6 +199,39 @@ def detach_keep_c8(x):
     return d
 
 
+class ForkFn(torch.autograd.Function):
+    """x -> n aliases of x for n consumers.  Backward sums the consumers' gradients in ONE library launch (fp32 sum of up to four
+    BF16_C8 gradients with a single rounding, `ess_add_bf16`; fp32 NCHW: `ess_add`) -- autograd would otherwise accumulate the
+    gradient of a tensor with several consumers with n - 1 torch-native elementwise adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.detach() for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        if acc.dtype == torch.bfloat16:
+            i = 1
+            while i < len(gs):  # (up to three more per launch would need a wider kernel; 2 + 2 covers every site of the step)
+                acc = hip.add_bf16(acc, gs[i], gs[i + 1] if i + 1 < len(gs) else None)
+                i += 2
+        else:
+            for g in gs[1:]:
+                acc = hip.add(acc, g)
+        return acc, None
+
+
+def fork(x, n=2):
+    """n aliases of `x`, one per consumer (see ForkFn); the tensor itself when no gradient can flow."""
+    if n == 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return ForkFn.apply(x, n)
+
+
 class Conv2dFn(torch.autograd.Function):
     """conv2d(+bias) over the channel concat of (x0[, x1]), each optionally nearest-x2 upsampled on the
     fly.  Replaces nn.Conv2d / torch.cat / F.interpolate(nearest) (models/style_networks.py:69-88,
@@ -314,14 +347,14 @@ class Conv2dFn(torch.autograd.Function):
             # stride-2 3x3 (assembled from parity phases into a temporary): still no AccumulateGrad node -- those keep the
             # stream they were created on, which breaks a later hipGraph capture of the step
             if dw is not None and _direct(weight) and (db is None or (ctx.bias_ref is not None and ctx.bias_ref() is not None and _direct(ctx.bias_ref()))):
-                weight.grad.add_(dw)
+                hip.add(weight.grad, dw, out=weight.grad)
                 if db is not None:
-                    ctx.bias_ref().grad.add_(db)
+                    hip.add(ctx.bias_ref().grad, db, out=ctx.bias_ref().grad)
                 dw = db = None
                 if GRAD_READY_HOOK is not None:
                     GRAD_READY_HOOK(weight)
         if d_skip is not None and need0:  # not fusable (or no data-gradient was computed): plain sum
-            d0 = d_skip if d0 is None else (d0 + d_skip if c8in else hip.add(d0, d_skip.contiguous()))
+            d0 = d_skip if d0 is None else (hip.add_bf16(d0, d_skip.contiguous()) if c8in else hip.add(d0, d_skip.contiguous()))
         return d0, d1, dw, db, None, None, None, None, None, None
 
 

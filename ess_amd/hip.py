@@ -44,7 +44,7 @@ EXPORTS = [
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
-    'ess_upsample_bilinear2x_add_c8_from_c8',
+    'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16',
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
             'ess_upsample_bilinear2x_add': [P, P, P, I, I, I, P],
             'ess_sumpool2x2': [P, P, I, I, I, I, P],
             'ess_add': [P, P, P, I64, P],
+            'ess_add_bf16': [P, P, P, P, I64, P],
             'ess_event_normalize': [P, P, I64, P, P],
             'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, P],
             'ess_sym_js_loss': [P, P, P, P, F, I, I, I, P, P],
@@ -462,6 +463,17 @@ def add(a, b, out=None):
     return out
 
 
+def add_bf16(a, b, c=None, out=None):
+    """a + b (+ c) over bfloat16 tensors of one shape (BF16_C8 gradients): fp32 sum, one rounding."""
+    if a.shape != b.shape or (c is not None and c.shape != a.shape) or a.numel() % 8:
+        raise EssHipError('add_bf16: shape mismatch / not a whole number of 8-element vectors')
+    if out is None:
+        out = torch.empty_like(a)
+    bf = torch.bfloat16
+    _check(lib().ess_add_bf16(ptr(a, bf), ptr(b, bf), ptr(c, bf), ptr(out, bf), a.numel() // 8, stream()), 'ess_add_bf16')
+    return out
+
+
 def event_normalize(x):
     ptr(x)  # device / dtype / layout check before anything is allocated
     y = torch.empty_like(x)
@@ -575,6 +587,8 @@ def augment_image_label(img, label, params, height, width, id_lut=None):
     N, Hs, Ws = img.shape
     if params.shape != (N, 12):
         raise EssHipError('augment_image_label: params must be [N, 12]')
+    if id_lut is not None and id_lut.numel() < 256:
+        raise EssHipError('augment_image_label: id_lut must have 256 entries (the kernel indexes it with the label id clamped to 0..255)')
     out = torch.empty(N, 1, height, width, dtype=torch.float32, device=img.device)
     out_l = torch.empty(N, height, width, dtype=torch.int64, device=img.device) if label is not None else None
     _check(lib().ess_augment_image_label(ptr(img), ptr(label, torch.int64), ptr(params), ptr(id_lut, torch.int64), ptr(out),

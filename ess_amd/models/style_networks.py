@@ -117,18 +117,20 @@ class SemSegE2VID(nn.Module):
         if self.skip_connect:
             x = self.decoder_scale_1(x)
             x = self.decoder_scale_2[0].forward_fused(x, lat(input_dict[4]), up=True)
-            x = self.decoder_scale_2[1](x)
-            self.update_skip_dict(out, x, sz_in)
+            # out[4] / out[2] feed the next stage AND (through the returned dict) the cycle losses: Fn.fork sums the two
+            # gradients in one library launch instead of autograd's accumulation add
+            x, xo = Fn.fork(self.decoder_scale_2[1](x))
+            self.update_skip_dict(out, xo, sz_in)
             x = self.decoder_scale_3[0].forward_fused(x, lat(input_dict[2]), up=True)
-            x = self.decoder_scale_3[1](x)
-            self.update_skip_dict(out, x, sz_in)
+            x, xo = Fn.fork(self.decoder_scale_3[1](x))
+            self.update_skip_dict(out, xo, sz_in)
             x = self.decoder_scale_4[0].forward_fused(x, None, up=True)
         else:
             x = self.decoder_scale_1(x)
-            x = self.decoder_scale_2[1].forward_fused(x, None, up=True)
-            self.update_skip_dict(out, x, sz_in)
-            x = self.decoder_scale_3[1].forward_fused(x, None, up=True)
-            self.update_skip_dict(out, x, sz_in)
+            x, xo = Fn.fork(self.decoder_scale_2[1].forward_fused(x, None, up=True))
+            self.update_skip_dict(out, xo, sz_in)
+            x, xo = Fn.fork(self.decoder_scale_3[1].forward_fused(x, None, up=True))
+            self.update_skip_dict(out, xo, sz_in)
             x = self.decoder_scale_4[1].forward_fused(x, None, up=True)
         c5 = self.decoder_scale_5[0]
         x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0, out_c8=False)  # the logits: fp32 NCHW for the loss / metric kernels
@@ -204,8 +206,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if self.downsample is not None:
-            identity = _ConvBN.run(self.downsample[0], self.downsample[1], x, None, relu=False)
-            out = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True)
+            xa, xb = Fn.fork(x)  # two consumers (1x1 downsample, conv1): their data-gradients are summed by one library launch
+            identity = _ConvBN.run(self.downsample[0], self.downsample[1], xa, None, relu=False)
+            out = _ConvBN.run(self.conv1, self.bn1, xb, None, relu=True)
         elif self.bn1.training:
             # identity skip: x enters the graph once, conv1 hands it through (skip gradient added in its dgrad epilogue)
             out, identity = _ConvBN.run(self.conv1, self.bn1, x, None, relu=True, passthrough=True)
@@ -279,11 +282,13 @@ class StyleEncoderE2VID(nn.Module):
         out = {1: x}
         sz_in = x.shape[3]
         x = self.encoder_scale_1(x.contiguous())
-        if self.skip_connect:
-            self.update_skip_dict(out, x, sz_in)
+        if self.skip_connect:  # (a returned latent and the next stage: two consumers, see Fn.fork)
+            x, xo = Fn.fork(x)
+            self.update_skip_dict(out, xo, sz_in)
         x = self.encoder_scale_2(x)
         if self.skip_connect:
-            self.update_skip_dict(out, x, sz_in)
+            x, xo = Fn.fork(x)
+            self.update_skip_dict(out, xo, sz_in)
         x = self.encoder_scale_3(x)
         self.update_skip_dict(out, x, sz_in)
         flush_bn_counters()

@@ -80,6 +80,8 @@ class BaseTrainer(object):
     # time), what is gained is the 2 ms between an eager and a captured step.  The averaged gradients are the same numbers either
     # way (an elementwise mean over ranks does not depend on how the buffer is cut into buckets).
     def enable_step_graph(self, example_batch, warmup=2):
+        """NOTE: the `warmup` iterations are REAL train steps on `example_batch` (weights, optimiser moments and BatchNorm running
+        statistics move), as torch's capture recipe prescribes; pass warmup=0 to capture without them once the step has run."""
         dp = D.world_size() > 1
         flat = lambda b: [t for part in b for t in (part if isinstance(part, (list, tuple)) else [part])]  # noqa: E731
         unflat = lambda like, ts: [unflat_part(p, ts) for p in like]  # noqa: E731
@@ -121,7 +123,49 @@ class BaseTrainer(object):
                 o._step -= 1  # capture records the launches without running them: the step prepared above did not happen
                 o._prepared = False
         self._g_like, self._g_outputs = example_batch, outputs
+        self._graph_adopt_packed()
         return self
+
+    # ---- packed-weight cache vs the captured step.  A replay rewrites the weights through raw pointers (the RAdam kernel) and
+    # refreshes, IN PLACE, exactly the packed copies that existed when the step was captured (functional.repack ran once, at
+    # capture time: its python half -- dropping bias rows, layouts the multi-tensor pack does not cover, the first-source filter
+    # copies -- is not part of the graph).  So (i) cache entries created by an eager forward BETWEEN replays (validation: another
+    # batch size, eval-mode specs, bias rows) are never refreshed and would go stale: they are dropped after every replay;
+    # (ii) the packed tensors the graph reads must outlive any cache eviction (load_state_dict / broadcast / invalidate_packed bump
+    # versions and would free them under the graph): the trainer holds references; (iii) when parameters or buffers were replaced
+    # or modified outside the captured step (their version counters moved), the graph's packed copies no longer match the weights:
+    # the step is re-captured (without warm-up steps) before the next replay.
+    def _graph_models_signature(self):
+        sig = []
+        for m in self.models_dict.values():
+            for t in list(m.parameters()) + list(m.buffers()):
+                sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def _graph_adopt_packed(self):
+        from .. import functional as Fn
+        owned, keep = {}, []
+        for o in self.optimizers_dict.values():
+            for p in o.param_groups[0]['params']:
+                ent = Fn._pack_cache.get(id(p))
+                if ent is not None and ent[0]() is p:
+                    owned[id(p)] = set(ent[2])
+        for ent in Fn._pack_cache.values():  # (every packed copy alive now may be read by the recorded kernels)
+            keep.extend(ent[2].values())
+        self._g_owned, self._g_keep = owned, keep
+        self._g_sig = self._graph_models_signature()
+
+    def _graph_drop_foreign_packed(self):
+        from .. import functional as Fn
+        for o in self.optimizers_dict.values():
+            for p in o.param_groups[0]['params']:
+                Fn._first_cache.pop(id(p), None)
+                ent = Fn._pack_cache.get(id(p))
+                if ent is None:
+                    continue
+                own = self._g_owned.get(id(p), ())
+                for key in [k for k in ent[2] if k not in own]:
+                    del ent[2][key]
 
     def _replay_step(self, batch):
         flat = [t for part in batch for t in (part if isinstance(part, (list, tuple)) else [part])]
@@ -129,6 +173,9 @@ class BaseTrainer(object):
             if dst.shape != src.shape:
                 raise ValueError('captured train step: batch shape differs from the captured one')
             dst.copy_(src, non_blocking=True)
+        if self._graph_models_signature() != self._g_sig:
+            # weights / buffers were replaced or modified outside the captured step (load_state_dict, broadcast, user code)
+            self.enable_step_graph(batch, warmup=0)
         opts = list(self.optimizers_dict.values())
         for o in opts:
             o.prepare_step()
@@ -143,6 +190,9 @@ class BaseTrainer(object):
                     self.grad_reducer.launch(part)
             self.grad_reducer.wait()
             self._g_tail.replay()
+        for o in opts:
+            o._prepared = False  # consumed by the replayed optimiser launch (an eager step() afterwards prepares its own scalars)
+        self._graph_drop_foreign_packed()
         vec = self._g_vec.clone()  # the graph's own buffers are overwritten by the next replay
         return {k: vec[i] for i, k in enumerate(self._g_keys)}, self._g_outputs, vec[-1]
 

@@ -75,7 +75,19 @@ class GradAllReducer:
             cur.append(p)
             acc += k
             last = i == len(params) - 1
-            if last or (len(buckets) < n_buckets - 1 and acc - lo >= total / n_buckets):
+            # (never cut between a conv weight and its bias: the bias gradient is written by the weight's launch, and a bucket is
+            # released by its conv WEIGHTS -- a bias leading the next bucket would go on the wire before that launch)
+            if last or (len(buckets) < n_buckets - 1 and acc - lo >= total / n_buckets and params[i + 1].dim() == 4):
+                # a bucket is released when the weight-gradient launches of its CONVOLUTION weights have been issued.  A conv bias
+                # is completed by the same launch as its weight; any other 1-D parameter (BatchNorm gamma / beta) is finished by a
+                # kernel that does not report here, so a bucket holding one could go on the wire early: refuse instead of racing.
+                for j, q in enumerate(cur):
+                    if q.requires_grad and q.dim() != 4:
+                        prev = cur[j - 1] if j > 0 else None
+                        if not (q.dim() == 1 and prev is not None and prev.dim() == 4 and prev.shape[0] == q.shape[0]):
+                            raise ValueError('GradAllReducer.arm: bucketed overlap needs conv weights (+ their biases) only; this '
+                                             'optimiser holds other parameters (e.g. BatchNorm affine) -- all-reduce its flat '
+                                             'gradient with launch() after the backward instead')
                 need = {id(q) for q in cur if q.dim() == 4 and q.requires_grad}
                 b = {'lo': lo, 'hi': acc, 'need': need, 'done': False}
                 for q in cur:
@@ -125,13 +137,20 @@ def all_reduce_sum_(tensors):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
-def reduce_validation_sums(cumulative_losses, n):
-    """Loss sums and batch count of a validation epoch, summed over the ranks (each validates its own shard)."""
-    if world_size() <= 1 or not cumulative_losses:
+def reduce_validation_sums(cumulative_losses, n, device=None):
+    """Loss sums and batch count of a validation epoch, summed over the ranks (each validates its own shard).  EVERY rank must
+    call this, also one whose shard was empty (n == 0, no keys): it contributes zeros for the keys the others report -- a rank
+    that skipped the collectives would leave the others blocked in them."""
+    if world_size() <= 1:
         return cumulative_losses, n
-    keys = sorted(cumulative_losses)
-    vals = [cumulative_losses[k].detach().float().reshape(()) for k in keys]
-    t = torch.stack(vals + [torch.tensor(float(n), device=vals[0].device)])
+    gathered = [None] * world_size()
+    dist.all_gather_object(gathered, sorted(cumulative_losses))
+    keys = sorted(set().union(*[set(g) for g in gathered]))
+    if device is None:
+        device = next(iter(cumulative_losses.values())).device if cumulative_losses else torch.device('cpu')
+    zero = torch.zeros((), dtype=torch.float32, device=device)
+    vals = [cumulative_losses[k].detach().float().reshape(()).to(device) if k in cumulative_losses else zero for k in keys]
+    t = torch.stack(vals + [torch.tensor(float(n), dtype=torch.float32, device=device)])
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: t[i] for i, k in enumerate(keys)}, float(t[-1])
 

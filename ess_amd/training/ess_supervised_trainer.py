@@ -115,9 +115,10 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
             for k, v in losses.items():
                 cumulative_losses[k] = cumulative_losses[k] + v if k in cumulative_losses else v
             n += 1
-        if n == 0:
+        # (every rank takes part in the reductions, also one whose shard was empty: see reduce_validation_sums)
+        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n, self.device)
+        if n == 0:  # (the GLOBAL count: every rank returns here together)
             return
-        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n)
         m = self.metrics_semseg_b.get_metrics_summary()
         summary = {k: float(v) / n for k, v in cumulative_losses.items()}
         summary['semseg_sensor_b_mean_iou'], summary['semseg_sensor_b_acc'] = float(m['mean_iou']), float(m['acc'])

@@ -215,13 +215,16 @@ class ESSModel(base_trainer.BaseTrainer):
         terms = self._e_terms = []  # the weighted terms g_loss is the sum of (train_step starts the backward pass from them)
         cycle_name = first_sensor_name + '_to_' + second_sensor_name
         scales = (2, 4, 8) if s.skip_connect_encoder else (8,)
+        dec_in = dict(content_second_sensor)
         for k in scales:
-            li = self.cycle_content_loss(content_second_sensor[k], content_first_sensor[k], weight=s.weight_cycle_loss)
+            # each image latent feeds its L1 term and the decoder: two consumers, gradients summed by one library launch (Fn.fork)
+            lat_l1, dec_in[k] = Fn.fork(content_second_sensor[k])
+            li = self.cycle_content_loss(lat_l1, content_first_sensor[k], weight=s.weight_cycle_loss)
             terms.append(li)
             g_loss = g_loss + li
             losses['cycle_latent_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
         task_backend = self.models_dict['back_end']
-        pred_second_sensor = task_backend(content_second_sensor)
+        pred_second_sensor = task_backend(dec_in)
         if pred_first_sensor_no_grad is None:
             with torch.no_grad():
                 pred_first_sensor_no_grad = task_backend(content_first_sensor)
@@ -337,9 +340,10 @@ class ESSModel(base_trainer.BaseTrainer):
             for k, v in losses.items():
                 cumulative_losses[k] = cumulative_losses[k] + v if k in cumulative_losses else v
             n += 1
-        if n == 0:
+        # (every rank takes part in the reductions, also one whose shard was empty: see reduce_validation_sums)
+        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n, self.device)
+        if n == 0:  # (the GLOBAL count: every rank returns here together)
             return
-        cumulative_losses, n = D.reduce_validation_sums(cumulative_losses, n)
         if sensor_name == 'sensor_a':
             tracked = [('semseg_sensor_a', self.metrics_semseg_a)]
         elif self.settings.semseg_label_val_b:

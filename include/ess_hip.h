@@ -223,6 +223,10 @@ int ess_sumpool2x2(const float* x, float* y, int32_t planes, int32_t H_out, int3
                    ess_stream_t stream);
 /* y = a + b (skip_sum, e2vid/model/unet.py:12-13); in place allowed.                                */
 int ess_add(const float* a, const float* b, float* y, int64_t n, ess_stream_t stream);
+/* y = a + b (+ c when c != NULL) over bfloat16 tensors of n_vectors x 8 elements (16-byte aligned; any layout, e.g. BF16_C8):
+ * fp32 sum, one round to nearest even; in place allowed.  Replaces autograd's gradient accumulation for an activation with
+ * several consumers (models/style_networks.py:69-88: out[2] / out[4] feed the next stage and a loss).            */
+int ess_add_bf16(const void* a, const void* b, const void* c, void* y, int64_t n_vectors, ess_stream_t stream);
 
 /* EventPreprocessor.__call__ normalisation (e2vid/utils/inference_utils.py:96-107) over the whole
  * tensor of n floats: non-zero mean/std, y = (x!=0)*(x-mean)/std; identity copy when all-zero.

@@ -63,6 +63,62 @@ def test_captured_step_is_bit_identical_to_eager(kind, mode):
         hip.set_compute('fp32')
 
 
+@pytest.mark.parametrize('kind', ['ess', 'ess_supervised'])
+def test_captured_step_interleaved_with_eager_forwards(kind):
+    """Replays interleaved with eager forwards (validation between training steps) and with weights replaced under the graph:
+    a replay refreshes only the packed weight copies it was captured with, so cache entries an eager forward creates in between
+    (another batch size, eval-mode specs, bias rows) must not survive it, and a load_state_dict after capture must reach the
+    replayed step.  Reference run: the same sequence issued eagerly -- losses, validation logits and weights bit-identical."""
+    from ess_amd import hip
+    shape, vshape = (2, 3, 2, 96, 128, 11), (1, 3, 2, 96, 128, 11)
+    try:
+        runs = []
+        for graph in (False, True):
+            tr = _trainer(kind, 'bf16', shape)
+            b0 = _batch(kind, shape, 300)
+            if graph:
+                tr.enable_step_graph(b0, warmup=2)
+            else:
+                tr.train_step(b0)
+                tr.train_step(b0)
+            vb = _batch('ess_supervised', vshape, 777)  # (events, labels) of another batch size
+            trace = []
+
+            def validate():
+                for m in tr.models_dict.values():
+                    m.eval()
+                with torch.no_grad():
+                    losses, _ = tr.val_step([vb[0], vb[1]], 'sensor_b')
+                for m in tr.models_dict.values():
+                    m.train()
+                tr.front_end_sensor_b.eval()
+                return {k: float(v) for k, v in losses.items()}
+            trace.append(tr.train_step(_batch(kind, shape, 301))[2].item())
+            trace.append(validate())
+            for s in range(3):
+                trace.append(tr.train_step(_batch(kind, shape, 302 + s))[2].item())
+            trace.append(validate())
+            # weights replaced under the captured step
+            tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, shape[5]), 192, decoder_style=True))
+            trace.append(tr.train_step(_batch(kind, shape, 310))[2].item())
+            trace.append(tr.train_step(_batch(kind, shape, 311))[2].item())
+            trace.append(validate())
+            # an eager optimiser step after replays uses its own step scalars (RAdam's prepared flag is consumed by the replay)
+            g, tr._g = getattr(tr, '_g', None), None
+            trace.append(tr.train_step(_batch(kind, shape, 312))[2].item())
+            tr._g = g
+            trace.append(tr.train_step(_batch(kind, shape, 313))[2].item())
+            torch.cuda.synchronize()
+            w = {k: v.detach().clone() for k, v in tr.task_backend.state_dict().items()}
+            runs.append((trace, w, tr.optimizers_dict['optimizer_back']._step))
+        (t0, w0, s0), (t1, w1, s1) = runs
+        assert s0 == s1, (s0, s1)
+        assert t0 == t1, [(a, b) for a, b in zip(t0, t1) if a != b][:3]
+        assert all(torch.equal(w0[k], w1[k]) for k in w0)
+    finally:
+        hip.set_compute('fp32')
+
+
 def test_captured_step_host_issue_time():
     """Full-size config 3 step: host-side time to ISSUE one step (no synchronisation inside the timed region), eager vs replay."""
     from ess_amd import hip
