@@ -174,6 +174,17 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   if (ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
     if (lds2 <= 160 * 1024) {
+      // persistent launch when the grid exceeds one resident set of workgroups (2 per CU by registers -- 1 for the 128-row
+      // instance -- and by LDS): see the tile schedule in conv_bf16_ws.hip.  ESS_WS_PERSIST=0: one workgroup per tile (tuning).
+      static const int persist = [] { const char* e = getenv("ESS_WS_PERSIST"); return e ? atoi(e) : 1; }();
+      const int per_cu_lds = (int)((160 * 1024) / lds2), per_cu = (mb == 4 ? 1 : 2) < per_cu_lds ? (mb == 4 ? 1 : 2) : per_cu_lds;
+      const int slots = 256 * per_cu;
+      if (persist && (int)grid.x > slots) {
+        ConvKArgs t = a;
+        t.persist = 1;
+        conv_bf16_launch_ws(mb, d->epilogue, c8, dim3((unsigned)slots), lds2, st, t);
+        return ess_launch_status("conv2d_forward(bf16, wave-specialised, persistent)");
+      }
       conv_bf16_launch_ws(mb, d->epilogue, c8, grid, lds2, st, a);
       return ess_launch_status("conv2d_forward(bf16, wave-specialised)");
     }

@@ -16,12 +16,15 @@ using namespace essconv;
 
 constexpr int HT_W = 32, HT_H = 32, HT_IW = 40, HT_IH = HT_H + 4;
 
-template <bool SC>
+// NC: channel capacity of the instance (2: the BASELINE voxel grids; 5: the reference's own default, nr_temporal_bins = 5,
+// config/settings_DSEC.yaml:15) -- R = 5 NC filter rows = NS = ceil(R / 2) K-steps; a missing last row carries zero weights.
+template <bool SC, int NC>
 __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a, int tiles_x, int tiles_y) {
+  constexpr int R = 5 * NC, NS = (R + 1) / 2;
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
-  __shared__ float tile[2 * HT_IH * HT_IW];
-  __shared__ __attribute__((aligned(16))) u32x4 wfrag[5 * 2 * 32];
+  __shared__ float tile[NC * HT_IH * HT_IW];
+  __shared__ __attribute__((aligned(16))) u32x4 wfrag[NS * 2 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int ct = logical % a.n_cout_tiles;
@@ -34,19 +37,19 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
 
   // ---- weights: tap-paired pack [tile][chunk 0][pair][tap parity][cout 32][channel 8] -> A fragments [K-step][half][cout][8 slots]
   const unsigned short* wp = (const unsigned short*)a.wpk + (size_t)ct * (13 * 2 * 32 * 8);
-  for (int i = tid; i < 320; i += 256) {
+  for (int i = tid; i < NS * 2 * 32; i += 256) {
     const int m = i & 31, r = i >> 5;
     const int c = r / 5, ky = r - 5 * c;
     unsigned v[5];
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) v[kx] = wp[(size_t)((ky * 5 + kx) * 32 + m) * 8 + c];  // (pair * 2 + parity = tap)
+    for (int kx = 0; kx < 5; ++kx) v[kx] = r < R ? wp[(size_t)((ky * 5 + kx) * 32 + m) * 8 + c] : 0u;  // (pair * 2 + parity = tap)
     const u32x4 f = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4], 0u};
     wfrag[r * 32 + m] = f;  // row r = 2 s + h
   }
   // ---- input tile: both channels, 2-pixel halo, zero outside the image (and for an absent second channel)
   {
     const ess_rsrc r_in = ess_make_rsrc(a.src0 + (size_t)n * a.C0 * a.Hin * a.Win, (size_t)a.C0 * a.Hin * a.Win * 4);
-    constexpr int NLD = (2 * HT_IH * HT_IW + 255) / 256;
+    constexpr int NLD = (NC * HT_IH * HT_IW + 255) / 256;
     float ld[NLD];  // every load is in flight before the first LDS write
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -54,13 +57,13 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
       const int c = i / (HT_IH * HT_IW), rem = i - c * (HT_IH * HT_IW);
       const int iy = rem / HT_IW, ix = rem - iy * HT_IW;
       const int gy = y0 - 2 + iy, gx = x0 - 2 + ix;
-      const bool ok = (i < 2 * HT_IH * HT_IW) & (c < a.C0) & (gy >= 0) & (gy < a.Hin) & (gx >= 0) & (gx < a.Win);
+      const bool ok = (i < NC * HT_IH * HT_IW) & (c < a.C0) & (gy >= 0) & (gy < a.Hin) & (gx >= 0) & (gx < a.Win);
       ld[k] = ess_bload(r_in, ok ? (unsigned)((c * a.Hin + gy) * a.Win + gx) * 4u : ESS_OOB, 0);
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int i = tid + k * 256;
-      if (i < 2 * HT_IH * HT_IW) tile[i] = ld[k];
+      if (i < NC * HT_IH * HT_IW) tile[i] = ld[k];
     }
   }
   // per-channel scale / shift of this lane's rows (the packed vectors are padded to the 32-row tile)
@@ -74,13 +77,13 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
     sh[4 * j] = h4.x; sh[4 * j + 1] = h4.y; sh[4 * j + 2] = h4.z; sh[4 * j + 3] = h4.w;
   }
   __syncthreads();
-  u32x4 af[5];
-  int roff[5];
+  u32x4 af[NS];
+  int roff[NS];
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
+  for (int s = 0; s < NS; ++s) {
     const int r = 2 * s + half, c = r / 5, ky = r - 5 * c;
     af[s] = wfrag[r * 32 + p];
-    roff[s] = (c * HT_IH + ky) * HT_IW + p;
+    roff[s] = r < R ? (c * HT_IH + ky) * HT_IW + p : p;  // (a row past the filter: zero weights on finite data)
   }
   const bool relu = a.act == ESS_ACT_RELU;
   const bool out8 = a.fmt_out == ESS_FMT_BF16_C8;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
+    for (int s = 0; s < NS; ++s) {
       const float* src = tile + ly * HT_IW + roff[s];
       float v[8];
 #pragma unroll
@@ -293,7 +296,7 @@ namespace essconv {
 
 bool conv_bf16_head_applies(const EssConvDesc* d, const EssConvPlan& pl) {
   static const bool on = [] { const char* e = getenv("ESS_CONV_HEAD"); return !(e && e[0] == '0'); }();
-  return on && d->compute == ESS_COMPUTE_BF16 && d->ksize == 5 && d->stride == 1 && d->pad == 2 && d->C1 == 0 && d->C0 <= 2 &&
+  return on && d->compute == ESS_COMPUTE_BF16 && d->ksize == 5 && d->stride == 1 && d->pad == 2 && d->C1 == 0 && d->C0 <= 5 &&
          d->mode0 == ESS_SRC_DIRECT && d->fmt0 == ESS_FMT_F32_NCHW && d->epilogue == ESS_EPI_LINEAR && d->out_split == 0 &&
          (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU) && pl.cout_tile == 32 && pl.n_chunks == 1 && pl.ck == 8;
 }
@@ -320,8 +323,13 @@ void conv_bf16_launch_stem(const EssConvDesc* d, const EssConvPlan& pl, hipStrea
 void conv_bf16_launch_head(const EssConvDesc* d, const EssConvPlan& pl, hipStream_t st, const ConvKArgs& a) {
   const int tiles_x = ceil_div(d->W_out, HT_W), tiles_y = ceil_div(d->H_out, HT_H);
   const dim3 grid((unsigned)(tiles_x * tiles_y * pl.n_cout_tiles * d->N));
-  if (a.scale) hipLaunchKernelGGL(conv_bf16_head5_kernel<true>, grid, dim3(256), 0, st, a, tiles_x, tiles_y);
-  else hipLaunchKernelGGL(conv_bf16_head5_kernel<false>, grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+  if (d->C0 <= 2) {
+    if (a.scale) hipLaunchKernelGGL((conv_bf16_head5_kernel<true, 2>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_bf16_head5_kernel<false, 2>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+  } else {  // 3 .. 5 voxel-grid bins
+    if (a.scale) hipLaunchKernelGGL((conv_bf16_head5_kernel<true, 5>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+    else hipLaunchKernelGGL((conv_bf16_head5_kernel<false, 5>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+  }
 }
 
 }  // namespace essconv

@@ -37,17 +37,40 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ct = logical % a.n_cout_tiles;
-  const int sp = logical / a.n_cout_tiles;
-  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  // Tile schedule.  Plain launch: one workgroup per tile, XCD-contiguous order (xcd_remap).  Persistent launch (a.persist: the grid
+  // is one resident set of workgroups): workgroup b -- on XCD b % 8 by the dispatcher's round-robin -- walks every (grid / 8)-th
+  // tile of its XCD's contiguous range, so neighbouring workgroups of an XCD still work on neighbouring tiles at the same time.
+  // What the loop buys: after the last chunk's barrier the producer waves go straight on to the NEXT tile (index arithmetic, first
+  // chunk's loads and LDS writes, second chunk's loads) while the matrix waves run this tile's epilogue -- the prologue of tile
+  // t + 1 overlaps the epilogue of tile t inside one workgroup instead of relying on the other workgroup of the CU being out of phase.
+  int t_start, t_count, t_first = 0, t_step = 1;
+  if (a.persist) {
+    const int total = a.n_cout_tiles * a.n_tiles * a.N, q = total >> 3, r = total & 7, xcd = (int)(blockIdx.x & 7);
+    t_start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    t_count = q + (xcd < r ? 1 : 0);
+    t_first = (int)(blockIdx.x >> 3);
+    t_step = (int)(gridDim.x >> 3);
+  } else {
+    t_start = xcd_remap(blockIdx.x, gridDim.x);
+    t_count = 1;
+  }
+  // (one tile loop PER ROLE: with a common loop hipcc hoists both roles' tile-invariant values above it and keeps the producers'
+  // staging plan alive through the matrix waves' epilogue -- 59 spilled VGPRs in the 128-register instances)
+#define ESS_TILE_LOOP for (int ti = t_first; ti < t_count; ti += t_step)
+#define ESS_TILE_DECODE                                                    \
+  const int logical = t_start + ti;                                        \
+  const int ct = logical % a.n_cout_tiles;                                 \
+  const int sp = logical / a.n_cout_tiles;                                 \
+  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;                     \
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;             \
   const int y0 = ty * TH, x0 = tx * TW;
   const int bufsz = CB8 * a.plane + WSZ;  // one stage: input tile + weight slab (16-byte units)
   ESS_CT(0);
   ESS_CW(46);
 
   if (role == 1 && SRCBF) {
+    ESS_TILE_LOOP {
+    ESS_TILE_DECODE
     // ------------------------------------------------------------------ producer, BF16_C8 sources
     // The sources are already bf16 pixel vectors ([N][C/8][H][W][8]): staging one is ONE 16-byte load and ONE
     // ds_write_b128, no conversion.  A halo row of the tile is 34 x 16 B contiguous, so an 8-channel block costs ~5
@@ -140,9 +163,12 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       }
     }
     ESS_CT(47);
+    }  // tile loop
     return;
   }
   if (role == 1) {
+    ESS_TILE_LOOP {
+    ESS_TILE_DECODE
     // ------------------------------------------------------------------------------------------- producer
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
     const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
@@ -212,9 +238,17 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       }
       __syncthreads();
     }
+    }  // tile loop
     return;
   }
   // --------------------------------------------------------------------------------------------- consumer
+  ESS_TILE_LOOP {
+  ESS_TILE_DECODE
+  // (the lane-dependent addressing below is tile-invariant; an opaque copy of the thread id per tile keeps hipcc from hoisting it
+  // out of the tile loop, where it would stay live through the epilogue: +28 spilled VGPRs in the 128-register instances)
+  int tid_t = (int)(threadIdx.x & 255);
+  asm volatile("" : "+v"(tid_t));
+  const int tid = tid_t, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int ox = p & (BW - 1), oy = p >> a.bwl;
   const int wx = wave & (WX - 1), wy = wave >> a.wxl;
   const int lx = wx * BW + ox;
@@ -308,12 +342,15 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
   ESS_CT(45);
   __builtin_amdgcn_s_setprio(0);
 #ifdef ESS_ABLATE
-  if (a.deep & 8) return;  // (ablation build only: no epilogue)
+  if (a.deep & 8) continue;  // (ablation build only: no epilogue)
 #endif
   if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   ESS_CT(47);
   if constexpr (EPI != ESS_EPI_LSTM) ESS_CW(43);
+  }  // tile loop
+#undef ESS_TILE_LOOP
+#undef ESS_TILE_DECODE
 }
 
 

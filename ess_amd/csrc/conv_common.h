@@ -29,6 +29,7 @@ struct ConvKArgs {
   int fmt0, fmt1;  // ESS_FMT_* of the sources
   int fmt_out;     // ESS_FMT_BF16_C8: `out` / `out2` ARE BF16_C8 tensors (LINEAR epilogue), nothing is written in fp32
   int fmt_res;     // format of `residual`
+  int persist;     // 3x3 wave-specialised kernel: the grid is one resident set of workgroups, each walking several tiles
   int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
 };
 

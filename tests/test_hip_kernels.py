@@ -752,9 +752,11 @@ def test_augment_image_label_vs_oracle(H, shape):
 
 
 @pytest.mark.parametrize('case', [(2, 2, 32, 37, 70, 1, 'fp32'), (1, 2, 32, 64, 96, 1, 'c8'), (2, 1, 32, 33, 41, 0, 'both'),
-                                  (1, 2, 24, 40, 64, 1, 'c8'), (1, 2, 64, 35, 33, 1, 'both'), (2, 2, 20, 16, 31, 0, 'fp32')])
+                                  (1, 2, 24, 40, 64, 1, 'c8'), (1, 2, 64, 35, 33, 1, 'both'), (2, 2, 20, 16, 31, 0, 'fp32'),
+                                  (1, 5, 32, 44, 64, 1, 'c8'), (2, 5, 32, 37, 70, 1, 'both'), (1, 3, 32, 22, 36, 0, 'fp32'), (1, 4, 40, 33, 41, 1, 'both')])
 def test_conv_head5x5_bf16(H, case):
-    """The recurrent encoder's head (reference e2vid/model/unet.py:118: 5x5, padding 2, 1-2 input channels) on its dedicated bf16
+    """The recurrent encoder's head (reference e2vid/model/unet.py:118: 5x5, padding 2; 1-2 input channels in the BASELINE configs, 5
+    voxel-grid bins in the reference's own default, config/settings_DSEC.yaml:15) on its dedicated bf16
     kernel (conv_bf16_head.hip): exact (to accumulation order) against an fp32 conv of bf16-rounded operands; outputs as fp32
     planes, as a BF16_C8 tensor, or as planes + BF16_C8 copy -- ragged sizes, channel tails, two channel tiles."""
     N, C, Cout, Hv, Wv, act, form = case
