@@ -168,6 +168,17 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   if (is_paired(d)) {  // 5x5: tap-paired wave-specialised kernel (the plan and the weight pack are specific to it)
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;
     ESS_CHECK_ARG(lds2 <= 160 * 1024, "conv(bf16, 5x5): two stages of %d B exceed the 160 KiB LDS", pl.lds_bytes);
+    {  // persistent launch (see the 3x3 kernel below): one resident set of workgroups when the grid exceeds it
+      static const int persist = [] { const char* e = getenv("ESS_WS_PERSIST"); return e ? atoi(e) : 1; }();
+      const int by_regs = (d->stride == 2 && mb == 2) ? 1 : 2, by_lds = (int)((160 * 1024) / lds2);
+      const int slots = 256 * (by_regs < by_lds ? by_regs : by_lds);
+      if (persist && (int)grid.x > slots) {
+        ConvKArgs t = a;
+        t.persist = 1;
+        conv_bf16_launch_pair(d->stride, mb, c8, dim3((unsigned)slots), lds2, st, t);
+        return ess_launch_status("conv2d_forward(bf16, tap-paired, persistent)");
+      }
+    }
     conv_bf16_launch_pair(d->stride, mb, c8, grid, lds2, st, a);
     return ess_launch_status("conv2d_forward(bf16, tap-paired)");
   }

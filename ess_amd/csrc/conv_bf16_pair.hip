@@ -24,15 +24,31 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int BW = 1 << a.bwl, WX = 1 << a.wxl, RB = 32 >> a.bwl;
   const int TW = WX << a.bwl, TH = (4 >> a.wxl) * NBW * RB;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ct = logical % a.n_cout_tiles;
-  const int sp = logical / a.n_cout_tiles;
-  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;
-  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  // tile schedule: plain (one workgroup per tile) or persistent (a.persist) -- as in conv_bf16_ws.hip, one tile loop per role
+  int t_start, t_count, t_first = 0, t_step = 1;
+  if (a.persist) {
+    const int total = a.n_cout_tiles * a.n_tiles * a.N, q = total >> 3, r = total & 7, xcd = (int)(blockIdx.x & 7);
+    t_start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    t_count = q + (xcd < r ? 1 : 0);
+    t_first = (int)(blockIdx.x >> 3);
+    t_step = (int)(gridDim.x >> 3);
+  } else {
+    t_start = xcd_remap(blockIdx.x, gridDim.x);
+    t_count = 1;
+  }
+#define ESS_TILE_LOOP for (int ti = t_first; ti < t_count; ti += t_step)
+#define ESS_TILE_DECODE                                                    \
+  const int logical = t_start + ti;                                        \
+  const int ct = logical % a.n_cout_tiles;                                 \
+  const int sp = logical / a.n_cout_tiles;                                 \
+  const int tile = sp % a.n_tiles, n = sp / a.n_tiles;                     \
+  const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;             \
   const int y0 = ty * TH, x0 = tx * TW;
   const int bufsz = a.plane + WSZ;  // one stage: 8-channel input tile + weight slab (16-byte units)
 
   if (role == 1) {
+    ESS_TILE_LOOP {
+    ESS_TILE_DECODE
     // ------------------------------------------------------------------------------------------- producer
     const int iy0 = y0 * S - a.pad, ix0 = x0 * S - a.pad;
     const int npos = a.IH * a.IW;
@@ -180,9 +196,15 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
         __syncthreads();
       }
     }
+    }  // tile loop
     return;
   }
   // --------------------------------------------------------------------------------------------- consumer
+  ESS_TILE_LOOP {
+  ESS_TILE_DECODE
+  int tid_t = (int)(threadIdx.x & 255);  // (opaque per tile: keeps the lane addressing from being hoisted out of the tile loop)
+  asm volatile("" : "+v"(tid_t));
+  const int tid = tid_t, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int ox = p & (BW - 1), oy = p >> a.bwl;
   const int wx = wave & (WX - 1), wy = wave >> a.wxl;
   const int lx = wx * BW + ox;
@@ -231,6 +253,9 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
     __syncthreads();
   }
   conv_epilogue<MB, ESS_EPI_LINEAR>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  }  // tile loop
+#undef ESS_TILE_LOOP
+#undef ESS_TILE_DECODE
 }
 
 

@@ -264,6 +264,68 @@ __global__ void evnorm_apply_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// All T time slices of a batch in one reduce + one map launch.  x = [B][T][chunk] (the trainers' event tensor [B, T*C, H, W]:
+// slice t of sample b is a contiguous run of chunk = C*H*W floats), y = [T][B][chunk] (each normalised slice a contiguous
+// [B, C, H, W] tensor); statistics per slice over the whole batch, as EventPreprocessor computes them on data_b[:, t*C:(t+1)*C].
+// workspace: double[T][3].  blockIdx.y = slice.
+__global__ __launch_bounds__(256) void evnorm_slices_reduce_kernel(const float* __restrict__ x, int B, int T, int64_t chunk, double* ws) {
+  __shared__ double red[16];
+  const int t = blockIdx.y;
+  double c = 0, s = 0, ss = 0;
+  if ((chunk & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+    const int64_t c4 = chunk >> 2, n4 = (int64_t)B * c4;
+    const f32x4* x4 = (const f32x4*)x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t b = i / c4, off = i - b * c4;
+      const f32x4 v = x4[(b * T + t) * c4 + off];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c += v[j] != 0.f ? 1.0 : 0.0; s += v[j]; ss += (double)v[j] * v[j]; }
+    }
+  } else {
+    const int64_t n = (int64_t)B * chunk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t b = i / chunk, off = i - b * chunk;
+      const float v = x[(b * T + t) * chunk + off];
+      if (v != 0.f) { c += 1; s += v; ss += (double)v * v; }
+    }
+  }
+  c = block_sum_d(c, red);
+  s = block_sum_d(s, red);
+  ss = block_sum_d(ss, red);
+  if (threadIdx.x == 0) { atomicAdd(ws + 3 * t, c); atomicAdd(ws + 3 * t + 1, s); atomicAdd(ws + 3 * t + 2, ss); }
+}
+
+__global__ void evnorm_slices_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T, int64_t chunk, const double* ws) {
+  const int t = blockIdx.y;
+  const double cnt = ws[3 * t];
+  float mean = 0.f, sd = 1.f;
+  const bool on = cnt > 0;
+  if (on) {  // fp32 arithmetic on the totals, as the reference does (inference_utils.py:104-105)
+    const float fs = (float)ws[3 * t + 1], fss = (float)ws[3 * t + 2], fc = (float)cnt;
+    mean = fs / fc;
+    sd = sqrtf(fss / fc - mean * mean);
+  }
+  if ((chunk & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+    const int64_t c4 = chunk >> 2, n4 = (int64_t)B * c4;
+    const f32x4* x4 = (const f32x4*)x;
+    f32x4* y4 = (f32x4*)y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t b = i / c4, off = i - b * c4;
+      f32x4 v = x4[(b * T + t) * c4 + off];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = on ? (v[j] != 0.f ? (v[j] - mean) / sd : 0.f) : v[j];
+      y4[(int64_t)t * n4 + i] = v;
+    }
+  } else {
+    const int64_t n = (int64_t)B * chunk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t b = i / chunk, off = i - b * chunk;
+      const float v = x[(b * T + t) * chunk + off];
+      y[(int64_t)t * n + i] = on ? (v != 0.f ? (v - mean) / sd : 0.f) : v;
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t n, int bs = 256, int cap = 256 * 16) {
   int64_t g = ceil_div64(n, bs);
   return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -363,6 +425,23 @@ extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* wo
   return ess_launch_status("event_normalize");
 }
 
+
+extern "C" int ess_event_normalize_slices(const float* x, float* y, int32_t B, int32_t T, int64_t chunk, void* workspace,
+                                          ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && workspace && B > 0 && T > 0 && T <= 65535 && chunk > 0, "event_normalize_slices: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  {
+    hipError_t e = hipMemsetAsync(workspace, 0, (size_t)T * 3 * sizeof(double), st);
+    if (e != hipSuccess) {
+      ess_set_error("event_normalize_slices: memset failed: %s", hipGetErrorString(e));
+      return ESS_ELAUNCH;
+    }
+  }
+  const int64_t n = (int64_t)B * chunk;
+  hipLaunchKernelGGL(evnorm_slices_reduce_kernel, dim3(grid_for(n / 4, 256, 128), (unsigned)T), dim3(256), 0, st, x, B, T, chunk, (double*)workspace);
+  hipLaunchKernelGGL(evnorm_slices_apply_kernel, dim3(grid_for(n / 4, 256, 1024), (unsigned)T), dim3(256), 0, st, x, y, B, T, chunk, (const double*)workspace);
+  return ess_launch_status("event_normalize_slices");
+}
 
 // fp32 NCHW -> BF16_C8 ([N][ceil(C/8)][H][W][8] bfloat16, tail channels zero): one thread = one pixel vector.
 namespace {

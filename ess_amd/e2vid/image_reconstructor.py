@@ -46,18 +46,51 @@ class ImageReconstructor:
             events = self.crop.pad(events)
             if not events.is_contiguous():
                 events = events.contiguous()
-            if need_image:
-                out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'])
-            else:
-                # lean_state: this step only advances the recurrent state (callers: every time step but the last of a
-                # training / validation sequence); latent is then None and the fp32 hidden states are not materialised
-                out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], encoder_only=True,
-                                                 lean=lean_state and not self.no_recurrent and _LEAN)
-            self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
-            if self.standardization and out is not None:
-                b, h, w = out.size(0), out.size(2), out.size(3)
-                flat = out.view(b, -1)
-                flat = flat - flat.min(1, keepdim=True)[0]
-                flat = flat / flat.max(1, keepdim=True)[0]
-                out = flat.view(b, 1, h, w)
+            return self._step(events, need_image, lean_state)
+
+    def _step(self, events, need_image, lean_state):
+        """One model step on a normalised, padded, contiguous slice (under no_grad)."""
+        if need_image:
+            out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'])
+        else:
+            # lean_state: this step only advances the recurrent state (callers: every time step but the last of a
+            # training / validation sequence); latent is then None and the fp32 hidden states are not materialised
+            out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], encoder_only=True,
+                                             lean=lean_state and not self.no_recurrent and _LEAN)
+        self.last_states_for_each_channel['grayscale'] = None if self.no_recurrent else states
+        if self.standardization and out is not None:
+            b, h, w = out.size(0), out.size(2), out.size(3)
+            flat = out.view(b, -1)
+            flat = flat - flat.min(1, keepdim=True)[0]
+            flat = flat / flat.max(1, keepdim=True)[0]
+            out = flat.view(b, 1, h, w)
         return out, states, latent
+
+    def update_reconstruction_sequence(self, event_tensor, T, need_image=True):
+        """The trainers' hot loop as one call (reference training/ess_trainer.py:277-280, ess_supervised_trainer.py:128-130):
+            for i in range(T): out, states, latent = update_reconstruction(event_tensor[:, i*C:(i+1)*C])
+        -> (out, states, latent) of the LAST step (out is None unless need_image).  Same per-slice arithmetic; what changes is the
+        issue pattern: the non-zero mean / std normalisation of all T slices runs as ONE reduce + ONE map launch straight from the
+        [B, T*C, H, W] tensor (no per-slice strided copy, 2 launches instead of 3 T), and the steps t < T-1 are lean.  Falls back
+        to the per-slice path when the preprocessor has hot pixels / flipping or the size needs reflection padding."""
+        from .. import hip
+        with torch.no_grad():
+            events = event_tensor.to(self.device)
+            if events.shape[1] % T:
+                raise ValueError('update_reconstruction_sequence: channel count is not T equal slices')
+            C = events.shape[1] // T
+            pre = self.event_preprocessor
+            batched = self.crop.is_identity and not pre.flip and len(pre.hot_pixel_locations) == 0 and not pre.no_normalize and \
+                events.is_contiguous() and events.dtype == torch.float32
+            slices = hip.event_normalize_slices(events, T) if batched else None
+            res = (None, None, None)
+            for i in range(T):
+                last = i == T - 1
+                if slices is not None:
+                    ev = slices[i]
+                else:
+                    ev = self.crop.pad(pre(events[:, i * C:(i + 1) * C]))
+                    if not ev.is_contiguous():
+                        ev = ev.contiguous()
+                res = self._step(ev, need_image and last, not last)
+            return res

@@ -44,7 +44,7 @@ EXPORTS = [
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
-    'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16',
+    'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices',
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
             'ess_add': [P, P, P, I64, P],
             'ess_add_bf16': [P, P, P, P, I64, P],
             'ess_event_normalize': [P, P, I64, P, P],
+            'ess_event_normalize_slices': [P, P, I, I, I64, P, P],
             'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, P],
             'ess_sym_js_loss': [P, P, P, P, F, I, I, I, P, P],
             'ess_l1_loss': [P, P, P, P, F, I64, P, P],
@@ -479,6 +480,20 @@ def event_normalize(x):
     y = torch.empty_like(x)
     ws = workspace(64, x.device, 'evnorm')
     _check(lib().ess_event_normalize(ptr(x), ptr(y), x.numel(), c_void_p(ws.data_ptr()), stream()), 'ess_event_normalize')
+    return y
+
+
+def event_normalize_slices(x, T):
+    """EventPreprocessor's normalisation of every time slice x[:, t*C:(t+1)*C] of an event tensor [B, T*C, H, W] in one reduce +
+    one map launch -> [T, B, C, H, W] (slice t contiguous); statistics per slice over the whole batch."""
+    ptr(x)
+    B, TC, H, W = x.shape
+    if TC % T:
+        raise EssHipError(f'event_normalize_slices: {TC} channels are not {T} equal slices')
+    C = TC // T
+    y = torch.empty(T, B, C, H, W, dtype=torch.float32, device=x.device)
+    ws = workspace(24 * T, x.device, 'evnorm_slices')
+    _check(lib().ess_event_normalize_slices(ptr(x), ptr(y), B, T, C * H * W, c_void_p(ws.data_ptr()), stream()), 'ess_event_normalize_slices')
     return y
 
 

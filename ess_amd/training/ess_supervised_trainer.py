@@ -89,10 +89,8 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
                 m.eval()
         self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         T, C = s.nr_events_data_b, s.input_channels_b
-        for i in range(T):
-            # only the encoder half feeds the recurrent state; the image half is needed at the last step only
-            img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
-                data_b[:, i * C:(i + 1) * C, :, :], need_image=False, lean_state=i < T - 1)
+        # (only the encoder half feeds the recurrent state and the latents: no reconstruction is needed by this trainer)
+        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=False)
         losses, outputs = {}, {}
         loss, pred_b = self.trainTaskStep('sensor_b', latent_real, labels_b, losses)
         return loss, losses, outputs
@@ -140,9 +138,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         with torch.no_grad():
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             T, C = s.nr_events_data_b, s.input_channels_b
-            for i in range(T):
-                _, _, latent = self.reconstructor.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=False,
-                                                                        lean_state=i < T - 1)
+            _, _, latent = self.reconstructor.update_reconstruction_sequence(data, T, need_image=False)
             self.valTaskStep(latent, labels, losses, sensor)
         return losses, None
 

@@ -247,10 +247,9 @@ class ESSModel(base_trainer.BaseTrainer):
         self.models_dict['front_sensor_b'].eval()
         self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         T, C = s.nr_events_data_b, s.input_channels_b
-        with torch.no_grad():
-            for i in range(T):
-                img_fake, states_real, latent_real = self.reconstructor.update_reconstruction(
-                    data_b[:, i * C:(i + 1) * C, :, :], need_image=(i == T - 1), lean_state=i < T - 1)
+        # (the loop `for i in range(T): update_reconstruction(data_b[:, i*C:(i+1)*C])` of the reference as one call: all T slices
+        # normalised by one reduce + one map launch, lean steps for t < T-1)
+        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=True)
         return img_fake, latent_real
 
     def event_train_step(self, batch, enc=None):
@@ -379,9 +378,7 @@ class ESSModel(base_trainer.BaseTrainer):
             rec = self.reconstructor_valid
             rec.last_states_for_each_channel = {'grayscale': None}
             T, C = s.nr_events_data_b, s.input_channels_b
-            for i in range(T):  # only the last slice's image and latents are consumed
-                img_fake, _, content = rec.update_reconstruction(data[:, i * C:(i + 1) * C, :, :], need_image=i == T - 1,
-                                                                 lean_state=i < T - 1)
+            img_fake, _, content = rec.update_reconstruction_sequence(data, T, need_image=True)  # (only the last slice's image and latents are consumed)
             preds = self.valTaskStep(content, labels, losses, sensor)
             self.valCycleStep(content, img_fake, labels, losses, sensor, 'sensor_a', preds)
         return losses, None

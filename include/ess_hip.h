@@ -232,6 +232,11 @@ int ess_add_bf16(const void* a, const void* b, const void* c, void* y, int64_t n
  * tensor of n floats: non-zero mean/std, y = (x!=0)*(x-mean)/std; identity copy when all-zero.
  * workspace: >= 32 bytes, zeroed by the call.  No host synchronisation.                             */
 int ess_event_normalize(const float* x, float* y, int64_t n, void* workspace, ess_stream_t stream);
+/* The same normalisation for all T time slices of a batch in two launches (training/ess_trainer.py:277-280 runs it once per
+ * slice data_b[:, t*C:(t+1)*C]): x = [B][T][chunk] with chunk = C*H*W (the event tensor [B, T*C, H, W] as it is: no slice
+ * copies), y = [T][B][chunk] (slice t = a contiguous [B, C, H, W] tensor), statistics per slice over the whole batch.
+ * workspace: T * 24 bytes.                                                                          */
+int ess_event_normalize_slices(const float* x, float* y, int32_t B, int32_t T, int64_t chunk, void* workspace, ess_stream_t stream);
 
 /* ---- events -> voxel grid on the device (the step in front of the encoder) --------------------
  * All slices of a batch in one launch: events concatenated structure-of-arrays, slice s = [slice_offsets[s],

@@ -639,3 +639,43 @@ def test_concat_conv_first_source_only_gradient():
         assert relerr(a.grad, torch.nn.functional.avg_pool2d(up.grad, 2) * 4) < 1e-4, it
         w.grad.copy_(gw)
         opt.step()  # rewrites w behind autograd's back: the cached slice and packed layouts must follow
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 2, 48, 64), (3, 4, 5, 40, 56), (1, 3, 2, 22, 36)])
+def test_sequence_call_matches_per_slice_loop(shape):
+    """ImageReconstructor.update_reconstruction_sequence (all T slices normalised by one reduce + one map launch straight from the
+    [B, T*C, H, W] tensor, lean steps) against the reference's loop of update_reconstruction calls on slice views (reference
+    training/ess_trainer.py:277-280): the batched normalisation (`ess_event_normalize_slices`) equals the per-slice one to fp32
+    rounding of the statistics, image / latents / states agree to 1e-5; (22, 36) needs reflection padding and takes the per-slice
+    fallback inside the sequence call; an all-zero slice stays all zero."""
+    from ess_amd import hip
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.options.inference_options import default_options
+    B, T, C, H, W = shape
+    cfg = O.e2vid_config(num_bins=C)
+    sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 61)
+    ev, _, _, _ = O.synth_batch(B, T, C, H, W, 6, seed=23)
+    ev[:, C:2 * C] = 0  # slice 1 all zero: the `num_nonzeros == 0` branch
+    ev = ev.cuda().contiguous()
+    if H % 8 == 0:
+        sl = hip.event_normalize_slices(ev, T)
+        for t in range(T):
+            ref = hip.event_normalize(ev[:, t * C:(t + 1) * C].contiguous())
+            assert relerr(sl[t], ref) < 1e-6 if ref.abs().max() > 0 else float(sl[t].abs().max()) == 0.0
+    for mode in ('fp32', 'bf16'):
+        hip.set_compute(mode)
+        try:
+            model = _e2vid(cfg, sd)
+            rec = ImageReconstructor(model, H, W, C, torch.device('cuda:0'), default_options())
+            rec.last_states_for_each_channel = {'grayscale': None}
+            for t in range(T):
+                img0, st0, lat0 = rec.update_reconstruction(ev[:, t * C:(t + 1) * C])
+            rec.last_states_for_each_channel = {'grayscale': None}
+            img1, st1, lat1 = rec.update_reconstruction_sequence(ev, T)
+            assert relerr(img1, img0) < 1e-5
+            for k in (1, 2, 4, 8):
+                assert relerr(lat1[k], lat0[k]) < 1e-5, k
+            for (h0, c0), (h1, c1) in zip(st0, st1):
+                assert relerr(h1, h0) < 1e-5 and relerr(c1, c0) < 1e-5
+        finally:
+            hip.set_compute('fp32')
