@@ -271,13 +271,24 @@ __global__ __launch_bounds__(256) void conv_bf16_stem7_kernel(const ConvKArgs a,
           uint2 pk[2];
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
-            bf16x4 b;
+            float q[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int c = cbase + 8 * (jp + jj) + 4 * half + i;
-              b[i] = (__bf16)(c < a.Cout ? v[4 * (jp + jj) + i] : 0.f);
+              q[i] = c < a.Cout ? v[4 * (jp + jj) + i] : 0.f;
             }
-            pk[jj] = __builtin_bit_cast(uint2, b);
+            if (a.out_f16) {  // (uniform) ESS_FMT_F16_C8: the stem's output is a pre-norm tensor (BatchNorm reads it)
+              typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+              f16x4 h;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) h[i] = (_Float16)q[i];
+              pk[jj] = __builtin_bit_cast(uint2, h);
+            } else {
+              bf16x4 b;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) b[i] = (__bf16)q[i];
+              pk[jj] = __builtin_bit_cast(uint2, b);
+            }
           }
           const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);

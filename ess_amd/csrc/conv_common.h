@@ -29,6 +29,7 @@ struct ConvKArgs {
   int fmt0, fmt1;  // ESS_FMT_* of the sources
   int fmt_out;     // ESS_FMT_BF16_C8: `out` / `out2` ARE BF16_C8 tensors (LINEAR epilogue), nothing is written in fp32
   int fmt_res;     // format of `residual`
+  int out_f16;     // BF16_C8-output epilogue: store IEEE half instead of bfloat16 (ESS_FMT_F16_C8: a pre-norm tensor, read by the norm kernels only)
   int persist;     // 3x3 wave-specialised kernel: the grid is one resident set of workgroups, each walking several tiles
   int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
 };
@@ -530,10 +531,18 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
         }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-          bf16x4 b;
+          if (a.out_f16) {  // (uniform)
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 h;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
-          pk[jj][nb] = __builtin_bit_cast(uint2, b);
+            for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[nb][i];
+            pk[jj][nb] = __builtin_bit_cast(uint2, h);
+          } else {
+            bf16x4 b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
+            pk[jj][nb] = __builtin_bit_cast(uint2, b);
+          }
         }
       }
       // exchange halves: lanes 0-31 end up with the whole vector of block blk0, lanes 32-63 with that of blk0 + 1
@@ -865,7 +874,7 @@ inline int validate(const EssConvDesc* d) {
     return ESS_OK;
   }
   ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_BF16_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),
-                "conv: bad output / residual format");
+                "conv: bad output / residual format");  // (ESS_FMT_F16_C8 outputs arrive here as BF16_C8 + the kernels' out_f16 flag)
   if (d->fmt_out == ESS_FMT_BF16_C8)
     ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && (d->out_split % 8) == 0 &&
                       (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU || d->act == ESS_ACT_SUMPOOL2),

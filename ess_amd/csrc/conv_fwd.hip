@@ -226,6 +226,18 @@ extern "C" int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const 
 extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1, const void* packed_w,
                                   const float* scale, const float* shift, const void* residual, const float* aux0,
                                   const float* aux1, void* out, void* out2, void* out_bf16, ess_stream_t stream) {
+  // ESS_FMT_F16_C8 output: the BF16_C8-output path with half elements (LINEAR epilogue; no pooled output, no out_split)
+  EssConvDesc dcopy;
+  bool out_f16 = false;
+  if (d && d->fmt_out == ESS_FMT_F16_C8) {
+    ESS_CHECK_ARG(d->act != ESS_ACT_SUMPOOL2 && d->out_split == 0 && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),
+                  "conv: an F16_C8 output takes no SUMPOOL2 / out_split; a residual comes as BF16_C8");
+    dcopy = *d;
+    dcopy.fmt_out = ESS_FMT_BF16_C8;
+    if (residual) dcopy.fmt_res = ESS_FMT_BF16_C8;
+    d = &dcopy;
+    out_f16 = true;
+  }
   int rc = validate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
@@ -258,6 +270,7 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
 #ifdef ESS_ABLATE  // diagnostic builds only (-DESS_ABLATE): ESS_WS_ABL=<bits> lets the 3x3 kernel skip loads / LDS writes / MFMAs / epilogue
   { static const int abl = [] { const char* b = getenv("ESS_WS_ABL"); return b ? atoi(b) & ~1 : 0; }(); a.deep = abl; }
 #endif
+  a.out_f16 = out_f16 ? 1 : 0;
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;

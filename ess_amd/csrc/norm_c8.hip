@@ -25,6 +25,24 @@ __device__ __forceinline__ void unpack8(u32x4n v, float (&f)[8]) {
     f[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u);
   }
 }
+// x (the PRE-norm tensor a convolution wrote) may be an F16_C8 tensor -- the same layout with IEEE half elements: the norm kernels
+// are its only readers, and half's 11-bit significand keeps 8x more of a channel whose mean is large against its spread than
+// bfloat16 does (ablation in DESIGN.md section 5: the bf16 rounding of the pre-norm tensors was the largest single contribution
+// to the logit error of the bf16 configuration).  Flag: bit 8 of the kernels' `relu` argument.
+__device__ __forceinline__ void unpack8h(u32x4n v, float (&f)[8]) {
+  typedef _Float16 f16x2n __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned w = v[q];  // (ROCm 7.2: a bit_cast applied directly to an ext-vector element reads element 0 for every q)
+    const f16x2n h = __builtin_bit_cast(f16x2n, w);
+    f[2 * q] = (float)h[0];
+    f[2 * q + 1] = (float)h[1];
+  }
+}
+__device__ __forceinline__ void unpack8x(u32x4n v, float (&f)[8], int xf16) {
+  if (xf16) unpack8h(v, f);  // (uniform)
+  else unpack8(v, f);
+}
 __device__ __forceinline__ u32x4n pack8n(const float (&f)[8]) {
   bf16x8n b;
 #pragma unroll
@@ -66,6 +84,8 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                             u32x4n* __restrict__ y, float* __restrict__ stats, int CB, int C,
                                                             int hw, float eps, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   __shared__ float red[16 * 8];
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   const size_t base = (size_t)g * hw;
@@ -86,7 +106,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
     const int i = threadIdx.x + k * THREADS;
     if (i < hw) {
       float f[8];
-      unpack8(xv[k], f);
+      unpack8x(xv[k], f, xf16);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += f[j];
     }
@@ -100,7 +120,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
     const int i = threadIdx.x + k * THREADS;
     if (i < hw) {
       float f[8];
-      unpack8(opaque(xv[k]), f);
+      unpack8x(opaque(xv[k]), f, xf16);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = f[j] - mean[j]; q[j] += d * d; }
     }
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
       const int k = k0 + u, i = threadIdx.x + k * THREADS;
       if (k < MV && i < hw) {
         float f[8], rf[8];
-        unpack8(opaque(xv[k]), f);
+        unpack8x(opaque(xv[k]), f, xf16);
         if (res) unpack8(rv[u], rf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -151,6 +171,8 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
 __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
                                                         const float* __restrict__ stats, u32x4n* __restrict__ dx, int CB, int C,
                                                         int hw, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   __shared__ float red[16 * 8];
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   const size_t base = (size_t)g * hw;
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict
     const int i = threadIdx.x + k * 256;
     if (i < hw) {
       float f[8], gg[8];
-      unpack8(xv[k], f);
+      unpack8x(xv[k], f, xf16);
       unpack8(gv[k], gg);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict
     const int i = threadIdx.x + k * 256;
     if (i < hw) {
       float f[8], gg[8];
-      unpack8(opaque(xv[k]), f);
+      unpack8x(opaque(xv[k]), f, xf16);
       unpack8(opaque(gv[k]), gg);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -218,6 +240,8 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
                                                         const u32x4n* __restrict__ dy, const float* __restrict__ stats,
                                                         double* sums, int hw, int nseg, int seg_stride, int CB, int C,
                                                         int per_sample_stats, int relu, int relu_from_y) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   __shared__ double redd[4 * 16];
   const int g = blockIdx.x, nsl = gridDim.y, sl = blockIdx.y;
   const int len = (hw + nsl - 1) / nsl;
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
       for (int u = 0; u < U; ++u) {
         if (i + u * 256 >= i1) continue;
         float f[8];
-        unpack8(xv[u], f);
+        unpack8x(xv[u], f, xf16);
         if (MODE == 0) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += (double)f[j] * f[j]; }
@@ -320,6 +344,8 @@ __device__ __forceinline__ void group_total8(const double* sums, int g, int nsl,
 __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                           u32x4n* __restrict__ y, float* __restrict__ stats, const double* sums,
                                                           int nsl, int CB, int C, int hw, float eps, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   double t0[8], t1[8];
   group_total8(sums, g, nsl, t0, t1);
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
       const int ii = i + u * stride;
       if (ii >= hw) continue;
       float f[8], rf[8];
-      unpack8(xv[u], f);
+      unpack8x(xv[u], f, xf16);
       if (res) unpack8(rv[u], rf);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -370,6 +396,8 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
 __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
                                                               const float* __restrict__ stats, const double* sums, int nsl,
                                                               u32x4n* __restrict__ dx, int CB, int C, int hw, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   double t0[8], t1[8];
   group_total8(sums, g, nsl, t0, t1);
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __re
       const int ii = i + u * stride;
       if (ii >= hw) continue;
       float f[8], gg[8];
-      unpack8(xv[u], f);
+      unpack8x(xv[u], f, xf16);
       unpack8(gv[u], gg);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -417,6 +445,8 @@ __global__ __launch_bounds__(256) void bn_apply_c8_kernel(const u32x4n* __restri
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           u32x4n* __restrict__ y, float* __restrict__ stats, const double* sums,
                                                           int nsl, int N, int CB, int C, int hw, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   const int g = blockIdx.x, cb = g % CB;
   const double cnt = (double)N * hw;
   double t0[8], t1[8];
@@ -456,7 +486,7 @@ __global__ __launch_bounds__(256) void bn_apply_c8_kernel(const u32x4n* __restri
       const int ii = i + u * stride;
       if (ii >= hw) continue;
       float f[8], rf[8];
-      unpack8(xv[u], f);
+      unpack8x(xv[u], f, xf16);
       if (res) unpack8(rv[u], rf);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -475,6 +505,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
                                                               const float* __restrict__ stats, const double* sums, int nsl,
                                                               u32x4n* __restrict__ dx, u32x4n* __restrict__ dres, float* dgamma,
                                                               float* dbeta, int accumulate, int N, int CB, int C, int hw, int relu) {
+  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+  relu &= 0xff;
   const int g = blockIdx.x, cb = g % CB;
   const double cnt = (double)N * hw;
   double t0[8], t1[8];
@@ -518,7 +550,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
       }
       if (dres) dres[base + ii] = pack8n(gg);
       if (dx) {
-        unpack8(xv[u], f);
+        unpack8x(xv[u], f, xf16);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? gr[j] * (gg[j] - m1[j] - (f[j] - mean[j]) * rstd[j] * m2[j]) : 0.f;
         dx[base + ii] = pack8n(f);
@@ -559,12 +591,13 @@ inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr
 extern "C" size_t ess_norm_workspace_c8(int32_t groups) { return (size_t)(groups > 0 ? groups + 1024 : 0) * 8 * 16; }
 
 extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C,
-                                       int32_t hw, float eps, int32_t relu, void* workspace, size_t workspace_bytes,
+                                       int32_t hw, float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes,
                                        ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && stats && N > 0 && C > 0 && hw > 0, "instnorm_forward_c8: bad arguments");
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_forward_c8: relu must be 0 or 1");
   ESS_CHECK_ARG(al16(x, residual, y), "instnorm_forward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* rs = (const u32x4n*)residual; u32x4n* ys = (u32x4n*)y;
   if (hw <= 256 * MAXV) {
@@ -579,18 +612,19 @@ extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void
   if (rc) return rc;
   const int nsl = split_for8(groups, hw);
   hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, nullptr, nullptr, (double*)workspace, hw, 1,
-                     0, CB, C, 1, 0, 0);
+                     0, CB, C, 1, relu & 0x100, 0);
   hipLaunchKernelGGL(in_apply_c8_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, rs, ys, stats,
                      (const double*)workspace, nsl, CB, C, hw, eps, relu);
   return ess_launch_status("instnorm_forward_c8(split)");
 }
 
 extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C,
-                                        int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
+                                        int32_t hw, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && dy && stats && dx && N > 0 && C > 0 && hw > 0, "instnorm_backward_c8: bad arguments");
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_backward_c8: relu must be 0 or 1");
   ESS_CHECK_ARG(al16(x, dy, dx), "instnorm_backward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* gs = (const u32x4n*)dy; u32x4n* ds = (u32x4n*)dx;
   if (hw <= 256 * MAXV) {
@@ -609,18 +643,19 @@ extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const flo
 
 extern "C" int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const float* gamma, const float* beta,
                                               float* running_mean, float* running_var, float momentum, float eps, void* y,
-                                              float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace,
+                                              float* stats, int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace,
                                               size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && gamma && beta && y && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_forward_c8: bad arguments");
   ESS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "batchnorm_train_forward_c8: running stats come in pairs");
   ESS_CHECK_ARG(al16(x, residual, y), "batchnorm_train_forward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8;
   int rc = need_ws(workspace, ess_norm_workspace_c8(CB), workspace_bytes, "batchnorm_train_forward_c8");
   if (rc) return rc;
   const int nsl = split_for8(CB, hw);
   hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(CB, nsl), dim3(256), 0, st, (const u32x4n*)x, nullptr, nullptr, nullptr,
-                     (double*)workspace, hw, N, CB, CB, C, 0, 0, 0);
+                     (double*)workspace, hw, N, CB, CB, C, 0, relu & 0x100, 0);
   hipLaunchKernelGGL(bn_apply_c8_kernel, dim3(N * CB, chunks_for8(N * CB, hw)), dim3(256), 0, st, (const u32x4n*)x,
                      (const u32x4n*)residual, gamma, beta, running_mean, running_var, momentum, eps, (u32x4n*)y, stats,
                      (const double*)workspace, nsl, N, CB, C, hw, relu);
@@ -629,11 +664,12 @@ extern "C" int ess_batchnorm_train_forward_c8(const void* x, const void* residua
 
 extern "C" int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma,
                                                const float* stats, void* dx, void* d_residual, float* dgamma, float* dbeta,
-                                               int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu,
+                                               int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16,
                                                void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && dy && gamma && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_backward_c8: bad arguments");
   ESS_CHECK_ARG(al16(x, y, dy, dx, d_residual), "batchnorm_train_backward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8;
   int rc = need_ws(workspace, ess_norm_workspace_c8(CB), workspace_bytes, "batchnorm_train_backward_c8");
   if (rc) return rc;

@@ -125,22 +125,38 @@ def _virt(x, mode):
     return x.shape[2] * m, x.shape[3] * m  # (dims 2, 3 are H, W in both layouts)
 
 
+def _blocked(x):
+    return hip.is_c8(x)
+
+
 def _channels(x):
-    """Channel count of an activation: fp32 NCHW, or BF16_C8 [N, C/8, H, W, 8] (whole blocks: every activation of the
-    trainable networks that is stored as BF16_C8 has a multiple of 8 channels)."""
-    return x.shape[1] * 8 if hip.is_c8(x) else x.shape[1]
+    """Channel count of an activation: fp32 NCHW, or BF16_C8 / F16_C8 [N, C/8, H, W, 8] (whole blocks: every activation of the
+    trainable networks that is stored channel-blocked has a multiple of 8 channels)."""
+    return x.shape[1] * 8 if _blocked(x) else x.shape[1]
 
 
 def _fmt(x):
     return hip.FMT_BF16_C8 if hip.is_c8(x) else hip.FMT_F32_NCHW
 
 
+PRE_NORM = 'f16'  # out_c8 value of a convolution whose output goes straight into an InstanceNorm / train-mode BatchNorm
+
+
 def _empty_act(N, C, H, W, device, c8):
     if c8:
         if C % 8:
             raise hip.EssHipError(f'a BF16_C8 activation needs a multiple of 8 channels, got {C}')
-        return hip.bf16_c8_empty(N, C, H, W, device)
+        return hip.f16_c8_empty(N, C, H, W, device) if c8 == PRE_NORM else hip.bf16_c8_empty(N, C, H, W, device)
     return torch.empty(N, C, H, W, dtype=torch.float32, device=device)
+
+
+def pre_norm_fmt():
+    """Storage of a convolution output that feeds a norm kernel: F16_C8 in the bf16 configuration (switch ESS_PRE_NORM_F16=0:
+    BF16_C8 like every other activation -- the round-2 behaviour, for A/B measurements), fp32 NCHW otherwise."""
+    import os
+    if not c8_mode():
+        return False
+    return PRE_NORM if os.environ.get('ESS_PRE_NORM_F16', '1')[:1] != '0' else True
 
 
 def c8_mode():
@@ -261,7 +277,8 @@ class Conv2dFn(torch.autograd.Function):
         spec = hip.conv_spec(N, Hv, Wv, C0, C1, Cout, k, stride, pad, mode0, mode1)
         out = _empty_act(N, Cout, spec.H_out, spec.W_out, x0.device, out_c8)
         shift = packed_rows(spec, bias) if bias is not None else None
-        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out, src_fmt=_fmt(x0), out_fmt=_fmt(out))
+        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out, src_fmt=_fmt(x0),
+                         out_fmt=hip.FMT_F16_C8 if out_c8 == PRE_NORM else _fmt(out))
         ctx.spec = spec
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
@@ -386,21 +403,22 @@ def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT
     return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1, False, out_c8)
 
 
-def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0):
+def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0, out_c8=None):
     """-> (conv2d(x0), x0): use the second value as the skip operand of a residual block (see Conv2dFn.forward)."""
-    return Conv2dFn.apply(x0, None, weight, bias, stride, pad, hip.SRC_DIRECT, hip.SRC_DIRECT, True)
+    return Conv2dFn.apply(x0, None, weight, bias, stride, pad, hip.SRC_DIRECT, hip.SRC_DIRECT, True, out_c8)
 
 
 class InstanceNormFn(torch.autograd.Function):
     """y = act(InstanceNorm(x)) + residual   (models/style_networks.py:163-164,180-182,192); fp32 NCHW or BF16_C8 tensors."""
 
     @staticmethod
-    def forward(ctx, x, residual, relu, eps):
-        if hip.is_c8(x):
-            y, stats = hip.instnorm_forward_c8(x, _channels(x), residual, relu, eps)
+    def forward(ctx, x, residual, relu, eps, x_f16=False):
+        """x_f16: x is an F16_C8 tensor (the producing convolution was asked for PRE_NORM storage)"""
+        if _blocked(x):
+            y, stats = hip.instnorm_forward_c8(x, _channels(x), residual, relu, eps, x_f16)
         else:
             y, stats = hip.instnorm_forward(x, residual, relu, eps)
-        ctx.relu = relu
+        ctx.relu, ctx.x_f16 = relu, x_f16
         ctx.save_for_backward(x, stats)
         return y
 
@@ -410,14 +428,14 @@ class InstanceNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = hip.instnorm_backward_c8(x, _channels(x), dy, stats, ctx.relu) if hip.is_c8(x) else \
+            dx = hip.instnorm_backward_c8(x, _channels(x), dy, stats, ctx.relu, ctx.x_f16) if _blocked(x) else \
                 hip.instnorm_backward(x, dy, stats, ctx.relu)
         dres = dy if ctx.needs_input_grad[1] else None
-        return dx, dres, None, None
+        return dx, dres, None, None, None
 
 
-def instance_norm(x, residual=None, relu=False, eps=1e-5):
-    return InstanceNormFn.apply(x, residual, relu, eps)
+def instance_norm(x, residual=None, relu=False, eps=1e-5, x_f16=False):
+    return InstanceNormFn.apply(x, residual, relu, eps, x_f16)
 
 
 class BatchNormTrainFn(torch.autograd.Function):
@@ -425,10 +443,11 @@ class BatchNormTrainFn(torch.autograd.Function):
     as used by StyleEncoderE2VID, models/style_networks.py:116-121); fp32 NCHW or BF16_C8 tensors."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
-        if hip.is_c8(x):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, x_f16=False):
+        ctx.x_f16 = x_f16
+        if _blocked(x):
             y, stats = hip.batchnorm_train_forward_c8(x, _channels(x), residual, gamma.detach(), beta.detach(), running_mean,
-                                                      running_var, momentum, eps, relu)
+                                                      running_var, momentum, eps, relu, x_f16)
         else:
             y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
                                                    momentum, eps, relu)
@@ -443,9 +462,9 @@ class BatchNormTrainFn(torch.autograd.Function):
         dy = dy.contiguous()
         need_dx, need_dres, need_g, need_b = ctx.needs_input_grad[0:4]
         beta = ctx.beta_ref()
-        if hip.is_c8(x):
+        if _blocked(x):
             C = _channels(x)
-            bwd = lambda *a, **k: hip.batchnorm_train_backward_c8(x, C, *a, **k)  # noqa: E731
+            bwd = lambda *a, **k: hip.batchnorm_train_backward_c8(x, C, *a, x_f16=ctx.x_f16, **k)  # noqa: E731
         else:
             bwd = lambda *a, **k: hip.batchnorm_train_backward(x, *a, **k)  # noqa: E731
         # like the conv weight gradients: add straight into the leaves' .grad (views of the optimiser's flat buffer)
@@ -453,15 +472,15 @@ class BatchNormTrainFn(torch.autograd.Function):
         direct = need_g and need_b and beta is not None and _direct(gamma) and _direct(beta)
         if direct:
             dx, dres = bwd(y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, gamma.grad, beta.grad, accumulate=True)
-            return dx, dres, None, None, None, None, None, None, None
+            return dx, dres, None, None, None, None, None, None, None, None
         dgamma = torch.empty_like(gamma) if (need_g or need_b) else None
         dbeta = torch.empty_like(gamma) if (need_g or need_b) else None
         dx, dres = bwd(y, dy, gamma.detach(), stats, ctx.relu, need_dx, need_dres, dgamma, dbeta)
-        return dx, dres, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None
+        return dx, dres, (dgamma if need_g else None), (dbeta if need_b else None), None, None, None, None, None, None
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1, eps=1e-5):
-    return BatchNormTrainFn.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
+def batch_norm_train(x, gamma, beta, running_mean, running_var, residual=None, relu=False, momentum=0.1, eps=1e-5, x_f16=False):
+    return BatchNormTrainFn.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, x_f16)
 
 
 # ---- losses.  The kernels produce the loss AND its gradient w.r.t. the first argument in one pass, both already scaled by

@@ -19,7 +19,7 @@ EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED = 0, 1
 COMPUTE_FP32, COMPUTE_BF16 = 0, 1
-FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8 = 0, 1, 2
+FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
 
 _default_compute = COMPUTE_FP32
 
@@ -117,10 +117,10 @@ def lib():
             'ess_voxel_grid_temporal': [P, P, P, P, P, I64, I, I, I, I, I, P, P],
             'ess_voxel_normalize': [P, I, I64, I, P, c_size_t, P],
             'ess_from_bf16_c8': [P, P, I, I, I, I, P],
-            'ess_instnorm_forward_c8': [P, P, P, P, I, I, I, F, I, P, c_size_t, P],
-            'ess_instnorm_backward_c8': [P, P, P, P, I, I, I, I, P, c_size_t, P],
-            'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P, c_size_t, P],
-            'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P],
+            'ess_instnorm_forward_c8': [P, P, P, P, I, I, I, F, I, I, P, c_size_t, P],
+            'ess_instnorm_backward_c8': [P, P, P, P, I, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, c_size_t, P],
             'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
             'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
@@ -247,11 +247,12 @@ def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=No
     out_bf: additionally receives `out` in that format (the frozen encoder's staging copies);
     out_fmt FMT_BF16_C8: `out` / `out2` (and `residual`, if any) ARE BF16_C8 tensors, no fp32 tensor is written."""
     sdt = torch.bfloat16 if src_fmt == FMT_BF16_C8 else torch.float32
-    odt = torch.bfloat16 if out_fmt == FMT_BF16_C8 else torch.float32
-    res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else (out_fmt if residual is not None else FMT_F32_NCHW)
+    odt = torch.bfloat16 if out_fmt in (FMT_BF16_C8, FMT_F16_C8) else torch.float32  # (an F16_C8 tensor travels in a bfloat16-typed container: see f16_c8_empty)
+    rdt = torch.bfloat16 if out_fmt in (FMT_BF16_C8, FMT_F16_C8) else torch.float32  # (an F16_C8 output takes a BF16_C8 residual)
+    res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else ((FMT_BF16_C8 if out_fmt == FMT_F16_C8 else out_fmt) if residual is not None else FMT_F32_NCHW)
     desc = spec.desc if (src_fmt, out_fmt, res_fmt) == (FMT_F32_NCHW,) * 3 else spec.desc_fmt(src_fmt, out_fmt, res_fmt)
     _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt),
-                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, odt), ptr(aux0), ptr(aux1),
+                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, rdt), ptr(aux0), ptr(aux1),
                                     ptr(out, odt), ptr(out2, odt), ptr(out_bf, torch.bfloat16), stream()),
            'ess_conv2d_forward')
     return out
@@ -298,6 +299,20 @@ def from_bf16_c8(y, C):
 def is_c8(t):
     """Is `t` a BF16_C8 tensor (bfloat16 [N][C/8][H][W][8])?"""
     return t is not None and t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[-1] == 8
+
+
+def f16_c8_empty(N, C, H, W, device):
+    """Uninitialised F16_C8 tensor (a pre-normalisation convolution output of the bf16 configuration: IEEE half elements in the
+    BF16_C8 layout, read by the norm kernels only).  The container is a BFLOAT16-typed torch tensor on purpose: autograd casts a
+    gradient to the dtype of the tensor it belongs to, and the gradient of a pre-norm tensor is a BF16_C8 tensor -- a float16-typed
+    container would make the engine insert dtype casts.  The format travels as an explicit flag (conv out_fmt, norm x_f16)."""
+    return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+
+
+def f16_c8_to_float(t, C):
+    """fp32 NCHW values of an F16_C8 tensor (tests / diagnostics; plain torch ops)."""
+    N, nb, H, W, _ = t.shape
+    return t.view(torch.float16).float().permute(0, 1, 4, 2, 3).reshape(N, nb * 8, H, W)[:, :C].contiguous()
 
 
 _ws_cache = {}
@@ -373,52 +388,56 @@ def batchnorm_train_backward(x, y, dy, gamma, stats, relu, need_dx=True, need_dr
     return dx, dres
 
 
-# ---- the same norms on BF16_C8 tensors [N, ceil(C/8), H, W, 8] (C = real channel count)
-def instnorm_forward_c8(x, C, residual, relu, eps=1e-5):
+# ---- the same norms on BF16_C8 tensors [N, ceil(C/8), H, W, 8] (C = real channel count); x may be an F16_C8 tensor (is_f16c8)
+def instnorm_forward_c8(x, C, residual, relu, eps=1e-5, x_f16=False):
     N, CB, H, W, _ = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
     L = lib()
+    xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
-    _check(L.ess_instnorm_forward_c8(ptr(x, torch.bfloat16), ptr(residual, torch.bfloat16), ptr(y, torch.bfloat16), ptr(stats), N, C,
-                                     H * W, c_float(eps), int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
+    _check(L.ess_instnorm_forward_c8(ptr(x, xdt), ptr(residual, torch.bfloat16), ptr(y, torch.bfloat16), ptr(stats), N, C,
+                                     H * W, c_float(eps), int(relu), xf, c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
            'ess_instnorm_forward_c8')
     return y, stats
 
 
-def instnorm_backward_c8(x, C, dy, stats, relu):
+def instnorm_backward_c8(x, C, dy, stats, relu, x_f16=False):
     N, CB, H, W, _ = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     L = lib()
+    xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
-    _check(L.ess_instnorm_backward_c8(ptr(x, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(stats), ptr(dx, torch.bfloat16), N, C, H * W,
-                                      int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward_c8')
+    _check(L.ess_instnorm_backward_c8(ptr(x, xdt), ptr(dy, torch.bfloat16), ptr(stats), ptr(dx, torch.bfloat16), N, C, H * W,
+                                      int(relu), xf, c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward_c8')
     return dx
 
 
-def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, x_f16=False):
     N, CB, H, W, _ = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
     L = lib()
+    xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
-    _check(L.ess_batchnorm_train_forward_c8(ptr(x, torch.bfloat16), ptr(residual, torch.bfloat16), ptr(gamma), ptr(beta),
+    _check(L.ess_batchnorm_train_forward_c8(ptr(x, xdt), ptr(residual, torch.bfloat16), ptr(gamma), ptr(beta),
                                             ptr(running_mean), ptr(running_var), c_float(momentum), c_float(eps),
-                                            ptr(y, torch.bfloat16), ptr(stats), N, C, H * W, int(relu), c_void_p(ws.data_ptr()),
+                                            ptr(y, torch.bfloat16), ptr(stats), N, C, H * W, int(relu), xf, c_void_p(ws.data_ptr()),
                                             c_size_t(ws.numel()), stream()), 'ess_batchnorm_train_forward_c8')
     return y, stats
 
 
 def batchnorm_train_backward_c8(x, C, y, dy, gamma, stats, relu, need_dx=True, need_dres=False, dgamma=None, dbeta=None,
-                                accumulate=False):
+                                accumulate=False, x_f16=False):
     N, CB, H, W, _ = x.shape
-    dx = torch.empty_like(x) if need_dx else None
-    dres = torch.empty_like(x) if need_dres else None
+    dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dx else None
+    dres = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dres else None
     L = lib()
+    xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
-    _check(L.ess_batchnorm_train_backward_c8(ptr(x, torch.bfloat16), ptr(y, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(gamma),
+    _check(L.ess_batchnorm_train_backward_c8(ptr(x, xdt), ptr(y, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(gamma),
                                              ptr(stats), ptr(dx, torch.bfloat16), ptr(dres, torch.bfloat16), ptr(dgamma), ptr(dbeta),
-                                             int(accumulate), N, C, H * W, int(relu), c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
+                                             int(accumulate), N, C, H * W, int(relu), xf, c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
                                              stream()), 'ess_batchnorm_train_backward_c8')
     return dx, dres
 

@@ -32,9 +32,10 @@ class ReLUINSConv2d(nn.Module):
     def forward_fused(self, x, skip=None, up=False):
         """conv over cat(nearest_up2(x) if up else x, skip) without materialising either."""
         c = self.model[0]
+        pre = Fn.pre_norm_fmt() if hip.is_c8(x) else None  # (the conv output is a pre-norm tensor: F16_C8 in the bf16 configuration)
         y = Fn.conv2d(x, c.weight, c.bias, c.stride[0], c.padding[0], x1=skip,
-                      mode0=hip.SRC_NEAREST_UP2 if up else hip.SRC_DIRECT)
-        return Fn.instance_norm(y, None, True, self.model[1].eps)
+                      mode0=hip.SRC_NEAREST_UP2 if up else hip.SRC_DIRECT, out_c8=pre)
+        return Fn.instance_norm(y, None, True, self.model[1].eps, x_f16=pre == Fn.PRE_NORM)
 
     def forward(self, x):
         return self.forward_fused(x)
@@ -59,10 +60,11 @@ class INSResBlock(nn.Module):
         c1, c2 = self.model[0], self.model[3]
         # x enters the graph ONCE: conv1 hands it through as the skip operand, so the skip gradient is added inside
         # conv1's data-gradient kernel instead of by a separate elementwise pass (functional.Conv2dFn.forward)
-        y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1)
-        y = Fn.instance_norm(y, None, True, self.model[1].eps)
-        y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1)
-        return Fn.instance_norm(y, skip, False, self.model[4].eps)  # IN(.) + residual in one pass
+        pre = Fn.pre_norm_fmt() if hip.is_c8(x) else None  # (the conv outputs are pre-norm tensors: F16_C8 in the bf16 configuration)
+        y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1, out_c8=pre)
+        y = Fn.instance_norm(y, None, True, self.model[1].eps, x_f16=pre == Fn.PRE_NORM)
+        y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1, out_c8=pre)
+        return Fn.instance_norm(y, skip, False, self.model[4].eps, x_f16=pre == Fn.PRE_NORM)  # IN(.) + residual in one pass
 
 
 class SemSegE2VID(nn.Module):
@@ -161,13 +163,14 @@ class _ConvBN(nn.Module):
         fp32 image)."""
         out_c8 = Fn.c8_mode()
         if bn.training:
+            pre = Fn.pre_norm_fmt()  # (the conv output is read by the BatchNorm kernels only: F16_C8 in the bf16 configuration)
             if passthrough:
                 y, skip = Fn.Conv2dFn.apply(x, None, conv.weight, None, conv.stride[0], conv.padding[0], hip.SRC_DIRECT,
-                                            hip.SRC_DIRECT, True, out_c8)
+                                            hip.SRC_DIRECT, True, pre)
             else:
-                y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], out_c8=out_c8)
+                y = Fn.conv2d(x, conv.weight, None, conv.stride[0], conv.padding[0], out_c8=pre)
             out = Fn.batch_norm_train(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu,
-                                      bn.momentum, bn.eps)
+                                      bn.momentum, bn.eps, x_f16=pre == Fn.PRE_NORM)
             _PENDING_BN_COUNTERS.append(bn.num_batches_tracked)  # incremented together (flush_bn_counters): 1 launch, not 15
             return (out, skip) if passthrough else out
         if passthrough:

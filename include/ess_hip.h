@@ -49,7 +49,9 @@ enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
  * fp32 NCHW output (out_bf16 of ess_conv2d_forward, or ess_to_bf16_c8): bfloat16 [N][ceil(C/8)][H][W][8], i.e. the
  * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv
  * stages it with plain 16-byte copies: 4x fewer cache-line touches and half the bytes of the fp32 NCHW path.      */
-enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1,
+/* ESS_FMT_F16_C8: the BF16_C8 layout with IEEE half elements.  ONLY as a convolution OUTPUT (fmt_out, LINEAR epilogue) that a norm
+ * kernel reads (x of ess_instnorm_* / ess_batchnorm_train_*_c8 with x_f16 = 1): pre-normalisation tensors keep 11 significant bits. */
+enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3,
        ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / ConvGRU hidden states between time steps (recurrent epilogues only) */ };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
@@ -177,17 +179,18 @@ int ess_instnorm_backward(const float* x, const float* dy, const float* stats, f
  * ess_norm_workspace_c8(ceil(C/8)) (BatchNorm) bytes.                                                          */
 size_t ess_norm_workspace_c8(int32_t groups);
 int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C, int32_t hw,
-                            float eps, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+                            float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C, int32_t hw,
-                             int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+                             int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, void* y, float* stats,
-                                   int32_t N, int32_t C, int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes,
-                                   ess_stream_t stream);
+                                   int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace,
+                                   size_t workspace_bytes, ess_stream_t stream);
 int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma, const float* stats,
                                     void* dx, void* d_residual, float* dgamma, float* dbeta, int32_t accumulate, int32_t N,
-                                    int32_t C, int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes,
+                                    int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes,
                                     ess_stream_t stream);
+/* x_f16 = 1: x (the pre-normalisation tensor) is an ESS_FMT_F16_C8 tensor; every other tensor stays BF16_C8.          */
 
 /* BatchNorm2d, training mode (ResNet prefix of StyleEncoderE2VID, models/style_networks.py:116-121):
  * batch statistics, running-stat update with momentum (unbiased var), y = act(bn(x) + residual).

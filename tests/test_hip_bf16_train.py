@@ -50,16 +50,6 @@ def _encoder_outputs(tr, ev, T, C):
     return img_fake.cpu(), {k: v.cpu() for k, v in latent.items()}
 
 
-def _encoder_outputs(tr, ev, T, C):
-    """the frozen event encoder's outputs exactly as event_train_step computes them (deterministic kernels)"""
-    rec = tr.reconstructor
-    rec.last_states_for_each_channel = {'grayscale': None}
-    with torch.no_grad():
-        for i in range(T):
-            img_fake, _, latent = rec.update_reconstruction(ev[:, i * C:(i + 1) * C], need_image=(i == T - 1), lean_state=i < T - 1)
-    return img_fake.cpu(), {k: v.cpu() for k, v in latent.items()}
-
-
 def _rel_l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30)).item()
 

@@ -411,3 +411,53 @@ def test_conv_c8_full_size_against_fp32_form(H, shape):
         assert int(bad.sum()) <= 1e-5 * bad.numel(), f'{int(bad.sum())} of {bad.numel()} elements off by more than a bf16 ulp'
     finally:
         H.set_compute('fp32')
+
+
+@pytest.mark.parametrize('case', [(2, 64, 24, 40), (1, 40, 130, 170), (3, 128, 60, 80)])
+def test_f16_c8_pre_norm_forms(H, case):
+    """ESS_FMT_F16_C8 (round 3): the pre-normalisation convolution outputs of the bf16 configuration are IEEE-half tensors in the
+    BF16_C8 layout -- written by the conv epilogue (fmt_out), read by the norm kernels (x_f16).  (i) the conv's F16_C8 output is the
+    half rounding of its fp32-form output; (ii) InstanceNorm / train-mode BatchNorm forward and backward on an F16_C8 x give
+    bit-identical results to the same kernels on a BF16_C8 x when x holds values both formats represent exactly (small multiples
+    of 1/8): the kernels differ in the unpacking only."""
+    N, C, Hh, Ww = case
+    H.set_compute('bf16')
+    try:
+        dev = torch.device('cuda')
+        g = torch.Generator(device='cuda').manual_seed(3 + C)
+        # (i) convolution output
+        x = torch.randn(N, C, Hh, Ww, device=dev, generator=g).to(torch.bfloat16).float()
+        w = torch.randn(C, C, 3, 3, device=dev, generator=g) / math.sqrt(9 * C)
+        b = torch.randn(C, device=dev, generator=g)
+        spec = H.conv_spec(N, Hh, Ww, C, 0, C, 3, 1, 1)
+        pw, pb = H.pack_weights(spec, w), H.pack_rows(spec, b)
+        o32 = torch.empty(N, C, Hh, Ww, device=dev)
+        H.conv_forward(spec, x, None, pw, None, pb, out=o32)
+        o16 = H.f16_c8_empty(N, C, Hh, Ww, dev)
+        H.conv_forward(spec, H.to_bf16_c8(x), None, pw, None, pb, out=o16, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F16_C8)
+        got, ref = H.f16_c8_to_float(o16, C), o32.half().float()
+        bad = (got - ref).abs() > 2.0 ** -10 * ref.abs().clamp(min=2.0 ** -6)  # one half ulp-step where the fp32 sums differ in order
+        assert int(bad.sum()) <= 1e-5 * bad.numel()
+        # (ii) norm kernels: exactly representable x
+        xe = torch.randint(-64, 65, (N, C, Hh, Ww), device=dev, generator=g).float() / 8
+        xb = H.to_bf16_c8(xe)
+        xh = H.f16_c8_empty(N, C, Hh, Ww, dev)
+        xh.view(torch.float16).copy_(xb.float().half())
+        res = H.to_bf16_c8(torch.randn(N, C, Hh, Ww, device=dev, generator=g))
+        dy = H.to_bf16_c8(torch.randn(N, C, Hh, Ww, device=dev, generator=g))
+        for relu in (True, False):
+            yb, sb = H.instnorm_forward_c8(xb, C, res, relu)
+            yh, sh = H.instnorm_forward_c8(xh, C, res, relu, x_f16=True)
+            assert torch.equal(yb, yh) and torch.equal(sb, sh)
+            assert torch.equal(H.instnorm_backward_c8(xb, C, dy, sb, relu), H.instnorm_backward_c8(xh, C, dy, sh, relu, x_f16=True))
+            gam, bet = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
+            outs = []
+            for xx, f in ((xb, False), (xh, True)):
+                rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+                y, st = H.batchnorm_train_forward_c8(xx, C, res, gam, bet, rm, rv, 0.1, 1e-5, relu, x_f16=f)
+                dg, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+                dx, dr = H.batchnorm_train_backward_c8(xx, C, y, dy, gam, st, relu, True, True, dg, dbt, x_f16=f)
+                outs.append((y, st, rm, rv, dx, dr, dg, dbt))
+            assert all(torch.equal(a, b2) for a, b2 in zip(*outs))
+    finally:
+        H.set_compute('fp32')
