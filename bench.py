@@ -325,12 +325,7 @@ def main():
     hip.lib()
     hip.set_compute(args.compute)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('ESS_DIST_BACKEND', 'nccl')  # 'nccl' = RCCL over xGMI
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=device)
-        else:
-            dist.init_process_group(backend=backend)
+        D.init_for_device(device)  # backend 'nccl' = RCCL over xGMI, bound to this rank's GPU (ESS_DIST_BACKEND=gloo overrides)
 
     torch.manual_seed(6)
     st = synthetic_settings(args.trainer, 'DSEC_events', (args.height, args.width), args.classes, args.batch, args.T, args.C,

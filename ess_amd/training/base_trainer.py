@@ -109,10 +109,22 @@ class BaseTrainer(object):
             # (under a process group: thread-local error mode -- the collective backend's watchdog thread queries events while this
             # thread captures, which the default global mode treats as a capture violation)
             mode = {'capture_error_mode': 'thread_local'} if dp else {}
+            # data parallel, a trainer with two optimisers whose gradients complete one after the other (the UDA step: image encoder,
+            # then decoder): THREE graphs -- [forwards + image-encoder backward] | [decoder task backward] | [optimisers] -- so that the
+            # all-reduce of the first flat gradient, issued between the first two replays, runs on the collective's stream UNDER the
+            # second replay (9.5 M floats are ~0.1 ms of xGMI wire time; the point is that nothing of it is exposed)
+            split = dp and hasattr(self, '_finish_deferred_backward') and os.environ.get('ESS_DP_SPLIT_GRAPH', '1') != '0'
+            self._g_mid = torch.cuda.CUDAGraph() if split else None
             with torch.cuda.graph(self._g, **mode):
-                losses, outputs, final = self._train_step_eager(static_batch, optimise=not dp)
+                if split:
+                    losses, outputs, final = self._train_step_eager(static_batch, optimise=False, defer_task_backward=True)
+                else:
+                    losses, outputs, final = self._train_step_eager(static_batch, optimise=not dp)
                 self._g_keys = sorted(losses)
                 self._g_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self._g_keys] + [final.detach().float().reshape(())])
+            if split:
+                with torch.cuda.graph(self._g_mid, pool=self._g.pool(), **mode):
+                    self._finish_deferred_backward()
             if dp:
                 with torch.cuda.graph(self._g_tail, pool=self._g.pool(), **mode):
                     for o in opts:
@@ -185,7 +197,13 @@ class BaseTrainer(object):
                 # gloo stages device tensors through the host on its own threads: left to wait for a busy stream itself it took
                 # 0.5-1 s per step (two ranks on one GPU); RCCL collectives are stream-ordered and need no host synchronisation
                 torch.cuda.current_stream().synchronize()
-            for o in opts:  # (a few collectives of <= 8 MB each, all in flight together, like the eager step's buckets)
+            mid = getattr(self, '_g_mid', None)
+            for i, o in enumerate(opts):  # (a few collectives of <= 8 MB each, all in flight together, like the eager step's buckets)
+                if mid is not None and i == len(opts) - 1:
+                    # the first optimiser's gradients (image encoder) are on the wire: the decoder's task backward replays under them
+                    mid.replay()
+                    if not D.stream_ordered_collectives():
+                        torch.cuda.current_stream().synchronize()
                 for part in o.flat_grad.split(1 << 21):
                     self.grad_reducer.launch(part)
             self.grad_reducer.wait()

@@ -24,6 +24,22 @@ def init_from_env(backend=None):
     return world
 
 
+def init_for_device(device, backend=None):
+    """The process group of one rank bound to `device` (bench.py, one process per GPU).  'nccl' (= RCCL over xGMI on ROCm) gets
+    device_id so that the communicator is created eagerly on THIS rank's GPU (no lazy init inside the first collective, no
+    guessing of the device from the rank); ESS_DIST_BACKEND overrides the backend ('gloo' on a box without RCCL).
+    HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment for multi-process GPU work on this driver (dmabuf IPC only)."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend is None:
+        backend = os.environ.get('ESS_DIST_BACKEND', 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group(backend='nccl', device_id=device)
+    else:
+        dist.init_process_group(backend=backend)
+    return backend
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

@@ -121,8 +121,11 @@ class ESSModel(base_trainer.BaseTrainer):
             return self._replay_step(input_batch)
         return self._train_step_eager(input_batch)
 
-    def _train_step_eager(self, input_batch, optimise=True):
-        """optimise=False (recording the data-parallel step: BaseTrainer.enable_step_graph): stop behind the backward passes."""
+    def _train_step_eager(self, input_batch, optimise=True, defer_task_backward=False):
+        """optimise=False (recording the data-parallel step: BaseTrainer.enable_step_graph): stop behind the backward passes.
+        defer_task_backward (with optimise=False): stop behind the backward of the image-encoder terms -- the image encoder's
+        gradients are complete -- and leave the decoder's task backward to `_finish_deferred_backward()`, which the captured
+        data-parallel step records as a graph of its own so that the first all-reduce runs under its replay."""
         losses, outputs = {}, {}
         opt_front, opt_back = self.optimizers_dict['optimizer_front_sensor_a'], self.optimizers_dict['optimizer_back']
         opt_back.zero_grad()
@@ -151,7 +154,12 @@ class ESSModel(base_trainer.BaseTrainer):
             enc = self.encode_events(input_batch)
 
         e_loss, t_loss, event_losses, event_outputs = self.event_train_step(input_batch, enc)
-        if fork:
+        if defer_task_backward and not optimise:
+            Fn.unit_backward(self._e_terms)  # image encoder only (the decoder was frozen while this graph was recorded)
+            if fork:  # (the weight-gradient kernels add into .grad themselves: no AccumulateGrad leaf tells the engine to join B)
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+            self._deferred_fork = fork
+        elif fork:
             # one backward over both sets of terms: the engine enqueues the image-encoder chain (recorded on B) and the decoder
             # chain (recorded on A) on their own streams and joins them at the end; they write disjoint gradient buffers
             Fn.unit_backward(self._e_terms + self._t_terms)
@@ -176,6 +184,12 @@ class ESSModel(base_trainer.BaseTrainer):
         opt_back.step()
         opt_front.step()
         return losses, outputs, final_loss
+
+    def _finish_deferred_backward(self):
+        """Second half of a step recorded with defer_task_backward: the decoder's task backward (decoder gradients only)."""
+        Fn.unit_backward(self._t_terms)
+        if getattr(self, '_deferred_fork', False):
+            torch.cuda.current_stream().wait_stream(self._side_stream)
 
     def img_train_step(self, batch):
         s = self.settings

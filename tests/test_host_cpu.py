@@ -404,3 +404,37 @@ def test_header_enums_match_the_binding():
     assert {'FMT_F32_NCHW', 'FMT_BF16_C8', 'FMT_F32_C8', 'EPI_LSTM', 'SRC_ZERO_UP2', 'ACT_SUMPOOL2'} <= set(mirrored)
     wrong = {n: (v, getattr(hip, n)) for n, v in mirrored.items() if getattr(hip, n) != v}
     assert not wrong, wrong
+
+
+def test_rccl_process_group_construction_mocked(monkeypatch):
+    """No multi-GPU box is available to the build: the RCCL branch of the data-parallel start-up (bench.py --gpus N ->
+    distributed.init_for_device) is at least CONSTRUCTED here against a recording stand-in for torch.distributed -- backend
+    'nccl', device_id = this rank's device, rendezvous address and the dmabuf-IPC switch in the environment -- and the gradient
+    reducer issues averaged asynchronous all-reduces on that backend (ReduceOp.AVG: no post-division kernel)."""
+    import torch.distributed as dist
+    from ess_amd.training import distributed as D
+    calls = {}
+    monkeypatch.delenv('ESS_DIST_BACKEND', raising=False)
+    monkeypatch.delenv('MASTER_ADDR', raising=False)
+    monkeypatch.setattr(dist, 'init_process_group', lambda **kw: calls.update(init=kw))
+    dev = torch.device('cuda', 3)
+    assert D.init_for_device(dev) == 'nccl'
+    assert calls['init'] == {'backend': 'nccl', 'device_id': dev}
+    assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    monkeypatch.setenv('ESS_DIST_BACKEND', 'gloo')
+    assert D.init_for_device(dev) == 'gloo' and calls['init'] == {'backend': 'gloo'}
+    # reducer on the (mocked) nccl backend
+    class _Work:
+        def wait(self):
+            calls['waited'] = calls.get('waited', 0) + 1
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a: 8)
+    monkeypatch.setattr(dist, 'get_backend', lambda *a: 'nccl')
+    monkeypatch.setattr(dist, 'all_reduce', lambda t, op=None, async_op=False: (calls.setdefault('ops', []).append((t.numel(), op, async_op)), _Work())[1])
+    red = D.GradAllReducer()
+    g = torch.ones(1000)
+    red.launch(g)
+    red.wait()
+    assert calls['ops'] == [(1000, dist.ReduceOp.AVG, True)] and calls['waited'] == 1
+    assert torch.equal(g, torch.ones(1000))  # AVG on the wire: nothing divided on the host side
+    assert D.stream_ordered_collectives()
