@@ -15,6 +15,7 @@ from .utils.inference_utils import CropParameters, EventPreprocessor
 
 
 _LEAN = os.environ.get('ESS_LEAN', '1') != '0'  # diagnostic switch: materialise every fp32 state
+_T_PREFIX = os.environ.get('ESS_T_PREFIX', '0') == '1'  # time-batched head + first conv (measured: see DESIGN.md section 7c)
 
 class ImageReconstructor:
     def __init__(self, model, height, width, num_bins, device, options, augmentation=False, standardization=False):
@@ -48,10 +49,13 @@ class ImageReconstructor:
                 events = events.contiguous()
             return self._step(events, need_image, lean_state)
 
-    def _step(self, events, need_image, lean_state):
+    def _step(self, events, need_image, lean_state, prefix=None):
         """One model step on a normalised, padded, contiguous slice (under no_grad)."""
         if need_image:
             out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'])
+        elif prefix is not None:
+            out, states, latent = self.model(None, self.last_states_for_each_channel['grayscale'], encoder_only=True, lean=True,
+                                             prefix=prefix)
         else:
             # lean_state: this step only advances the recurrent state (callers: every time step but the last of a
             # training / validation sequence); latent is then None and the fp32 hidden states are not materialised
@@ -66,7 +70,7 @@ class ImageReconstructor:
             out = flat.view(b, 1, h, w)
         return out, states, latent
 
-    def update_reconstruction_sequence(self, event_tensor, T, need_image=True):
+    def update_reconstruction_sequence(self, event_tensor, T, need_image=True, time_batched_prefix=None):
         """The trainers' hot loop as one call (reference training/ess_trainer.py:277-280, ess_supervised_trainer.py:128-130):
             for i in range(T): out, states, latent = update_reconstruction(event_tensor[:, i*C:(i+1)*C])
         -> (out, states, latent) of the LAST step (out is None unless need_image).  Same per-slice arithmetic; what changes is the
@@ -83,6 +87,13 @@ class ImageReconstructor:
             batched = self.crop.is_identity and not pre.flip and len(pre.hot_pixel_locations) == 0 and not pre.no_normalize and \
                 events.is_contiguous() and events.dtype == torch.float32
             slices = hip.event_normalize_slices(events, T) if batched else None
+            # time-batched prefix (time_batched_prefix=True / ESS_T_PREFIX=1; off by default -- measured +-0 at T = 5 and T = 20, and
+            # it keeps (T-1) B head outputs alive: 3 GB at T = 20): head conv and the first encoder's conv depend on the slice only (reference
+            # unet.py:131-139), so the T-1 lean steps' worth of them can run as ONE launch each over [(T-1) B, C, H, W]
+            prefix = None
+            if slices is not None and T > 1 and (_T_PREFIX if time_batched_prefix is None else time_batched_prefix) and _LEAN and not self.no_recurrent and hasattr(self.model, 'forward_prefix'):
+                B = events.shape[0]
+                prefix = self.model.forward_prefix(slices[:T - 1].reshape((T - 1) * B, C, events.shape[2], events.shape[3]))
             res = (None, None, None)
             for i in range(T):
                 last = i == T - 1
@@ -92,5 +103,9 @@ class ImageReconstructor:
                     ev = self.crop.pad(pre(events[:, i * C:(i + 1) * C]))
                     if not ev.is_contiguous():
                         ev = ev.contiguous()
-                res = self._step(ev, need_image and last, not last)
+                pf = None
+                if prefix is not None and not last:
+                    B = events.shape[0]
+                    pf = (prefix[0][i * B:(i + 1) * B], prefix[1][i * B:(i + 1) * B])
+                res = self._step(ev, need_image and last, not last, prefix=pf)
             return res

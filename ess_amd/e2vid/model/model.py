@@ -46,9 +46,13 @@ class E2VIDRecurrent(BaseE2VID):
         super().__init__(config)
         self.unetrecurrent = UNetRecurrent(recurrent_block_type=self.recurrent_block_type, **self._unet_kwargs())
 
-    def forward(self, event_tensor, prev_states, encoder_only=False, lean=False):
-        """-> (img N x 1 x H x W, states per encoder, latent {1,2,4,8}); encoder_only / lean: see UNetRecurrent.forward."""
-        return self.unetrecurrent.forward(event_tensor, prev_states, encoder_only=encoder_only, lean=lean)
+    def forward(self, event_tensor, prev_states, encoder_only=False, lean=False, prefix=None):
+        """-> (img N x 1 x H x W, states per encoder, latent {1,2,4,8}); encoder_only / lean / prefix: see UNetRecurrent.forward."""
+        return self.unetrecurrent.forward(event_tensor, prev_states, encoder_only=encoder_only, lean=lean, prefix=prefix)
+
+    def forward_prefix(self, event_tensors):
+        """head + first encoder conv for many time slices at once (UNetRecurrent.forward_prefix)."""
+        return self.unetrecurrent.forward_prefix(event_tensors)
 
 
 class E2VIDDecoder(BaseE2VID):

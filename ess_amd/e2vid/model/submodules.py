@@ -37,6 +37,15 @@ def _mark_fp32_unwritten(t):
     t.ess_fp32_unwritten = True
 
 
+def _c8_placeholder(N, C, H, W, device, c8):
+    """The fp32 NCHW tensor of an activation that exists as a BF16_C8 copy only: a stride-0 view of ONE element (no memory behind
+    it), carrying shape, device and the copy; `_fp32` refuses its values."""
+    t = torch.empty((), dtype=torch.float32, device=device).expand(N, C, H, W)
+    _attach_c8(t, c8)
+    _mark_fp32_unwritten(t)
+    return t
+
+
 def _fp32(t):
     """The fp32 tensor itself -- refused when only the BF16_C8 copy of it exists."""
     if getattr(t, 'ess_fp32_unwritten', False):
@@ -506,11 +515,16 @@ class RecurrentConvLayer(nn.Module):
         self.conv = ConvLayer(in_channels, out_channels, kernel_size, stride, padding, activation, norm)
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
 
-    def forward(self, x, prev_state, lean=False):
+    def forward(self, x, prev_state, lean=False, x_conv=None):
+        """x_conv: the conv output computed ahead of time (time-batched prefix, UNetRecurrent.forward_prefix): a placeholder
+        carrying its BF16_C8 copy; `x` is then ignored."""
         # the conv output never leaves this module: in bf16 arithmetic the recurrent block stages it from the BF16_C8 copy
         # (a 64 | 128 | 256-channel tensor, always a whole number of 8-channel blocks), so its fp32 form is not written
-        x = self.conv(x, want_c8=True, c8_only=self.conv.conv2d.out_channels % 8 == 0 and hip.c8_stageable(3, 1, 1) and
-                      self._prev_has_c8(prev_state))
+        if x_conv is not None:
+            x = x_conv
+        else:
+            x = self.conv(x, want_c8=True, c8_only=self.conv.conv2d.out_channels % 8 == 0 and hip.c8_stageable(3, 1, 1) and
+                          self._prev_has_c8(prev_state))
         state = self.recurrent_block(x, prev_state, lean=lean)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state

@@ -126,7 +126,22 @@ class UNetRecurrent(BaseUNet):
         self.build_decoders()
         self.build_prediction_layer()
 
-    def forward(self, x, prev_states, encoder_only=False, lean=False):
+    def forward_prefix(self, x_all):
+        """The part of a time step that depends on the step's voxel grid only -- head conv and the first encoder's stride-2 conv
+        (reference unet.py:131-139: `x = self.head(x)`, `encoder.conv`) -- for MANY time slices at once: x_all = [S*B, C, H, W]
+        (S normalised slices stacked along the batch axis) -> (head copies, conv copies) as BF16_C8 tensors [S*B, ...], or None when
+        the lean BF16_C8 path is not available (exact-fp32 arithmetic, diagnostic switches).  forward(..., prefix=(head_t, conv_t))
+        then starts at the first recurrent block.  Two launches for S slices instead of 2 S."""
+        from .submodules import _c8_of
+        ok = hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2) and \
+            self.encoder_output_sizes[0] % 8 == 0 and self.base_num_channels % 8 == 0
+        if not ok:
+            return None
+        h = self.head(x_all, want_c8=True, c8_only=True)
+        x0 = self.encoders[0].conv(h, want_c8=True, c8_only=True)
+        return _c8_of(h), _c8_of(x0)
+
+    def forward(self, x, prev_states, encoder_only=False, lean=False, prefix=None):
         """lean (needs encoder_only; effective in bf16 arithmetic): the step's only purpose is the
         recurrent state for the NEXT step, so the fp32 forms of the head output and of the hidden states are not written
         (their BF16_C8 copies and the fp32 cell states are); `latent` is None.  Result-identical for the steps t < T-1 of
@@ -135,13 +150,23 @@ class UNetRecurrent(BaseUNet):
             raise ValueError('lean needs encoder_only')
         # every consumer of the unwritten fp32 tensors must be able to stage their BF16_C8 copies (diagnostic switches may forbid it)
         lean = lean and hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2)
-        x = self.head(x, want_c8=True, c8_only=lean)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic)
+        x_conv0 = None
+        if prefix is not None:  # (lean steps only: head and first conv were computed for all slices at once, forward_prefix)
+            if not lean:
+                raise ValueError('prefix needs a lean step')
+            from .submodules import _c8_placeholder
+            h8, c8 = prefix
+            N, H, W = h8.shape[0], h8.shape[2], h8.shape[3]
+            x = _c8_placeholder(N, self.base_num_channels, H, W, h8.device, h8)
+            x_conv0 = _c8_placeholder(N, self.encoder_output_sizes[0], c8.shape[2], c8.shape[3], c8.device, c8)
+        else:
+            x = self.head(x, want_c8=True, c8_only=lean)  # the first encoder conv stages from the BF16_C8 copy (bf16 arithmetic)
         head = x
         if prev_states is None:
             prev_states = [None] * self.num_encoders
         blocks, states = [], []
         for i, encoder in enumerate(self.encoders):
-            x, state = encoder(x, prev_states[i], lean=lean)
+            x, state = encoder(x, prev_states[i], lean=lean, x_conv=x_conv0 if i == 0 else None)
             blocks.append(x)
             states.append(state)
         if lean:

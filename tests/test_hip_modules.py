@@ -677,5 +677,11 @@ def test_sequence_call_matches_per_slice_loop(shape):
                 assert relerr(lat1[k], lat0[k]) < 1e-5, k
             for (h0, c0), (h1, c1) in zip(st0, st1):
                 assert relerr(h1, h0) < 1e-5 and relerr(c1, c0) < 1e-5
+            # time-batched prefix (head conv + first encoder conv of the T-1 lean steps as one launch each): the same per-sample
+            # arithmetic, bit-identical results
+            rec.last_states_for_each_channel = {'grayscale': None}
+            img2, st2, lat2 = rec.update_reconstruction_sequence(ev, T, time_batched_prefix=True)
+            assert torch.equal(img2, img1) and all(torch.equal(lat2[k], lat1[k]) for k in (1, 2, 4, 8))
+            assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(st2, st1))
         finally:
             hip.set_compute('fp32')
