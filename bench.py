@@ -107,9 +107,9 @@ def decoder_conv3x3_layers(args):
 
 def _traffic_from_profiles(tag):
     """HBM bytes per launch set from the PMC passes of tools/pmc_traffic.py (rocprofv3 --pmc, separate passes, the guide's gfx950
-    unit corrections), committed as profiles/r2_traffic.json; None when this shape / kernel was not profiled."""
+    unit corrections), committed as profiles/r3_traffic.json (builder-side PMC passes, not re-measured in this run); None when this shape / kernel was not profiled."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r3_traffic.json')) as f:
             t = json.load(f).get(tag)
     except (OSError, ValueError):
         return None

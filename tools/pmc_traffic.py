@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM traffic of the dominant kernels from hardware counters -> profiles/r2_traffic.json (read by bench.py's `roofline.traffic`).
+"""HBM traffic of the dominant kernels from hardware counters -> profiles/r3_traffic.json (read by bench.py's `roofline.traffic`).
 
 Run ON THE GPU BOX from the repo root:   python tools/pmc_traffic.py [outdir=gpurun_out/pmc_traffic]
 Recipe (MI355X_MICROARCH.md, section HBM / rocprofv3): two SEPARATE rocprofv3 --pmc passes over tools/traffic_probe.py
@@ -56,13 +56,13 @@ for p in plan:
                             'algorithmic_bytes': p['algorithmic_bytes']})
 res = {'_comment': 'HBM-side bytes per launch set from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/traffic_probe.py '
                    '(tools/pmc_traffic.py; traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction of MI355X_MICROARCH.md). '
-                   'conv3x3 = the 16 plain 3x3 convolutions of one decoder forward, gate = the three ConvLSTM levels of one time step.'}
+                   'conv3x3 = the 16 plain 3x3 convolutions of one decoder forward, gate = the three ConvLSTM levels of one time step, gru = the ConvGRU kernel pair on the three levels.'}
 for gname, gd in groups.items():
     res[f'{gname}/bf16/8/480x640'] = {'bytes': round(gd['bytes']), 'algorithmic_bytes': round(gd['algorithmic_bytes']),
                                       'ratio': round(gd['bytes'] / gd['algorithmic_bytes'], 3), 'layers': gd['layers'],
                                       'source': 'tools/pmc_traffic.py (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, separate passes)'}
-path = os.path.join(ROOT, 'gpurun_out', 'r2_traffic.json')
+path = os.path.join(ROOT, 'gpurun_out', 'r3_traffic.json')
 with open(path, 'w') as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))
-print('wrote', path, '(copy to profiles/r2_traffic.json)')
+print('wrote', path, '(copy to profiles/r3_traffic.json)')

@@ -2,7 +2,8 @@
 """Launch set for the HBM-traffic PMC passes (tools/pmc_traffic.py): at the bench shape (B=8, 480x640, bf16 configuration)
   * the 7 distinct plain 3x3 convolutions of one decoder forward, BF16_C8 in / out, exactly as the product issues them
     (REPS launches each, in the order of bench.decoder_conv3x3_layers);
-  * the fused ConvLSTM step on the three encoder levels (BF16_C8 sources, BF16_C8 copy of h').
+  * the fused ConvLSTM step on the three encoder levels (the product's lean launch: BF16_C8 sources, channel-blocked fp32 cell,
+    BF16_C8 copy of h') and the ConvGRU kernel pair in the same form.
 Prints the launch plan as JSON on the last line: pmc_traffic.py maps the profiler's dispatch sequence back onto it."""
 import json
 import os
@@ -51,14 +52,45 @@ for lvl, hid in enumerate((64, 128, 256)):
     w = (torch.randn(4 * hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(dev)
     pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(4 * hid, generator=g).to(dev))
     x, h = act(hid, H, W), act(hid, H, W)
-    c = torch.randn(B, hid, H, W, generator=g).to(dev)
-    ho, co, hb = torch.empty_like(c), torch.empty_like(c), hip.bf16_c8_empty(B, hid, H, W, dev)
+    # the product's lean launch (ConvLSTM.forward, steps t < T-1): channel-blocked fp32 cell in / out, BF16_C8 copy of h' only
+    c = torch.randn(B, hid, H, W, generator=g).to(dev).view(B, hid // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    co, hb = hip.f32_c8_empty(B, hid, H, W, dev), hip.bf16_c8_empty(B, hid, H, W, dev)
     torch.cuda.synchronize()
     for _ in range(REPS):
-        hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=ho, out2=co, out_bf=hb, src_fmt=hip.FMT_BF16_C8)
+        hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_bf=hb, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_F32_C8,
+                         aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     n = B * hid * H * W
     plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS,
-                 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 4 + 2) * n + 2 * 9 * 2 * hid * 4 * hid,
+                 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 4 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)})
+# ---- ConvGRU pair (lean launches of ConvGRU.forward): (update, reset) kernel, then candidate kernel
+for lvl, hid in enumerate((64, 128, 256)):
+    H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
+    s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
+    s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+    wu, wr, wo = [(torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(dev) for _ in range(3)]
+    bu, br, bo = [torch.randn(hid, generator=g).to(dev) for _ in range(3)]
+    pw1, pw2 = hip.pack_weights(s1, wu, wr), hip.pack_weights(s2, wo)
+    pb1, pb2 = hip.pack_rows(s1, bu, br), hip.pack_rows(s2, bo)
+    x8, h8 = act(hid, H, W), act(hid, H, W)
+    hb = torch.randn(B, hid // 8, H, W, 8, generator=g).to(dev)
+    u, hn = hip.f32_c8_empty(B, hid, H, W, dev), hip.f32_c8_empty(B, hid, H, W, dev)
+    rh8, hn8 = hip.bf16_c8_empty(B, hid, H, W, dev), hip.bf16_c8_empty(B, hid, H, W, dev)
+    n = B * hid * H * W
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        hip.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_F32_C8,
+                         aux_fmt=hip.FMT_F32_C8)
+    torch.cuda.synchronize()
+    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} update+reset', 'count': 1,
+                 'reps': REPS, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
+                 'flops': 2.0 * B * H * W * 9 * (2 * hid) * (2 * hid)})
+    for _ in range(REPS):
+        hip.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=hip.FMT_BF16_C8,
+                         out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
+    torch.cuda.synchronize()
+    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} candidate', 'count': 1,
+                 'reps': REPS, 'algorithmic_bytes': 2 * 2 * n + (4 + 4) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
+                 'flops': 2.0 * B * H * W * 9 * (2 * hid) * hid})
 print('PLAN ' + json.dumps(plan))
