@@ -5,7 +5,12 @@ __device__ unsigned long long g_cv_trace[2048 * 8 * 48];
 #define ESS_EPI_STAMP(i_) ESS_CT(i_)
 // wall clock (100 MHz, the same on every CU -- s_memtime is not): slot 46 at workgroup start, slot 43 at its end (non-LSTM kernels)
 #define ESS_CW(i_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = wall_clock64(); } while (0)
+// barrier with wait accounting: the cycles this wave spends inside the barrier are summed into `acc_`
+#define ESS_SYNC_ACC(acc_) do { const unsigned long long t0_ = __builtin_readcyclecounter(); __syncthreads(); acc_ += __builtin_readcyclecounter() - t0_; } while (0)
+#define ESS_CT_VAL(i_, v_) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) g_cv_trace[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 48 + (i_)] = (v_); } while (0)
 #else
+#define ESS_SYNC_ACC(acc_) __syncthreads()
+#define ESS_CT_VAL(i_, v_) do { } while (0)
 #define ESS_CW(i_) do { } while (0)
 #define ESS_CT(i_) do { } while (0)
 #endif
@@ -145,6 +150,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
     };
     const int nch = a.n_chunks;
+    unsigned long long bar_acc = 0, wait_acc = 0, commit_acc = 0;
+    (void)bar_acc; (void)wait_acc; (void)commit_acc;
     {
       ESS_CT(1);
       load_chunk(0, sa);
@@ -155,13 +162,27 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
       for (int ch = 0; ch < nch; ++ch) {
         if (ch < 40) ESS_CT(3 + ch);
         if (ch + 1 < nch) {
+#ifdef ESS_CV_TRACE
+          const unsigned long long tc0 = __builtin_readcyclecounter();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long tc1 = __builtin_readcyclecounter();
+          wait_acc += tc1 - tc0;
+#endif
           commit(ch + 1, (ch + 1) & 1, sa);
+#ifdef ESS_CV_TRACE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long tc2 = __builtin_readcyclecounter();
+          commit_acc += tc2 - tc1;
+#endif
           if (ch + 2 < nch) load_chunk(ch + 2, sa);
         }
         if (ch == nch - 1) ESS_CT(44);
-        __syncthreads();
+        ESS_SYNC_ACC(bar_acc);
       }
     }
+    ESS_CT_VAL(42, bar_acc);
+    ESS_CT_VAL(41, wait_acc);
+    ESS_CT_VAL(40, commit_acc);
     ESS_CT(47);
     }  // tile loop
     return;
@@ -271,6 +292,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   }
+  unsigned long long cbar_acc = 0;
+  (void)cbar_acc;
   ESS_CT(1);
   __syncthreads();  // stage 0 is ready
   ESS_CT(2);
@@ -337,8 +360,9 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #undef ESS_WAIT
 #undef ESS_MMA
     if (ch == a.n_chunks - 1) ESS_CT(44);
-    __syncthreads();
+    ESS_SYNC_ACC(cbar_acc);
   }
+  ESS_CT_VAL(42, cbar_acc);
   ESS_CT(45);
   __builtin_amdgcn_s_setprio(0);
 #ifdef ESS_ABLATE
