@@ -426,6 +426,28 @@ extern "C" int ess_event_normalize(const float* x, float* y, int64_t n, void* wo
 }
 
 
+// sum of up to 16 device scalars (the weighted loss terms of a train step -> the step's reported total) in one launch
+namespace {
+struct ScalarPtrs { const float* p[16]; int n; };
+__global__ void sum_scalars_kernel(const ScalarPtrs q, float* out) {
+  float s = 0.f;
+  for (int i = 0; i < q.n; ++i) s += *q.p[i];  // (fixed order: the order the trainer lists the terms in)
+  *out = s;
+}
+}  // namespace
+
+extern "C" int ess_sum_scalars(const float* const* terms, int32_t n, float* out, ess_stream_t stream) {
+  ESS_CHECK_ARG(terms && out && n > 0 && n <= 16, "sum_scalars: 1..16 terms");
+  ScalarPtrs q{};
+  q.n = n;
+  for (int i = 0; i < n; ++i) {
+    ESS_CHECK_ARG(terms[i] != nullptr, "sum_scalars: null term");
+    q.p[i] = terms[i];
+  }
+  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, q, out);
+  return ess_launch_status("sum_scalars");
+}
+
 extern "C" int ess_event_normalize_slices(const float* x, float* y, int32_t B, int32_t T, int64_t chunk, void* workspace,
                                           ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && workspace && B > 0 && T > 0 && T <= 65535 && chunk > 0, "event_normalize_slices: bad arguments");

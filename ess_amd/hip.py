@@ -44,7 +44,7 @@ EXPORTS = [
     'ess_voxel_grid_trilinear', 'ess_voxel_grid_trilinear_workspace', 'ess_voxel_grid_temporal', 'ess_voxel_normalize_workspace', 'ess_voxel_normalize',
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
-    'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices',
+    'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices', 'ess_sum_scalars',
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
             'ess_sumpool2x2': [P, P, I, I, I, I, P],
             'ess_add': [P, P, P, I64, P],
             'ess_add_bf16': [P, P, P, P, I64, P],
+            'ess_sum_scalars': [P, I, P, P],
             'ess_event_normalize': [P, P, I64, P, P],
             'ess_event_normalize_slices': [P, P, I, I, I64, P, P],
             'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, P],
@@ -491,6 +492,15 @@ def add_bf16(a, b, c=None, out=None):
         out = torch.empty_like(a)
     bf = torch.bfloat16
     _check(lib().ess_add_bf16(ptr(a, bf), ptr(b, bf), ptr(c, bf), ptr(out, bf), a.numel() // 8, stream()), 'ess_add_bf16')
+    return out
+
+
+def sum_scalars(terms):
+    """Sum of 0-dim fp32 device tensors (<= 16), in the order given, as one launch."""
+    terms = [t.detach() for t in terms]
+    out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+    arr = (c_void_p * len(terms))(*[ptr(t).value for t in terms])
+    _check(lib().ess_sum_scalars(arr, len(terms), ptr(out), stream()), 'ess_sum_scalars')
     return out
 
 

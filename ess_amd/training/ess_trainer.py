@@ -174,7 +174,7 @@ class ESSModel(base_trainer.BaseTrainer):
             Fn.unit_backward(self._t_terms)  # decoder only
             if overlap:
                 self.grad_reducer.flush()
-        final_loss = final_loss + e_loss.detach() + t_loss.detach()
+        final_loss = hip.sum_scalars([final_loss, e_loss, t_loss])  # (one library launch: the reference adds with one torch op per term)
         losses.update(event_losses)
         outputs.update(event_outputs)
 
@@ -235,7 +235,6 @@ class ESSModel(base_trainer.BaseTrainer):
             lat_l1, dec_in[k] = Fn.fork(content_second_sensor[k])
             li = self.cycle_content_loss(lat_l1, content_first_sensor[k], weight=s.weight_cycle_loss)
             terms.append(li)
-            g_loss = g_loss + li
             losses['cycle_latent_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
         task_backend = self.models_dict['back_end']
         pred_second_sensor = task_backend(dec_in)
@@ -246,12 +245,11 @@ class ESSModel(base_trainer.BaseTrainer):
         losses['cycle_pred_1x_' + cycle_name + '_loss'] = js.detach()
         if s.dataset_name_b == 'DSEC_events':
             terms.append(js)
-            g_loss = g_loss + js
         for k in (2, 4):
             li = self.cycle_content_loss(pred_second_sensor[k], pred_first_sensor_no_grad[k], weight=s.weight_cycle_task_loss)
             terms.append(li)
-            g_loss = g_loss + li
             losses['cycle_pred_{}x_{}_loss'.format(k, cycle_name)] = li.detach()
+        g_loss = hip.sum_scalars(terms)  # (reported value only: the backward pass starts from the terms themselves)
         return g_loss, pred_first_sensor_no_grad, pred_second_sensor
 
     def encode_events(self, batch):
@@ -317,7 +315,7 @@ class ESSModel(base_trainer.BaseTrainer):
         if s.train_on_event_labels:
             t_loss_b, _ = self.trainTaskStep('sensor_b', latent_real, labels_b, losses, pred=pred_real)
             self._t_terms.append(t_loss_b)
-            t_loss = t_loss + t_loss_b
+            t_loss = hip.sum_scalars([t_loss, t_loss_b])
         return e_loss, t_loss, losses, out
 
     def TasktrainCycleStep(self, first_sensor_name, second_sensor_name, content_first_sensor, content_second_sensor, losses,
@@ -335,8 +333,7 @@ class ESSModel(base_trainer.BaseTrainer):
         for k in (2, 4):
             li = self.cycle_content_loss(pred_first_sensor[k], pred_second_sensor_no_grad[k], weight=s.weight_cycle_task_loss)
             terms.append(li)
-            t_loss = t_loss + li
-        return t_loss
+        return hip.sum_scalars(terms)
 
     # ------------------------------------------------------------------ validation (reference :364-548)
     def resetValidationStatistics(self):

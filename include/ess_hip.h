@@ -229,6 +229,9 @@ int ess_add(const float* a, const float* b, float* y, int64_t n, ess_stream_t st
 /* y = a + b (+ c when c != NULL) over bfloat16 tensors of n_vectors x 8 elements (16-byte aligned; any layout, e.g. BF16_C8):
  * fp32 sum, one round to nearest even; in place allowed.  Replaces autograd's gradient accumulation for an activation with
  * several consumers (models/style_networks.py:69-88: out[2] / out[4] feed the next stage and a loss).            */
+/* out = sum of n (<= 16) device scalars, added in the order given: the reported total of a train step's weighted loss terms
+ * (training/ess_trainer.py:116-138 adds them with one torch op per term).  `terms` is a HOST array of device pointers.  */
+int ess_sum_scalars(const float* const* terms, int32_t n, float* out, ess_stream_t stream);
 int ess_add_bf16(const void* a, const void* b, const void* c, void* y, int64_t n_vectors, ess_stream_t stream);
 
 /* EventPreprocessor.__call__ normalisation (e2vid/utils/inference_utils.py:96-107) over the whole
