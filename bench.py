@@ -347,7 +347,8 @@ def main():
         try:
             trainer.enable_step_graph(batch, warmup=2)
             graph_note = 'hipGraph replay (whole step captured once)' if world == 1 else \
-                'hipGraph replay (forward + backward) | flat-gradient all-reduce | hipGraph replay (optimisers)'
+                ('hipGraph replay (forwards + image-encoder backward) | image-encoder all-reduce under hipGraph replay (decoder backward) | decoder all-reduce | hipGraph replay (optimisers)'
+                 if getattr(trainer, '_g_mid', None) is not None else 'hipGraph replay (forward + backward) | flat-gradient all-reduce | hipGraph replay (optimisers)')
         except Exception as e:  # noqa: BLE001  (the eager step is the same computation; say so in the record)
             graph_note = f'eager (capture failed: {type(e).__name__}: {e})'
             trainer._g = None
@@ -423,7 +424,7 @@ def main():
         bf16 = args.compute == 'bf16'
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         step_flops = executed_flops_per_step(args)
-        storage = ('activations and activation gradients of the decoder / image encoder stored as BF16_C8 only, BF16_C8 staging '
+        storage = ('activations and activation gradients of the decoder / image encoder stored as BF16_C8 only (pre-normalisation conv outputs as F16_C8), BF16_C8 staging '
                    'copies inside the frozen encoder; parameters, weight gradients (bf16 operands, fp32 accumulate / storage), norm '
                    'statistics, recurrent cell state, losses and optimiser state fp32') if bf16 else 'all tensors fp32 NCHW'
         result = {
