@@ -567,10 +567,147 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
   }
 }
 
+// The common case of the function above -- one output, every channel of the tile real, no residual, no pooling -- as
+// straight-line code: the general function spends 2.5-4 k cycles per 32-channel block in uniform branches, channel masks and
+// selects (cycle stamps, round 3: 7.3-8.5 k cycles per 64 x 64 tile of a bias-only layer with nothing to load), this one is
+// per block 64 optional v_max, 32 packed conversions, 8 half-wave swaps and four 16-byte stores.
+template <int MB, bool SC, bool SH, bool F16, bool RELU, bool RES>
+__device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                       int x, int y0, const int (&ly)[NBW]) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+  constexpr int COT = MB * 32;
+  const unsigned HW = (unsigned)(a.Hout * a.Wout);
+  const int nblk = a.Cout >> 3;
+  const ess_rsrc r_o = ess_make_rsrc((const char*)a.out + (size_t)n * nblk * HW * 16, (size_t)nblk * HW * 16);
+  const ess_rsrc r_rs = ess_make_rsrc((const char*)(RES ? a.residual : a.out) + (size_t)n * nblk * HW * 16, RES ? (size_t)nblk * HW * 16 : 0);
+  unsigned pix16[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int y = y0 + ly[nb];
+    pix16[nb] = ((y < a.Hout) & (x < a.Wout)) ? (unsigned)(y * a.Wout + x) * 16u : ESS_OOB;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+    float4 scv[4], shv[4];
+    u32x4e rva[2][NBW];  // residual vectors of this lane's two store blocks (block pair jp: block jp + half), per pixel block
+    if constexpr (SC || SH || RES) {
+      asm volatile("" ::: "memory");  // (one block's vectors at a time, see above)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = rowbase + j * 8 + 4 * half;
+        if constexpr (SC) scv[j] = *(const float4*)(a.scale + c0);
+        if constexpr (SH) shv[j] = *(const float4*)(a.shift + c0);
+      }
+      if constexpr (RES) {
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            const unsigned pl = (unsigned)((rowbase >> 3) + 2 * jh + half) * HW * 16u;
+            rva[jh][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, (int)(pix16[nb] != ESS_OOB ? pl + pix16[nb] : ESS_OOB), 0, 0);
+          }
+      }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+      uint2 pk[2][NBW];
+      uint2 rr[2][NBW];  // residual, exchanged to the accumulator layout: [block of the pair][pixel block] = this lane's 4 channels
+      if constexpr (RES) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const u32x4e rv = rva[jp >> 1][nb];
+          const auto s0 = __builtin_amdgcn_permlane32_swap(rv[0], rv[2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(rv[1], rv[3], false, false);
+          rr[0][nb] = make_uint2(s0[0], s1[0]);
+          rr[1][nb] = make_uint2(s0[1], s1[1]);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = jp + jj;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[mb][nb][4 * j + i];
+          if constexpr (SC && SH) {
+            v[0] = v[0] * scv[j].x + shv[j].x; v[1] = v[1] * scv[j].y + shv[j].y; v[2] = v[2] * scv[j].z + shv[j].z; v[3] = v[3] * scv[j].w + shv[j].w;
+          } else if constexpr (SC) {
+            v[0] *= scv[j].x; v[1] *= scv[j].y; v[2] *= scv[j].z; v[3] *= scv[j].w;
+          } else if constexpr (SH) {
+            v[0] += shv[j].x; v[1] += shv[j].y; v[2] += shv[j].z; v[3] += shv[j].w;
+          }
+          if constexpr (RES) {
+            const bf16x4 rb = __builtin_bit_cast(bf16x4, rr[jj][nb]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)rb[i];
+          }
+          if constexpr (RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          if constexpr (F16) {
+            f16x4 h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+            pk[jj][nb] = __builtin_bit_cast(uint2, h);
+          } else {
+            bf16x4 b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[i];
+            pk[jj][nb] = __builtin_bit_cast(uint2, b);
+          }
+        }
+      }
+      const unsigned plane = (unsigned)((rowbase >> 3) + jp + half) * HW * 16u;
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
+        const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_o, (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB), 0, 0);
+      }
+    }
+  }
+}
+
+template <int MB, bool SC, bool SH>
+__device__ __forceinline__ void conv_epilogue_c8_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
+                                                     int y0, const int (&ly)[NBW]) {
+  // (all uniform) the plain form needs every channel of this workgroup's tile to exist, so the masks can go
+  const bool relu = a.act == ESS_ACT_RELU, res = a.residual != nullptr;
+  const bool plain = a.out_split <= 0 && (a.act == ESS_ACT_NONE || relu) && (a.Cout % (MB * 32)) == 0 && !(a.out_f16 && (relu || res));
+  if (!plain) { conv_epilogue_c8_impl<MB, SC, SH>(a, acc, ct, n, half, x, y0, ly); return; }
+  if (a.out_f16) {  // (pre-norm tensors: no activation, no residual)
+    conv_epilogue_c8_plain<MB, SC, SH, true, false, false>(a, acc, ct, n, half, x, y0, ly);
+  } else if (res) {
+    if (relu) conv_epilogue_c8_plain<MB, SC, SH, false, true, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_plain<MB, SC, SH, false, false, true>(a, acc, ct, n, half, x, y0, ly);
+  } else {
+    if (relu) conv_epilogue_c8_plain<MB, SC, SH, false, true, false>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_plain<MB, SC, SH, false, false, false>(a, acc, ct, n, half, x, y0, ly);
+  }
+}
+
 // biased: the caller started its accumulators from the shift vector (conv_bias_init), nothing is left to add here
 template <int MB>
 __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                                  int y0, const int (&ly)[NBW], bool biased = false) {
+#ifndef ESS_C8_EPI_GENERAL
+  if (biased) {  // (uniform)
+    conv_epilogue_c8_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+  } else if (a.scale) {
+    if (a.shift) conv_epilogue_c8_sel<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_sel<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
+  } else {
+    if (a.shift) conv_epilogue_c8_sel<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+  }
+  return;
+#endif
   if (biased) {  // (uniform)
     conv_epilogue_c8_impl<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
   } else if (a.scale) {
