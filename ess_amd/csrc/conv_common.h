@@ -674,12 +674,104 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
   }
 }
 
+// The data-gradient forms as straight-line code: an optional second output (out_split, a multiple of 16 channels so that a
+// block pair never straddles it) and / or a 2x2-sum-pooled first output with 32-wide pixel blocks (the two pixel blocks of a
+// wave are vertical neighbours: one add in the lane, one across lane^1; only the even-x / even-y lanes of block 0 store).
+template <int MB, bool POOL>
+__device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                       int x, int y0, const int (&ly)[NBW]) {
+  static_assert(NBW == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+  constexpr int COT = MB * 32;
+  const unsigned HW = (unsigned)(a.Hout * a.Wout);
+  const int split = a.out_split;
+  const int nb_first = (split > 0 ? split : a.Cout) >> 3, nb_second = split > 0 ? (a.Cout - split) >> 3 : 0;
+  const int Wl = a.Wout >> 1;
+  const unsigned HW1 = POOL ? (unsigned)((a.Hout >> 1) * Wl) : HW;
+  const ess_rsrc r_o1 = ess_make_rsrc((const char*)a.out + (size_t)n * nb_first * HW1 * 16, (size_t)nb_first * HW1 * 16);
+  const ess_rsrc r_o2 = ess_make_rsrc(split > 0 ? (const char*)a.out2 + (size_t)n * nb_second * HW * 16 : (const char*)a.out,
+                                      split > 0 ? (size_t)nb_second * HW * 16 : 0);
+  unsigned pix16[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) {
+    const int y = y0 + ly[nb];
+    pix16[nb] = ((y < a.Hout) & (x < a.Wout)) ? (unsigned)(y * a.Wout + x) * 16u : ESS_OOB;
+  }
+  unsigned st_pool = ESS_OOB;  // pooled pixel of this lane (owner lanes only)
+  if constexpr (POOL) {
+    const int y = y0 + ly[0];
+    if ((y < a.Hout) & (x < a.Wout) & !(x & 1) & !(y & 1)) st_pool = (unsigned)((y >> 1) * Wl + (x >> 1)) * 16u;
+  }
+  auto xor1 = [](float f) {  // lane^1 through DPP (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0xB1, 0xf, 0xf, true));
+  };
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int rowbase = ct * COT + mb * 32;
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+      const int blk0 = (rowbase >> 3) + jp;
+      const bool first = blk0 < nb_first;  // (uniform; the whole pair: split % 16 == 0)
+      if (POOL && first) {
+        uint2 pk[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          bf16x4 b;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float p = acc[mb][0][4 * (jp + jj) + i] + acc[mb][1][4 * (jp + jj) + i];
+            p += xor1(p);
+            b[i] = (__bf16)p;
+          }
+          pk[jj] = __builtin_bit_cast(uint2, b);
+        }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, (int)(st_pool != ESS_OOB ? (unsigned)(blk0 + half) * HW1 * 16u + st_pool : ESS_OOB), 0, 0);
+      } else {
+        uint2 pk[2][NBW];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int nb = 0; nb < NBW; ++nb) {
+            bf16x4 b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = (__bf16)acc[mb][nb][4 * (jp + jj) + i];
+            pk[jj][nb] = __builtin_bit_cast(uint2, b);
+          }
+        const unsigned plane = (unsigned)(blk0 + half - (first ? 0 : nb_first)) * HW * 16u;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
+          const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
+          const int o = (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB);
+          if (first) __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, o, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(vec, r_o2, o, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 template <int MB, bool SC, bool SH>
 __device__ __forceinline__ void conv_epilogue_c8_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                                      int y0, const int (&ly)[NBW]) {
   // (all uniform) the plain form needs every channel of this workgroup's tile to exist, so the masks can go
   const bool relu = a.act == ESS_ACT_RELU, res = a.residual != nullptr;
   const bool plain = a.out_split <= 0 && (a.act == ESS_ACT_NONE || relu) && (a.Cout % (MB * 32)) == 0 && !(a.out_f16 && (relu || res));
+  if constexpr (!SC && !SH) {
+    const bool pool = a.act == ESS_ACT_SUMPOOL2;
+    const bool dgrad = (pool || a.out_split > 0) && (pool || a.act == ESS_ACT_NONE) && !res && !a.out_f16 && (a.out_split & 15) == 0 &&
+                       (a.Cout % (MB * 32)) == 0 && (!pool || a.bwl == 5);
+    if (dgrad) {
+      if (pool) conv_epilogue_c8_dgrad<MB, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_dgrad<MB, false>(a, acc, ct, n, half, x, y0, ly);
+      return;
+    }
+  }
   if (!plain) { conv_epilogue_c8_impl<MB, SC, SH>(a, acc, ct, n, half, x, y0, ly); return; }
   if (a.out_f16) {  // (pre-norm tensors: no activation, no residual)
     conv_epilogue_c8_plain<MB, SC, SH, true, false, false>(a, acc, ct, n, half, x, y0, ly);
