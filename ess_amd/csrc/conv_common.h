@@ -811,6 +811,101 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
   }
 }
 
+// ConvLSTM gate epilogue of the lean time steps as straight-line code: F32_C8 cell state in and out (or no previous state),
+// accumulators started from the bias, every hidden channel of the tile real.  The general form below carries the
+// NCHW / F32_C8 / bias-load choices as uniform branches inside the unrolled rows; hipcc then waits for the c_prev loads right
+// where they are issued (a join of the two load forms) -- cycle stamps: 2.5 k cycles of exposed latency + 6.7 k of branchy
+// arithmetic per 64 x 256 tile, 15-26 % of a matrix wave's tile.  Here the four activations that do not need c_prev (80 % of
+// the transcendental work) run, in place in the accumulators, while the loads are in flight.  The BF16_C8 copy of h' leaves as
+// whole 16-byte pixel vectors (half-wave swap between the two hidden blocks of a pair, as in conv_epilogue_c8).
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                      const int (&pixi)[NBW], unsigned HW) {
+  typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int nbh = a.hid >> 3;
+  const size_t state_b = (size_t)nbh * HW * 32;
+  const ess_rsrc r_prev = ess_make_rsrc(a.aux0 ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.out2, a.aux0 ? state_b : 0);
+  const ess_rsrc r_c = ess_make_rsrc(a.out2 + (size_t)n * nbh * 8 * HW, state_b);
+  const ess_rsrc r_h = ess_make_rsrc(a.out ? a.out + (size_t)n * nbh * 8 * HW : a.out2, a.out ? state_b : 0);
+  const ess_rsrc r_hb = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.out2, a.out_bf ? (size_t)nbh * HW * 16 : 0);
+  unsigned vo[MB][NBW];
+  u32x4c cp[MB][NBW];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      vo[mb][nb] = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb) * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
+      cp[mb][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_prev, (int)vo[mb][nb], 0, 0);  // (no previous state: zeros)
+    }
+  __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the loads to their first use to save 16 registers)
+  // packed row 8*g + j of a 32-row block = gate g (in, remember, out, cell) of hidden hb*8 + j
+  // (written as two phases -- the activations that do not need c_prev, then the rest; hipcc interleaves them per row to stay
+  // inside 128 registers, and a scheduling barrier between the phases made it spill ~100: the first row's 12 activations are what
+  // covers the load latency)
+  float igc[MB][NBW][4], gf[MB][NBW][4], go[MB][NBW][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        igc[mb][nb][jj] = ess_sigmoid(acc[mb][nb][jj]) * ess_tanh(acc[mb][nb][12 + jj]);
+        gf[mb][nb][jj] = ess_sigmoid(acc[mb][nb][4 + jj]);
+        go[mb][nb][jj] = ess_sigmoid(acc[mb][nb][8 + jj]);
+      }
+  float hn[MB][NBW][4];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      u32x4c cv;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float cprev = __builtin_bit_cast(float, (unsigned)cp[mb][nb][jj]);
+        const float cn = gf[mb][nb][jj] * cprev + igc[mb][nb][jj];
+        cv[jj] = __builtin_bit_cast(unsigned, cn);
+        hn[mb][nb][jj] = go[mb][nb][jj] * ess_tanh(cn);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(cv, r_c, (int)vo[mb][nb], 0, 0);
+    }
+  if (a.out) {  // (uniform; NULL in the lean steps: only the BF16_C8 copy of h' is wanted)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const u32x4c hv = {__builtin_bit_cast(unsigned, hn[mb][nb][0]), __builtin_bit_cast(unsigned, hn[mb][nb][1]),
+                           __builtin_bit_cast(unsigned, hn[mb][nb][2]), __builtin_bit_cast(unsigned, hn[mb][nb][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(hv, r_h, (int)vo[mb][nb], 0, 0);
+      }
+  }
+  if (a.out_bf) {  // (uniform)
+    auto pack = [&](int mb, int nb) {
+      bf16x4 b;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = (__bf16)hn[mb][nb][i];
+      return __builtin_bit_cast(uint2, b);
+    };
+    if constexpr (MB >= 2) {
+#pragma unroll
+      for (int mb = 0; mb < MB; mb += 2)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+          const uint2 p0 = pack(mb, nb), p1 = pack(mb + 1, nb);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
+          const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};  // lanes 0-31: block mb, lanes 32-63: block mb + 1
+          const unsigned o = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(vec, r_hb, (int)o, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+        if (pixi[nb] >= 0) ess_store_bf16x4(a.out_bf, (size_t)n * nbh, ct, HW, pixi[nb], half, hn[0][nb][0], hn[0][nb][1], hn[0][nb][2], hn[0][nb][3]);
+    }
+  }
+}
+
 // ALLOW8 = false: the caller dispatches BF16_C8 outputs to a dedicated kernel instantiation (conv_epilogue_c8 only: a fraction
 // of the code and registers of this function), so the run-time branch to it is left out here.
 template <int MB, int EPI, bool ALLOW8 = true>
@@ -827,6 +922,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
     const bool inb = y < a.Hout && x < a.Wout;
     pixi[nb] = inb ? y * a.Wout + x : -1;
     voff[nb] = inb ? ((unsigned)pixi[nb] + 4u * half * HW) * 4u : ESS_OOB;
+  }
+  if constexpr (EPI == ESS_EPI_LSTM) {
+#ifndef ESS_LSTM_EPI_GENERAL
+    if (biased && a.fmt_out == ESS_FMT_F32_C8 && (!a.aux0 || a.fmt_res == ESS_FMT_F32_C8) && (a.hid % (8 * MB)) == 0) {  // (uniform)
+      conv_epilogue_lstm_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      return;
+    }
+#endif
   }
   if constexpr (EPI == ESS_EPI_GRU_OUT) {
     conv_epilogue_gru_out<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
