@@ -4,6 +4,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef ESS_EPI_AUX
+#define ESS_EPI_AUX 2  // cache policy of the ConvLSTM state traffic (c_prev in, c / h' out): 2 = nt, streamed past the weights and halos in L2
+#endif
+#ifndef ESS_C8_AUX
+#define ESS_C8_AUX 0  // same for the BF16_C8 outputs of the plain epilogue (experiment)
+#endif
 namespace essconv {
 
 constexpr int NBW = 2;  // pixel blocks per wave
@@ -668,7 +674,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
         const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
-        __builtin_amdgcn_raw_buffer_store_b128(vec, r_o, (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_o, (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB), 0, ESS_C8_AUX);
       }
     }
   }
@@ -836,7 +842,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
       vo[mb][nb] = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb) * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
-      cp[mb][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_prev, (int)vo[mb][nb], 0, 0);  // (no previous state: zeros)
+      cp[mb][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_prev, (int)vo[mb][nb], 0, ESS_EPI_AUX);  // (no previous state: zeros)
     }
   __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the loads to their first use to save 16 registers)
   // packed row 8*g + j of a 32-row block = gate g (in, remember, out, cell) of hidden hb*8 + j
@@ -867,7 +873,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
         cv[jj] = __builtin_bit_cast(unsigned, cn);
         hn[mb][nb][jj] = go[mb][nb][jj] * ess_tanh(cn);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(cv, r_c, (int)vo[mb][nb], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(cv, r_c, (int)vo[mb][nb], 0, ESS_EPI_AUX);
     }
   if (a.out) {  // (uniform; NULL in the lean steps: only the BF16_C8 copy of h' is wanted)
 #pragma unroll
@@ -876,7 +882,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
       for (int nb = 0; nb < NBW; ++nb) {
         const u32x4c hv = {__builtin_bit_cast(unsigned, hn[mb][nb][0]), __builtin_bit_cast(unsigned, hn[mb][nb][1]),
                            __builtin_bit_cast(unsigned, hn[mb][nb][2]), __builtin_bit_cast(unsigned, hn[mb][nb][3])};
-        __builtin_amdgcn_raw_buffer_store_b128(hv, r_h, (int)vo[mb][nb], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hv, r_h, (int)vo[mb][nb], 0, ESS_EPI_AUX);
       }
   }
   if (a.out_bf) {  // (uniform)
@@ -896,7 +902,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
           const auto s1 = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
           const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};  // lanes 0-31: block mb, lanes 32-63: block mb + 1
           const unsigned o = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(vec, r_hb, (int)o, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(vec, r_hb, (int)o, 0, ESS_EPI_AUX);
         }
     } else {
 #pragma unroll
