@@ -574,6 +574,72 @@ def test_conv_bf16_c8_sources_and_copy(H, case):
             assert not ob.view(N, -1, Hh, Ww, 8).float().permute(0, 1, 4, 2, 3).reshape(N, -1, Hh, Ww)[:, Cout:].any()  # zero tail
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BF16_C8 outputs: the straight-line epilogues (conv_epilogue_c8_plain / _dgrad: every channel of the 64-channel tile real) against
+# the general function (conv_epilogue_c8_impl: reached here with 72 output channels, whose first 64 carry the same weights) --
+# the same arithmetic, so the same bits -- and against fp32 math on bf16-rounded operands.
+@pytest.mark.parametrize('form', ['bias', 'bias_f16', 'relu', 'scale_shift_relu', 'scale', 'residual', 'residual_relu', 'split', 'pool', 'pool_split'])
+@pytest.mark.parametrize('geom', [(2, 32, 24, 40), (1, 48, 20, 72)])
+def test_conv_c8_epilogue_forms_agree(H, form, geom):
+    N, Ci, Hh, Ww = geom
+    g = torch.Generator().manual_seed(Hh * 7 + len(form))
+    x = torch.randn(N, Ci, Hh, Ww, generator=g)
+    w72 = torch.randn(72, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    b72, s72 = torch.randn(72, generator=g), torch.rand(72, generator=g) + 0.5
+    relu = form.endswith('relu')
+    split = 32 if form.endswith('split') else 0
+    pool = form.startswith('pool')
+    f16 = form == 'bias_f16'
+    has_scale, has_shift, has_res = 'scale' in form, form not in ('scale', 'split', 'pool', 'pool_split'), form.startswith('residual')
+    act = H.ACT_SUMPOOL2 if pool else (H.ACT_RELU if relu else H.ACT_NONE)
+    xs = H.to_bf16_c8(dev(x))
+    outs = {}
+    for Co in (64, 72):
+        spec = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 3, 1, 1, act=act, out_split=split, compute=H.COMPUTE_BF16)
+        pw = H.pack_weights(spec, dev(w72[:Co]))
+        sc = H.pack_rows(spec, dev(s72[:Co])) if has_scale else None
+        sh = H.pack_rows(spec, dev(b72[:Co])) if has_shift else None
+        c1 = split if split else Co
+        h1, w1 = (Hh // 2, Ww // 2) if pool else (Hh, Ww)
+        mk = H.f16_c8_empty if f16 else H.bf16_c8_empty
+        o1 = mk(N, c1, h1, w1, 'cuda')
+        o1.view(torch.int16).fill_(0x7fc0 if not f16 else 0x7e00)  # NaN patterns: every element must be written
+        o2 = H.bf16_c8_empty(N, Co - split, Hh, Ww, 'cuda') if split else None
+        if o2 is not None:
+            o2.view(torch.int16).fill_(0x7fc0)
+        res = None
+        if has_res:
+            r = torch.randn(N, 72, Hh, Ww, generator=torch.Generator().manual_seed(5))
+            res = H.to_bf16_c8(dev(r[:, :Co]))
+        H.conv_forward(spec, xs, None, pw, sc, sh, residual=res, out=o1, out2=o2, src_fmt=H.FMT_BF16_C8,
+                       out_fmt=H.FMT_F16_C8 if f16 else H.FMT_BF16_C8)
+        v1 = H.f16_c8_to_float(o1, c1).cpu() if f16 else _un8(o1, c1)
+        outs[Co] = (v1, _un8(o2, Co - split) if split else None)
+    a, b = outs[64], outs[72]
+    assert torch.isfinite(a[0]).all() and torch.isfinite(b[0]).all()
+    n1 = split if split else 64
+    assert torch.equal(a[0][:, :n1], b[0][:, :n1])
+    if split:
+        assert torch.isfinite(a[1]).all() and torch.equal(a[1], b[1][:, :32])
+    # fp32 math on the bf16-rounded operands, rounded to the stored type
+    ref = F.conv2d(x.bfloat16().float(), w72[:64].bfloat16().float(), None, padding=1)
+    if has_scale:
+        ref = ref * s72[:64].view(1, -1, 1, 1)
+    if has_shift:
+        ref = ref + b72[:64].view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + torch.randn(N, 72, Hh, Ww, generator=torch.Generator().manual_seed(5))[:, :64].bfloat16().float()
+    if relu:
+        ref = F.relu(ref)
+    r1 = ref[:, :n1]
+    if pool:
+        r1 = F.avg_pool2d(r1, 2) * 4
+    tol = 2e-3 if f16 else 1.2e-2  # half / bfloat16 rounding of the stored value (relative to the largest magnitude: relerr)
+    assert relerr(a[0], r1) < tol
+    if split:
+        assert relerr(a[1], ref[:, 32:]) < tol
+
+
 @pytest.mark.parametrize('case', [(2, 32, 64, 48, 80, 2), (1, 24, 40, 22, 36, 2), (2, 64, 32, 24, 40, 1), (1, 8, 16, 19, 27, 1)])
 def test_conv5x5_paired_c8_sources(H, case):
     """5x5 (tap-paired kernel), stride 1 and 2: BF16_C8 sources give the same bits as fp32 NCHW sources, and both
@@ -789,7 +855,8 @@ def test_conv_head5x5_bf16(H, case):
         assert int(pad.abs().max() if pad.numel() else 0) == 0  # tail channels of the last block stay zero
 
 
-@pytest.mark.parametrize('case', [(2, 16, 64, 12, 20, 'bf16'), (1, 8, 12, 9, 13, 'bf16'), (2, 8, 16, 6, 10, 'fp32')])
+@pytest.mark.parametrize('case', [(2, 16, 64, 12, 20, 'bf16'), (1, 8, 12, 9, 13, 'bf16'), (2, 8, 16, 6, 10, 'fp32'), (1, 32, 256, 20, 24, 'bf16'),
+                                  (2, 32, 32, 17, 33, 'bf16')])
 def test_conv_lstm_blocked_states(H, case):
     """FMT_F32_C8 cell / hidden states ([N][hid/8][H][W][8] fp32, what travels between the lean time steps) against fp32 NCHW
     planes: the same arithmetic, so the values are identical -- as input (aux0), as output (out / out2), and both."""
@@ -811,17 +878,31 @@ def test_conv_lstm_blocked_states(H, case):
     def planes(t8):
         return t8.permute(0, 1, 4, 2, 3).reshape(N, nb * 8, Hh, Ww)[:, :hid].contiguous()
 
-    def run(cin_blocked, out_blocked):
+    def run(cin_blocked, out_blocked, lean=False, first=False):
         ho = (H.f32_c8_empty(N, hid, Hh, Ww, 'cuda') if out_blocked else torch.empty_like(h)).fill_(float('nan'))
         co = torch.empty_like(ho).fill_(float('nan'))
-        H.conv_forward(spec, x, h, pw, None, pb, aux0=blocked(c) if cin_blocked else c, out=ho, out2=co,
+        hb = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda') if comp == 'bf16' else None  # (the copy exists for bf16 compute only)
+        if hb is not None:
+            hb.view(torch.int16).fill_(0x7fc0)
+        prev = None if first else (blocked(c) if cin_blocked else c)
+        H.conv_forward(spec, x, h, pw, None, pb, aux0=prev, out=None if lean else ho, out2=co, out_bf=hb,
                        out_fmt=H.FMT_F32_C8 if out_blocked else H.FMT_F32_NCHW, aux_fmt=H.FMT_F32_C8 if cin_blocked else H.FMT_F32_NCHW)
-        return (planes(ho), planes(co)) if out_blocked else (ho, co)
-    h0, c0 = run(False, False)
+        return ((planes(ho), planes(co)) if out_blocked else (ho, co)) + (_un8(hb, hid) if hb is not None else torch.zeros(1),)
+    h0, c0, hb0 = run(False, False)
     assert torch.isfinite(h0).all() and torch.isfinite(c0).all()
+    if comp == 'bf16':
+        assert torch.equal(hb0, h0.bfloat16().float().cpu())  # the BF16_C8 copy of h' is RNE(h')
     for cin_b, out_b in ((True, False), (False, True), (True, True)):
-        h1, c1 = run(cin_b, out_b)
-        assert torch.equal(h1, h0) and torch.equal(c1, c0), (cin_b, out_b)
+        h1, c1, hb1 = run(cin_b, out_b)
+        assert torch.equal(h1, h0) and torch.equal(c1, c0) and torch.equal(hb1, hb0), (cin_b, out_b)
+    if comp != 'bf16':
+        return
+    # the lean form (no fp32 h', only its BF16_C8 copy) and the first step of a sequence (no previous cell state)
+    _, c2, hb2 = run(True, True, lean=True)
+    assert torch.equal(c2, c0) and torch.equal(hb2, hb0)
+    hf, cf, hbf = run(False, False, first=True)
+    _, cf8, hbf8 = run(True, True, lean=True, first=True)
+    assert torch.isfinite(cf).all() and torch.equal(cf8, cf) and torch.equal(hbf8, hbf)
 
 
 @pytest.mark.parametrize('case', [(2, 16, 64, 12, 20, 'bf16'), (1, 8, 12, 9, 13, 'bf16'), (2, 8, 16, 6, 10, 'fp32'), (1, 16, 256, 5, 7, 'bf16'),
