@@ -132,26 +132,30 @@ __global__ __launch_bounds__(256) void up2_bilinear_add_c8_kernel(const float* _
 // fp32 outputs): 16 x 16-byte loads per thread instead of 128 scalar ones, half the bytes.  Per output the expression and
 // operation order of the kernels above applied to the sources' bf16 values, i.e. bit-identical to feeding those kernels the
 // converted tensors.
+// One thread = 4 output columns of an output ROW PAIR (2 pr - 1, 2 pr), pr = 0 .. H: both rows blend the same two source rows
+// (pr - 1, pr), so the 16 loads, their unpacking, the a + b sums and the horizontal blends are done once for 8 output vectors (the
+// first version did them per output row: ~110 VALU and 4 loads per output vector, and the pass ran at 2.8-3.3 TB/s -- instruction-
+// bound, not memory-bound).  pr = 0 / pr = H hold one real row each (0 and 2 H - 1).  Per output the expression is unchanged.
 __global__ __launch_bounds__(256) void up2_bilinear_add_c8c8_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                                     uint4* __restrict__ y, int N, int CB, int H, int W) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  const int W2 = 2 * W, H2 = 2 * H, Q = W2 >> 2;
-  const unsigned total = (unsigned)N * CB * H2 * Q;
+  const int W2 = 2 * W, H2 = 2 * H, Q = W2 >> 2, HP = H + 1;
+  const unsigned total = (unsigned)N * CB * HP * Q;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const unsigned q = i % Q, t = i / Q;
-    const unsigned yy = t % H2, g = t / H2;  // g = n * CB + cb
-    const float sy = fmaxf(0.f, (yy + 0.5f) * 0.5f - 0.5f);
-    const int y0 = (int)sy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
-    const float ly = sy - y0, hy = 1.f - ly;
+    const int pr = (int)(t % HP);
+    const unsigned g = t / HP;  // g = n * CB + cb
+    // source rows of the pair: (pr - 1, pr); row 0 alone blends (0, 1) with weight 0 on the second, row 2H - 1 alone (H - 1, H - 1)
+    const int ra = pr == 0 ? 0 : pr - 1, rb = pr == 0 ? (H > 1 ? 1 : 0) : min(pr, H - 1);
     const int c[4] = {max(2 * (int)q - 1, 0), 2 * (int)q, 2 * (int)q + 1, min(2 * (int)q + 2, W - 1)};
-    const uint4* r0 = a + ((size_t)g * H + y0) * W;
-    const uint4* r1 = a + ((size_t)g * H + y1) * W;
+    const uint4* r0 = a + ((size_t)g * H + ra) * W;
+    const uint4* r1 = a + ((size_t)g * H + rb) * W;
     uint4 va0[4], va1[4], vb0[4], vb1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { va0[k] = r0[c[k]]; va1[k] = r1[c[k]]; }
     if (b) {
-      const uint4* s0 = b + ((size_t)g * H + y0) * W;
-      const uint4* s1 = b + ((size_t)g * H + y1) * W;
+      const uint4* s0 = b + ((size_t)g * H + ra) * W;
+      const uint4* s1 = b + ((size_t)g * H + rb) * W;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { vb0[k] = s0[c[k]]; vb1[k] = s1[c[k]]; }
     }
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(256) void up2_bilinear_add_c8c8_kernel(const uint4*
         for (int j = 0; j < 8; ++j) { u0[k][j] += (float)q0[j]; u1[k][j] += (float)q1[j]; }
       }
     }
-    uint4* dst = y + ((size_t)g * H2 + yy) * W2 + 4 * q;
+    // horizontal blends of the two source rows at the 4 output columns (shared by both output rows)
+    float h0[4][8], h1[4][8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int x = 4 * (int)q + k;
@@ -176,11 +181,27 @@ __global__ __launch_bounds__(256) void up2_bilinear_add_c8c8_kernel(const uint4*
       const float lx = sx - x0, hx = 1.f - lx;
       const int i0 = k == 0 ? 0 : (k == 3 ? 2 : 1);
       const int i1 = k == 0 ? (q == 0 ? 2 : 1) : (k == 3 ? 3 : 2);
-      bf16x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = (__bf16)(hy * (hx * u0[i0][j] + lx * u0[i1][j]) + ly * (hx * u1[i0][j] + lx * u1[i1][j]));
-      dst[k] = __builtin_bit_cast(uint4, v);
+      for (int j = 0; j < 8; ++j) {
+        h0[k][j] = hx * u0[i0][j] + lx * u0[i1][j];
+        h1[k][j] = hx * u1[i0][j] + lx * u1[i1][j];
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int yy = 2 * pr - 1 + rr;
+      if (yy < 0 || yy >= H2) continue;
+      const float sy = fmaxf(0.f, (yy + 0.5f) * 0.5f - 0.5f);
+      const int y0 = (int)sy;
+      const float ly = sy - y0, hy = 1.f - ly;
+      uint4* dst = y + ((size_t)g * H2 + yy) * W2 + 4 * q;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)(hy * h0[k][j] + ly * h1[k][j]);
+        dst[k] = __builtin_bit_cast(uint4, v);
+      }
     }
   }
 }
@@ -360,8 +381,8 @@ extern "C" int ess_upsample_bilinear2x_add_c8_from_c8(const void* a, const void*
   ESS_CHECK_ARG(a && y && N > 0 && C > 0 && H > 0 && W > 0, "upsample_bilinear2x_add_c8_from_c8: bad arguments");
   ESS_CHECK_ARG((W & 1) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0,
                 "upsample_bilinear2x_add_c8_from_c8: even source width and 16-byte aligned BF16_C8 tensors");
-  const int64_t total = (int64_t)N * ((C + 7) / 8) * 2 * H * (W / 2);
-  ESS_CHECK_ARG(total < ((int64_t)1 << 31), "upsample_bilinear2x_add_c8_from_c8: tensor too large for 32-bit indexing");
+  const int64_t total = (int64_t)N * ((C + 7) / 8) * (H + 1) * (W / 2);  // (one thread per output row pair and 4 columns)
+  ESS_CHECK_ARG((int64_t)N * ((C + 7) / 8) * 2 * H * (W / 2) < ((int64_t)1 << 31), "upsample_bilinear2x_add_c8_from_c8: tensor too large for 32-bit indexing");
   hipLaunchKernelGGL(up2_bilinear_add_c8c8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
                      (const uint4*)b, (uint4*)y, N, (C + 7) / 8, H, W);
   return ess_launch_status("upsample_bilinear2x_add_c8_from_c8");
