@@ -5,6 +5,14 @@ namespace {
 
 using namespace essconv;
 
+template <int I, int N, class F>
+__device__ __forceinline__ void pair_steps(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pair_steps<I + 1, N>(f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised variant for 5x5 filters (stride 1 and 2): "tap pairing".  With 25 taps a 16-channel chunk needs a
 // 51 KB weight slab per stage, which leaves room for neither double buffering nor a second workgroup.  Here a chunk is
@@ -12,7 +20,9 @@ using namespace essconv;
 // (k 8..15) tap 2p+1 -- for the B operand that is just a different LDS offset per half-wave, for A a different slab
 // row (packed [tile][chunk][pair][half][cout][8]).  13 pairs cover the 25 taps (the 26th has zero weights: 4 % waste);
 // a stage is one 8-channel input tile + 26.6 KB of weights, double-buffered like the 3x3 kernel, one barrier per chunk.
-template <int KS, int S, int MB, bool SRCBF>
+// OUT8: BF16_C8 output(s) -- an instantiation that contains conv_epilogue_c8 and nothing of the fp32 epilogue variants (as in
+// conv_bf16_ws.hip: the all-variants function carries ~30 k instructions of epilogues and their spills).
+template <int KS, int S, int MB, bool SRCBF, bool OUT8 = false>
 __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws_pair_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int NT = KS * KS, NP = (NT + 1) / 2;
@@ -228,31 +238,64 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
   __syncthreads();  // stage 0 is ready
+  __builtin_amdgcn_s_setprio(1);  // (the matrix waves take issue priority over the staging waves of their SIMDs, as in conv_bf16_ws.hip)
+  // ---- K loop.  The fragment reads run D = 2 (32-row tiles) or 1 tap pairs ahead of the MFMAs (D + 1 register sets, counted
+  // lgkmcnt): a pair is only MB x NBW MFMAs = 64-128 cycles of matrix work per wave, about one LDS round trip.  As plain loads hipcc sinks every
+  // ds_read to just above its MFMA and waits for it there with lgkmcnt(0) -- read, wait, MFMA, read, wait, MFMA: the matrix pipe
+  // idles for an LDS round trip in front of every instruction (the first version of this loop; the kernel ran at 0.27 of peak).
+  // So the reads and the waits are volatile asm statements, the wait taking the fragments as in/out operands (conv_bf16_ws.hip).
+  const unsigned lds0 = (unsigned)(size_t)(smem16);
+  const unsigned a_base = (unsigned)((a.plane + half * COT + p) * 16);
+  unsigned b_base[NBW], tofs[NP];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) b_base[nb] = (unsigned)(boff[nb] * 16);
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) tofs[pr] = (unsigned)((half ? tap_off(2 * pr + 1) : tap_off(2 * pr)) * 16);
+  struct Frags { u32x4 a[MB]; u32x4 b[NBW]; };
+  constexpr int NR = MB + NBW;  // LDS reads per pair
+  constexpr int D = MB == 1 ? 2 : 1;  // pairs the reads run ahead (64-row tiles: a pair is 128 cycles of MFMAs, and 128 registers hold two sets)
   for (int ch = 0; ch < a.n_chunks; ++ch) {
-    const u32x4* in_t = smem16 + (ch & 1) * bufsz;
-    const u32x4* w_t = in_t + a.plane;
-    bf16x8 af[2][MB], bfr[2][NBW];
-    auto read_pair = [&](int pr, int slot) {
-      const u32x4* wp = w_t + (pr * 2 + half) * COT + p;
+    const unsigned stage_b = lds0 + (unsigned)((ch & 1) * bufsz * 16);
+    const unsigned wa = stage_b + a_base;
+    unsigned ba[NBW];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) af[slot][mb] = __builtin_bit_cast(bf16x8, wp[mb * 32]);
-      const int toff = half ? tap_off(2 * pr + 1) : tap_off(2 * pr);
+    for (int nb = 0; nb < NBW; ++nb) ba[nb] = stage_b + b_base[nb];
+    Frags f[D + 1];
+    auto read_pair = [&](auto PR, Frags& F) {
+      constexpr int pr = decltype(PR)::value;
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) bfr[slot][nb] = __builtin_bit_cast(bf16x8, in_t[toff + boff[nb]]);
+      for (int mb = 0; mb < MB; ++mb) {
+        const unsigned ad = wa + (unsigned)(mb * 32 * 16);  // (a local: clang refuses captured variables inside asm operands of a generic lambda)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F.a[mb]) : "v"(ad), "n"(pr * 2 * COT * 16));
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const unsigned ad = ba[nb] + tofs[pr];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(F.b[nb]) : "v"(ad));
+      }
     };
-    read_pair(0, 0);
-#pragma unroll
-    for (int pr = 0; pr < NP; ++pr) {
-      if (pr + 1 < NP) read_pair(pr + 1, (pr + 1) & 1);
+    auto wait_mma = [&](auto N, Frags& F) {
+      constexpr int n_ = decltype(N)::value;
+      if constexpr (MB == 1) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(F.a[0]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(n_));
+      else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(F.a[0]), "+v"(F.a[MB > 1 ? 1 : 0]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(n_));
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pr & 1][mb], bfr[pr & 1][nb], acc[mb][nb], 0, 0, 0);
-    }
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a[mb]), __builtin_bit_cast(bf16x8, F.b[nb]), acc[mb][nb], 0, 0, 0);
+    };
+    pair_steps<0, D>([&](auto PR) { read_pair(PR, f[decltype(PR)::value]); });
+    pair_steps<0, NP>([&](auto PR) {
+      constexpr int pr = decltype(PR)::value;
+      if constexpr (pr + D < NP) read_pair(std::integral_constant<int, pr + D>{}, f[(pr + D) % (D + 1)]);
+      constexpr int ahead = (pr + D < NP) ? D : (NP - 1 - pr);  // pairs whose reads may still be in flight behind this one's
+      wait_mma(std::integral_constant<int, ahead * NR>{}, f[pr % (D + 1)]);
+    });
     __syncthreads();
   }
-  conv_epilogue<MB, ESS_EPI_LINEAR>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  __builtin_amdgcn_s_setprio(0);
+  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  else conv_epilogue<MB, ESS_EPI_LINEAR, false>(a, acc, ct, n, half, x0 + lx, y0, ly);
   }  // tile loop
 #undef ESS_TILE_LOOP
 #undef ESS_TILE_DECODE
@@ -261,13 +304,11 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
 
 template <int S, int MB>
 void launch_pair(bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
-  if (c8) {
-    ess_allow_lds(conv_bf16_ws_pair_kernel<5, S, MB, true>, lds);
-    hipLaunchKernelGGL((conv_bf16_ws_pair_kernel<5, S, MB, true>), grid, dim3(512), lds, st, a);
-  } else {
-    ess_allow_lds(conv_bf16_ws_pair_kernel<5, S, MB, false>, lds);
-    hipLaunchKernelGGL((conv_bf16_ws_pair_kernel<5, S, MB, false>), grid, dim3(512), lds, st, a);
-  }
+#define ESS_PAIR(C8_, O8_) { ess_allow_lds(conv_bf16_ws_pair_kernel<5, S, MB, C8_, O8_>, lds); hipLaunchKernelGGL((conv_bf16_ws_pair_kernel<5, S, MB, C8_, O8_>), grid, dim3(512), lds, st, a); }
+  const bool out8 = a.fmt_out == ESS_FMT_BF16_C8;
+  if (c8) { if (out8) ESS_PAIR(true, true) else ESS_PAIR(true, false) }
+  else { if (out8) ESS_PAIR(false, true) else ESS_PAIR(false, false) }
+#undef ESS_PAIR
 }
 
 }  // namespace
