@@ -229,7 +229,9 @@ def roofline_blocks(args, device):
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           'ms_per_launch_set': round(wg_ms, 4)}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
-                    '; HIP events on the launch stream, inside this process after the timed steps'}
+                    '; HIP events on the launch stream, inside this process after the timed steps; launch sets repeated back to back, i.e. '
+                    'at the sustained-matrix-load clock (the same kernels inside the step, between HBM-bound launches, run 5-20 % faster: '
+                    'rocprofv3 averages in profiles/r3_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7c)'}
 
 
 def executed_flops_per_step(args):
