@@ -95,6 +95,45 @@ def _timed(ev, stream, fn, reps=20, warm=3):
     return ev.elapsed_ms(e0, e1) / reps
 
 
+def in_step_conv_rate(trainer, batch):
+    """The time-dominant kernel INSIDE a train step: one extra eager step (after the timed region, same trainer, same batch) with a
+    HIP event pair around every launch of conv_bf16_ws_k3s1_kernel<2, LINEAR, BF16_C8 sources, BF16_C8 / F16_C8 output> -- the
+    3x3 / stride-1 convolutions of the trainable networks, forward and data-gradient forms -- on the stream the launches go to.
+    -> {launches, ms (sum of their durations), achieved TFLOP/s = their algorithmic FLOPs / that time}.  This is the rate the rocprofv3
+    summary of the eager step gives for the kernel (profiles/r3_uda_bf16_eager_kernel_stats.txt: average duration x launches)."""
+    from ess_amd import hip
+    spans = []
+    orig = hip.conv_forward
+
+    def wrapped(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None, out2=None,
+                out_bf=None, src_fmt=hip.FMT_F32_NCHW, out_fmt=hip.FMT_F32_NCHW, aux_fmt=hip.FMT_F32_NCHW):
+        (N, Hv, Wv, C0, C1, _, _, Cout, k, st, pad, epi, _, _, _, compute) = spec.key
+        hot = (k == 3 and st == 1 and epi == hip.EPI_LINEAR and compute == hip.COMPUTE_BF16 and src_fmt == hip.FMT_BF16_C8 and
+               out_fmt in (hip.FMT_BF16_C8, hip.FMT_F16_C8) and Cout > 32 and not (Cout >= 256 and C0 + C1 >= 512))
+        if not hot:
+            return orig(spec, src0, src1, packed_w, scale, shift, residual, aux0, aux1, out, out2, out_bf, src_fmt, out_fmt, aux_fmt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(spec, src0, src1, packed_w, scale, shift, residual, aux0, aux1, out, out2, out_bf, src_fmt, out_fmt, aux_fmt)
+        e1.record()
+        spans.append((e0, e1, 2.0 * N * spec.H_out * spec.W_out * 9 * (C0 + C1) * Cout))
+        return r
+
+    g_saved = (getattr(trainer, '_g', None), getattr(trainer, '_g_mid', None), getattr(trainer, '_g_tail', None))
+    hip.conv_forward = wrapped
+    try:
+        trainer._g = None  # (issue this step eagerly; the captured graph is restored below)
+        trainer.train_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        hip.conv_forward = orig
+        trainer._g = g_saved[0]
+    ms = sum(a.elapsed_time(b) for a, b, _ in spans)
+    fl = sum(f for _, _, f in spans)
+    return {'launches': len(spans), 'ms': round(ms, 4), 'achieved': round(fl / ms / 1e9, 1) if ms > 0 else None,
+            'note': 'HIP event pair around every launch of the kernel inside one eager train step issued after the timed region'}
+
+
 def decoder_conv3x3_layers(args):
     """The 16 plain 3x3 convolutions of ONE SemSegE2VID forward at the bench shape (models/style_networks.py:69-88,158-193):
     (C0, C1, Cout, Hv, Wv, mode0 = nearest-up2 of source 0, count).  These are the launches of the time-dominant kernel of
@@ -397,6 +436,13 @@ def main():
         elapsed = t.item()
     final_loss = float(out[-1])
 
+    in_step = None
+    if rank == 0 and world == 1 and args.compute == 'bf16' and not args.no_roofline:
+        try:
+            in_step = in_step_conv_rate(trainer, batch)
+        except Exception as e:  # (the launch-set loops below still report)
+            in_step = {'error': f'{type(e).__name__}: {e}'}
+
     extra = {}
     if world == 1 and args.compute == 'bf16' and not args.no_fp32_extra:
         # the parity-grade configuration next to the headline one: the SAME step in exact-fp32 arithmetic (fp32 MFMA, fp32 NCHW
@@ -450,6 +496,10 @@ def main():
             result['extra'] = extra
         if not args.no_roofline:
             result['roofline'] = roofline_blocks(args, device)
+            if in_step is not None:
+                result['roofline']['in_step'] = in_step
+                if in_step.get('achieved'):
+                    in_step['frac'] = round(in_step['achieved'] / peak, 4)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(result), flush=True)
