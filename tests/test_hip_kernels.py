@@ -640,6 +640,31 @@ def test_conv_c8_epilogue_forms_agree(H, form, geom):
         assert relerr(a[1], ref[:, 32:]) < tol
 
 
+@pytest.mark.parametrize('case', [(2, 32, 11, 24, 40, True, False), (1, 32, 11, 17, 34, True, True), (2, 24, 3, 9, 14, False, False), (1, 64, 16, 12, 20, True, False),
+                                  (1, 40, 1, 6, 10, True, True)])
+def test_conv_pred1x1_c8_to_planes(H, case):
+    """The prediction-head form (1x1, BF16_C8 source, <= 16 classes to fp32 NCHW planes) against fp64 math on the bf16-rounded
+    operands -- the products are exact in fp32, only the summation order is the kernel's: 2e-6 of the largest magnitude."""
+    N, C, K, Hh, Ww, has_b, has_s = case
+    g = torch.Generator().manual_seed(C * 31 + K)
+    x = torch.randn(N, C, Hh, Ww, generator=g)
+    w = torch.randn(K, C, 1, 1, generator=g) / C ** 0.5
+    b = torch.randn(K, generator=g) if has_b else None
+    sc = (torch.rand(K, generator=g) + 0.5) if has_s else None
+    spec = H.conv_spec(N, Hh, Ww, C, 0, K, 1, 1, 0, compute=H.COMPUTE_BF16)
+    pw = H.pack_weights(spec, dev(w))
+    out = torch.full((N, K, Hh, Ww), float('nan'), device='cuda')
+    H.conv_forward(spec, H.to_bf16_c8(dev(x)), None, pw, H.pack_rows(spec, dev(sc), fill=1.0) if has_s else None,
+                   H.pack_rows(spec, dev(b)) if has_b else None, out=out, src_fmt=H.FMT_BF16_C8)
+    ref = F.conv2d(x.bfloat16().float().double(), w.bfloat16().float().double())
+    if has_s:
+        ref = ref * sc.double().view(1, -1, 1, 1)
+    if has_b:
+        ref = ref + b.double().view(1, -1, 1, 1)
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < 2e-6
+
+
 @pytest.mark.parametrize('case', [(2, 32, 64, 48, 80, 2), (1, 24, 40, 22, 36, 2), (2, 64, 32, 24, 40, 1), (1, 8, 16, 19, 27, 1)])
 def test_conv5x5_paired_c8_sources(H, case):
     """5x5 (tap-paired kernel), stride 1 and 2: BF16_C8 sources give the same bits as fp32 NCHW sources, and both
