@@ -400,6 +400,111 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
   }
 }
 
+// ---- the two ConvGRU epilogues of the lean time steps as straight-line code (what conv_epilogue_lstm_c8 is to the LSTM one):
+// F32_C8 states in and out, bias in the accumulators, every hidden channel of the tile real; state loads issued first, 16-byte
+// stores, the BF16_C8 tensors (r*h, the copy of h') as whole pixel vectors via a half-wave swap between two hidden blocks.
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                        const int (&pixi)[NBW], unsigned HW) {
+  typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int nbh = a.hid >> 3;
+  const size_t state_b = (size_t)nbh * HW * 32;
+  const bool need_r = a.out_bf != nullptr;
+  const ess_rsrc r_h = ess_make_rsrc((a.aux0 && need_r) ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.out, (a.aux0 && need_r) ? state_b : 0);
+  const ess_rsrc r_u = ess_make_rsrc(a.out + (size_t)n * nbh * 8 * HW, state_b);
+  const ess_rsrc r_rb = ess_make_rsrc(need_r ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.out, need_r ? (size_t)nbh * HW * 16 : 0);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      unsigned vo[NBW][2];  // (indexed [nb] for the code below; one pixel block's vectors in flight at a time: 128 registers)
+      u32x4c hp[NBW][2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int hb = (ct * MB + mb) * 2 + q2;
+        vo[nb][q2] = pixi[nb] >= 0 ? ((unsigned)hb * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
+        hp[nb][q2] = __builtin_amdgcn_raw_buffer_load_b128(r_h, (int)vo[nb][q2], 0, ESS_GRU_AUX);  // (absent / unused: zeros)
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from sinking the loads to their first use)
+      uint2 pk[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        u32x4c uv;
+        bf16x4 rb;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          uv[jj] = __builtin_bit_cast(unsigned, ess_sigmoid(acc[mb][nb][8 * q2 + jj]));
+          if (need_r) rb[jj] = (__bf16)(ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj]) * __builtin_bit_cast(float, (unsigned)hp[nb][q2][jj]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(uv, r_u, (int)vo[nb][q2], 0, ESS_GRU_AUX);
+        pk[q2] = __builtin_bit_cast(uint2, rb);
+      }
+      if (need_r) {  // (uniform) lanes 0-31: hidden block 2 (ct MB + mb), lanes 32-63: the next one
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};
+        const unsigned o = pixi[nb] >= 0 ? ((unsigned)((ct * MB + mb) * 2 + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_rb, (int)o, 0, ESS_GRU_AUX);
+      }
+    }
+  }
+}
+
+template <int MB>
+__device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
+                                                         const int (&pixi)[NBW], unsigned HW) {
+  typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const int nbh = a.hid >> 3;
+  const size_t state_b = (size_t)nbh * HW * 32;
+  const ess_rsrc r_h = ess_make_rsrc(a.aux0 ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.aux1, a.aux0 ? state_b : 0);
+  const ess_rsrc r_u = ess_make_rsrc(a.aux1 + (size_t)n * nbh * 8 * HW, state_b);
+  const ess_rsrc r_o = ess_make_rsrc(a.out ? (const char*)(a.out + (size_t)n * nbh * 8 * HW) : (const char*)a.aux1, a.out ? state_b : 0);
+  const ess_rsrc r_ob = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.aux1, a.out_bf ? (size_t)nbh * HW * 16 : 0);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      unsigned vo[4];
+      u32x4c hv[4], uv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int hb = (ct * MB + mb) * 4 + j;
+        vo[j] = pixi[nb] >= 0 ? ((unsigned)hb * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
+        hv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, (int)vo[j], 0, ESS_GRU_AUX);
+        uv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_u, (int)vo[j], 0, ESS_GRU_AUX);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      uint2 pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4c ov;
+        bf16x4 ob;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float o = ess_tanh(acc[mb][nb][4 * j + jj]);
+          const float hprev = __builtin_bit_cast(float, (unsigned)hv[j][jj]), u = __builtin_bit_cast(float, (unsigned)uv[j][jj]);
+          const float hn = hprev * (1.f - u) + o * u;
+          ov[jj] = __builtin_bit_cast(unsigned, hn);
+          ob[jj] = (__bf16)hn;
+        }
+        if (a.out) __builtin_amdgcn_raw_buffer_store_b128(ov, r_o, (int)vo[j], 0, ESS_GRU_AUX);  // (uniform)
+        pk[j] = __builtin_bit_cast(uint2, ob);
+      }
+      if (a.out_bf) {  // (uniform)
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[j].x, pk[j + 1].x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[j].y, pk[j + 1].y, false, false);
+          const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};
+          const unsigned o = pixi[nb] >= 0 ? ((unsigned)((ct * MB + mb) * 4 + j + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(vec, r_ob, (int)o, 0, ESS_GRU_AUX);
+        }
+      }
+    }
+}
+
 // Accumulators that START from the per-channel shift (bias): accumulator register r of 32-row block mb holds packed row
 // (r & 3) + 8 (r >> 2) + 4 half, so four float4 loads per block fill both pixel blocks.  The loads ride in the matrix waves' wait
 // for the first staged chunk; the epilogue then has no shift to fetch (in the LSTM epilogue that was one dependent round trip
@@ -941,8 +1046,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
 #endif
   }
   if constexpr (EPI == ESS_EPI_GRU_OUT) {
+#ifndef ESS_GRU_EPI_GENERAL
+    if (biased && a.fmt_res == ESS_FMT_F32_C8 && a.aux1 && (!a.out || a.fmt_out == ESS_FMT_F32_C8) && (a.hid % (32 * MB)) == 0) {  // (uniform)
+      conv_epilogue_gru_out_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      return;
+    }
+#endif
     conv_epilogue_gru_out<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
   } else if constexpr (EPI == ESS_EPI_GRU_UR) {
+#ifndef ESS_GRU_EPI_GENERAL
+    if (biased && a.out && !a.out2 && a.fmt_out == ESS_FMT_F32_C8 && (!a.aux0 || a.fmt_res == ESS_FMT_F32_C8) && (a.hid % (16 * MB)) == 0) {  // (uniform)
+      conv_epilogue_gru_ur_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      return;
+    }
+#endif
     conv_epilogue_gru_ur<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
     if constexpr (ALLOW8) {
