@@ -239,7 +239,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ y,
                                                         const u32x4n* __restrict__ dy, const float* __restrict__ stats,
                                                         double* sums, int hw, int nseg, int seg_stride, int CB, int C,
-                                                        int per_sample_stats, int relu, int relu_from_y) {
+                                                        int per_sample_stats, int relu, int relu_from_y,
+                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
   const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
   relu &= 0xff;
   __shared__ double redd[4 * 16];
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
   const int len = (hw + nsl - 1) / nsl;
   const int i0 = sl * len, i1 = min(hw, i0 + len);
   const int cb = g % CB;
-  float mean[8], rstd[8];
+  float mean[8], rstd[8], ma[8], mb[8];  // (ma, mb: the forward's affine map y = x ma + mb, for a ReLU mask recomputed from x)
+  const bool affine_mask = MODE == 1 && relu && !relu_from_y && gamma != nullptr;
   if (MODE == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -255,6 +257,11 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
       const size_t p = per_sample_stats ? (size_t)(g / CB) * C + c : (size_t)c;
       mean[j] = stats[2 * p];
       rstd[j] = stats[2 * p + 1];
+      ma[j] = mb[j] = 0.f;
+      if (affine_mask) {  // (the expressions of bn_apply_c8_kernel)
+        ma[j] = rstd[j] * gamma[c];
+        mb[j] = beta[c] - mean[j] * ma[j];
+      }
     }
   }
   double s0[8], s1[8];
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xh = (f[j] - mean[j]) * rstd[j];
-            const bool off = relu && (relu_from_y ? yy[j] <= 0.f : xh <= 0.f);
+            const bool off = relu && (relu_from_y ? yy[j] <= 0.f : (affine_mask ? f[j] * ma[j] + mb[j] <= 0.f : xh <= 0.f));
             const float gr = off ? 0.f : gg[j];
             s0[j] += gr;
             s1[j] += (double)gr * xh;
@@ -504,14 +511,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
                                                               const u32x4n* __restrict__ dy, const float* __restrict__ gamma,
                                                               const float* __restrict__ stats, const double* sums, int nsl,
                                                               u32x4n* __restrict__ dx, u32x4n* __restrict__ dres, float* dgamma,
-                                                              float* dbeta, int accumulate, int N, int CB, int C, int hw, int relu) {
+                                                              float* dbeta, int accumulate, int N, int CB, int C, int hw, int relu,
+                                                              const float* __restrict__ beta) {
   const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
   relu &= 0xff;
+  const bool mask_x = relu && beta != nullptr;  // the forward had no residual: y <= 0 <=> x a + b <= 0, y is not read
   const int g = blockIdx.x, cb = g % CB;
   const double cnt = (double)N * hw;
   double t0[8], t1[8];
   group_total8(sums, cb, nsl, t0, t1);
-  float mean[8], rstd[8], m1[8], m2[8], gr[8];
+  float mean[8], rstd[8], m1[8], m2[8], gr[8], ma[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cb * 8 + j < C ? cb * 8 + j : C - 1;
@@ -524,6 +533,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
     m1[j] = (float)(t0[j] / cnt);
     m2[j] = (float)(t1[j] / cnt);
     gr[j] = gamma[c] * rstd[j];
+    ma[j] = mb[j] = 0.f;
+    if (mask_x) {  // (the expressions of bn_apply_c8_kernel)
+      ma[j] = rstd[j] * gamma[c];
+      mb[j] = beta[c] - mean[j] * ma[j];
+    }
   }
   const size_t base = (size_t)g * hw;
   constexpr int U = 2;
@@ -534,8 +548,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
     for (int u = 0; u < U; ++u) {
       const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
       gv[u] = dy[base + ic];
-      if (relu) yv[u] = y[base + ic];
-      if (dx) xv[u] = x[base + ic];
+      if (relu && !mask_x) yv[u] = y[base + ic];
+      if (dx || mask_x) xv[u] = x[base + ic];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -543,14 +557,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
       if (ii >= hw) continue;
       float gg[8], yy[8], f[8];
       unpack8(gv[u], gg);
-      if (relu) {
+      if (dx || mask_x) unpack8x(xv[u], f, xf16);
+      if (mask_x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (f[j] * ma[j] + mb[j] <= 0.f) gg[j] = 0.f;
+      } else if (relu) {
         unpack8(yv[u], yy);
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (yy[j] <= 0.f) gg[j] = 0.f;
       }
       if (dres) dres[base + ii] = pack8n(gg);
       if (dx) {
-        unpack8x(xv[u], f, xf16);
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? gr[j] * (gg[j] - m1[j] - (f[j] - mean[j]) * rstd[j] * m2[j]) : 0.f;
         dx[base + ii] = pack8n(f);
@@ -662,11 +679,14 @@ extern "C" int ess_batchnorm_train_forward_c8(const void* x, const void* residua
   return ess_launch_status("batchnorm_train_forward_c8");
 }
 
-extern "C" int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma,
+extern "C" int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
                                                const float* stats, void* dx, void* d_residual, float* dgamma, float* dbeta,
                                                int32_t accumulate, int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16,
                                                void* workspace, size_t workspace_bytes, ess_stream_t stream) {
-  ESS_CHECK_ARG(x && y && dy && gamma && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_backward_c8: bad arguments");
+  // beta != NULL (with relu): the forward was relu(bn(x)) without a residual -- the mask is recomputed from x, y is not read
+  const bool mask_x = (relu & 1) && beta != nullptr;
+  ESS_CHECK_ARG(x && (y || mask_x || !(relu & 1)) && dy && gamma && stats && N > 0 && C > 0 && hw > 0, "batchnorm_train_backward_c8: bad arguments");
+  ESS_CHECK_ARG(!(mask_x && d_residual), "batchnorm_train_backward_c8: a residual gradient needs the mask of the saved output (beta must be NULL)");
   ESS_CHECK_ARG(al16(x, y, dy, dx, d_residual), "batchnorm_train_backward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
@@ -675,9 +695,9 @@ extern "C" int ess_batchnorm_train_backward_c8(const void* x, const void* y, con
   if (rc) return rc;
   const int nsl = split_for8(CB, hw);
   hipLaunchKernelGGL((c8_reduce_kernel<1>), dim3(CB, nsl), dim3(256), 0, st, (const u32x4n*)x, (const u32x4n*)y, (const u32x4n*)dy,
-                     stats, (double*)workspace, hw, N, CB, CB, C, 0, relu, 1);
+                     stats, (double*)workspace, hw, N, CB, CB, C, 0, relu, mask_x ? 0 : 1, mask_x ? gamma : nullptr, mask_x ? beta : nullptr);
   hipLaunchKernelGGL(bn_bwd_apply_c8_kernel, dim3(N * CB, chunks_for8(N * CB, hw)), dim3(256), 0, st, (const u32x4n*)x,
                      (const u32x4n*)y, (const u32x4n*)dy, gamma, stats, (const double*)workspace, nsl, (u32x4n*)dx,
-                     (u32x4n*)d_residual, dgamma, dbeta, accumulate, N, CB, C, hw, relu);
+                     (u32x4n*)d_residual, dgamma, dbeta, accumulate, N, CB, C, hw, relu, mask_x ? beta : nullptr);
   return ess_launch_status("batchnorm_train_backward_c8");
 }

@@ -2,6 +2,7 @@
 Autograd-aware wrappers over the HIP kernels (ess_amd.hip).  torch.autograd is used only as the tape:
 every forward and backward body is one or more libess_hip.so launches.
 """
+import os
 import weakref
 
 import torch
@@ -438,6 +439,9 @@ def instance_norm(x, residual=None, relu=False, eps=1e-5, x_f16=False):
     return InstanceNormFn.apply(x, residual, relu, eps, x_f16)
 
 
+_MASK_FROM_X = os.environ.get('ESS_BN_MASK_FROM_X', '1') != '0'  # (diagnostic switch: BatchNorm backward reads the mask from y)
+
+
 class BatchNormTrainFn(torch.autograd.Function):
     """y = act(BatchNorm_train(x) + residual), running stats updated in place (torchvision BasicBlock
     as used by StyleEncoderE2VID, models/style_networks.py:116-121); fp32 NCHW or BF16_C8 tensors."""
@@ -452,6 +456,7 @@ class BatchNormTrainFn(torch.autograd.Function):
             y, stats = hip.batchnorm_train_forward(x, residual, gamma.detach(), beta.detach(), running_mean, running_var,
                                                    momentum, eps, relu)
         ctx.relu = relu
+        ctx.has_res = residual is not None
         ctx.beta_ref = weakref.ref(beta)
         ctx.save_for_backward(x, y, gamma, stats)
         return y
@@ -464,7 +469,9 @@ class BatchNormTrainFn(torch.autograd.Function):
         beta = ctx.beta_ref()
         if _blocked(x):
             C = _channels(x)
-            bwd = lambda *a, **k: hip.batchnorm_train_backward_c8(x, C, *a, x_f16=ctx.x_f16, **k)  # noqa: E731
+            # relu(bn(x)) without a residual: the mask is recomputed from x in the kernels, y is not read (two tensor passes less)
+            mask_beta = beta.detach() if (ctx.relu and not ctx.has_res and beta is not None and _MASK_FROM_X) else None
+            bwd = lambda *a, **k: hip.batchnorm_train_backward_c8(x, C, *a, x_f16=ctx.x_f16, beta=mask_beta, **k)  # noqa: E731
         else:
             bwd = lambda *a, **k: hip.batchnorm_train_backward(x, *a, **k)  # noqa: E731
         # like the conv weight gradients: add straight into the leaves' .grad (views of the optimiser's flat buffer)

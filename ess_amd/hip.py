@@ -121,7 +121,7 @@ def lib():
             'ess_instnorm_forward_c8': [P, P, P, P, I, I, I, F, I, I, P, c_size_t, P],
             'ess_instnorm_backward_c8': [P, P, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, I, P, c_size_t, P],
-            'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, c_size_t, P],
+            'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, c_size_t, P],
             'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
             'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
@@ -429,14 +429,15 @@ def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, runnin
 
 
 def batchnorm_train_backward_c8(x, C, y, dy, gamma, stats, relu, need_dx=True, need_dres=False, dgamma=None, dbeta=None,
-                                accumulate=False, x_f16=False):
+                                accumulate=False, x_f16=False, beta=None):
+    """beta (with relu, a forward WITHOUT residual): the ReLU mask is recomputed from x, y is not read."""
     N, CB, H, W, _ = x.shape
     dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dx else None
     dres = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dres else None
     L = lib()
     xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
-    _check(L.ess_batchnorm_train_backward_c8(ptr(x, xdt), ptr(y, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(gamma),
+    _check(L.ess_batchnorm_train_backward_c8(ptr(x, xdt), ptr(y, torch.bfloat16), ptr(dy, torch.bfloat16), ptr(gamma), ptr(beta),
                                              ptr(stats), ptr(dx, torch.bfloat16), ptr(dres, torch.bfloat16), ptr(dgamma), ptr(dbeta),
                                              int(accumulate), N, C, H * W, int(relu), xf, c_void_p(ws.data_ptr()), c_size_t(ws.numel()),
                                              stream()), 'ess_batchnorm_train_backward_c8')

@@ -186,10 +186,13 @@ int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const fl
                                    float* running_mean, float* running_var, float momentum, float eps, void* y, float* stats,
                                    int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace,
                                    size_t workspace_bytes, ess_stream_t stream);
-int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma, const float* stats,
-                                    void* dx, void* d_residual, float* dgamma, float* dbeta, int32_t accumulate, int32_t N,
-                                    int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes,
-                                    ess_stream_t stream);
+int ess_batchnorm_train_backward_c8(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                                    const float* stats, void* dx, void* d_residual, float* dgamma, float* dbeta, int32_t accumulate,
+                                    int32_t N, int32_t C, int32_t hw, int32_t relu, int32_t x_f16, void* workspace,
+                                    size_t workspace_bytes, ess_stream_t stream);
+/* beta: NULL -- the ReLU mask is read from the saved output y (a forward with a residual).  Non-NULL with relu = 1 -- the forward was
+ * relu(bn(x)) without a residual: the mask is recomputed from x as (x a + b <= 0) with the forward's a = rstd gamma, b = beta - mean a,
+ * y is not read (may be NULL), d_residual must be NULL: two tensor passes less per launch.                                          */
 /* x_f16 = 1: x (the pre-normalisation tensor) is an ESS_FMT_F16_C8 tensor; every other tensor stays BF16_C8.          */
 
 /* BatchNorm2d, training mode (ResNet prefix of StyleEncoderE2VID, models/style_networks.py:116-121):

@@ -227,6 +227,14 @@ def test_batch_norm_train_c8(H, case):
     assert rel(dg.cpu(), gr.grad) < 5e-3 and rel(db.cpu(), br.grad) < 5e-3
     if has_res:
         assert rel(un8(H, dres8, C), rr.grad) < 5e-3
+    else:
+        # relu(bn(x)) without a residual: the mask recomputed from x (beta given, y not read) is the mask of the saved output
+        dg2, db2 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        dx2, _ = H.batchnorm_train_backward_c8(x8, C, None if relu else y8, c8(H, dy), gamma.cuda(), stats, relu, True, False, dg2, db2,
+                                               beta=beta.cuda())
+        assert torch.equal(dx2.view(torch.int16), dx8.view(torch.int16)) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        with pytest.raises(H.EssHipError):  # a residual gradient needs the saved output's mask
+            H.batchnorm_train_backward_c8(x8, C, y8, c8(H, dy), gamma.cuda(), stats, True, True, True, dg2, db2, beta=beta.cuda())
 
 
 # ------------------------------------------------------------------------------------------------ weight gradients
