@@ -297,7 +297,25 @@ def cpu_baseline(args):
     sample of the same workload -- B=1 sequence of the same T/C/HxW/K -- 2 warm-ups, median of 5 timed steps."""
     import statistics
     from oracle import ess_oracle as O
-    nthreads = torch.get_num_threads()
+    # pinned thread counts (round 3's baseline moved 2.4x between boxes of the pool with torch's defaults): intra-op threads =
+    # the cores this process may run on (affinity mask; half of them when SMT siblings are visible as separate CPUs), one
+    # inter-op thread; the spread of the timed steps is reported next to the median
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    smt = 1
+    try:
+        with open('/sys/devices/system/cpu/smt/active') as f:
+            smt = 2 if f.read().strip() == '1' else 1
+    except OSError:
+        pass
+    nthreads = max(1, int(os.environ.get('ESS_CPU_BASELINE_THREADS', avail // smt)))
+    torch.set_num_threads(nthreads)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass  # (already fixed by earlier parallel work in this process)
     B, T, C, H, W, K = 1, args.T, args.C, args.height, args.width, args.classes
     cfg = O.e2vid_config(num_bins=C)
     sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 1)
@@ -317,6 +335,8 @@ def cpu_baseline(args):
         times.append(time.perf_counter() - t0)
     t = statistics.median(times[warm:])
     return {'value': round(B * T / t, 3), 'unit': 'voxel_grids/s', 'cores': nthreads, 'kind': 'port',
+            's_per_step': {'min': round(min(times[warm:]), 3), 'median': round(t, 3), 'max': round(max(times[warm:]), 3)},
+            'threads': {'intra_op': nthreads, 'inter_op': torch.get_num_interop_threads(), 'cpus_available': avail, 'smt': smt},
             'sample': f'{args.trainer} step, B={B} sequence (T={T}, C={C}, {H}x{W}, K={K}), fp32 torch-CPU oracle doing the work as '
                       f'written by the reference (full UNet every time step' +
                       (', 5 decoder forwards' if args.trainer == 'ess' else '') +

@@ -1,5 +1,5 @@
-// Error reporting and version for libess_hip.so.  No mutable global state besides the thread-local
-// last-error buffer.
+// Error reporting and version for libess_hip.so.  No mutable global state besides the thread-local last-error buffer and the
+// memo of dynamic-LDS opt-ins already made with the runtime (below).
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -13,3 +13,18 @@ void ess_set_error(const char* fmt, ...) {
 
 extern "C" const char* ess_last_error(void) { return g_err; }
 extern "C" int ess_version(void) { return 100; }
+
+// ---- dynamic-LDS opt-in, once per (kernel, device): see ess_allow_lds in common.h
+#include <map>
+#include <mutex>
+#include <utility>
+void ess_allow_lds_impl(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> granted;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& g = granted[{kernel, dev}];
+  if (bytes <= g) return;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) g = bytes;
+}

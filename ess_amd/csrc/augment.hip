@@ -6,8 +6,11 @@
 // their magnitudes, the crop offset) are drawn on the host per sample and arrive as a parameter row; the per-pixel noise is a
 // counter-based hash of (seed, pixel) so that the oracle reproduces it.  albumentations and cv2 are third-party packages absent
 // from /root/reference and from this image: their interpolation arithmetic is restated (bilinear with zero border, sample
-// positions at pixel centres, round-half-up quantisation), i.e. PARITY UNPINNED against the libraries themselves; Perspective
-// and the Sharpen / Blur / MotionBlur group are not provided.
+// positions at pixel centres, round-half-up quantisation), i.e. PARITY UNPINNED against the libraries themselves.
+// Round 4: the rest of the pipeline as a second stage (`ess_augment_perspective_filter`, below): Perspective(p=0.2) ->
+// RandomBrightnessContrast -> OneOf(Sharpen, Blur(3), MotionBlur(3))(p=0.5) need the NEIGHBOURS of a pixel of the cropped, noisy
+// image, so they cannot ride in the first stage's single pass: stage 1 then runs with alpha = 1 / beta = 0 and no id table, stage
+// 2 applies them after the warp, in the reference's order.
 #include "common.h"
 
 namespace {
@@ -60,7 +63,125 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
   }
 }
 
+// ---- stage 2 ------------------------------------------------------------------------------------------------------------------
+// Parameter row (NP2 floats): [0] perspective fired; [1..9] the INVERSE homography (row-major; warped pixel (x, y) of the
+// max_w x max_h rectangle -> source position in the H x W image: what cv2.warpPerspective computes from the forward matrix);
+// [10] max_w, [11] max_h (the rectangle the quadrilateral is mapped to, albumentations Perspective with keep_size: the warp
+// is followed by a bilinear resize back to H x W); [12] alpha, [13] beta (brightness / contrast, beta in levels); [14] stencil
+// fired; [15..23] the 3 x 3 correlation kernel (Sharpen / box blur / motion-blur line, normalised by the host).
+constexpr int NP2 = 24;
+
+__device__ __forceinline__ float lvl(const float* __restrict__ img, int H, int W, int y, int x) {  // 0..255 level of a stage-1 pixel, zero border
+  return (y >= 0 && y < H && x >= 0 && x < W) ? floorf(img[(size_t)y * W + x] * 255.f + 0.5f) : 0.f;
+}
+
+// one pixel of cv2.warpPerspective(img, M, (max_w, max_h), INTER_LINEAR, BORDER_CONSTANT 0), restated in float arithmetic
+__device__ __forceinline__ float warp_px(const float* __restrict__ img, const float* __restrict__ m, int H, int W, int xi, int yi) {
+  const float X = (float)xi, Y = (float)yi;
+  const float w = m[6] * X + m[7] * Y + m[8];
+  const float iw = w != 0.f ? 1.f / w : 0.f;
+  const float u = (m[0] * X + m[1] * Y + m[2]) * iw, v = (m[3] * X + m[4] * Y + m[5]) * iw;
+  if (!(u > -1.f && u < (float)W && v > -1.f && v < (float)H)) return 0.f;
+  const float uf = floorf(u), vf = floorf(v);
+  const int x0 = (int)uf, y0 = (int)vf;
+  const float fx = u - uf, fy = v - vf;
+  const float top = lvl(img, H, W, y0, x0) * (1.f - fx) + lvl(img, H, W, y0, x0 + 1) * fx;
+  const float bot = lvl(img, H, W, y0 + 1, x0) * (1.f - fx) + lvl(img, H, W, y0 + 1, x0 + 1) * fx;
+  return floorf(top * (1.f - fy) + bot * fy + 0.5f);
+}
+
+// Perspective (warp to the max_w x max_h rectangle, bilinear resize back to H x W with cv2's pixel-centre convention and
+// replicated edges; label: nearest warp, nearest resize) + brightness / contrast -> levels (fp32 0..255), labels
+__global__ __launch_bounds__(256) void augment_warp_kernel(const float* __restrict__ img, const int64_t* __restrict__ lab,
+                                                           const float* __restrict__ params, float* __restrict__ mid,
+                                                           int64_t* __restrict__ out_lab, const int64_t* __restrict__ lut, int N, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+    const float* p = params + (size_t)n * NP2;
+    const float* im = img + (size_t)n * H * W;
+    float v;
+    int64_t l = 0;
+    if (p[0] != 0.f) {
+      const int mw = (int)p[10], mh = (int)p[11];
+      const float sx = ((float)x + 0.5f) * ((float)mw / (float)W) - 0.5f, sy = ((float)y + 0.5f) * ((float)mh / (float)H) - 0.5f;
+      float xf = floorf(sx), yf = floorf(sy);
+      float fx = sx - xf, fy = sy - yf;
+      int x0 = (int)xf, y0 = (int)yf;
+      if (x0 < 0) { x0 = 0; fx = 0.f; }
+      if (y0 < 0) { y0 = 0; fy = 0.f; }
+      if (x0 >= mw - 1) { x0 = mw - 1; fx = 0.f; }
+      if (y0 >= mh - 1) { y0 = mh - 1; fy = 0.f; }
+      const int x1 = x0 + 1 < mw ? x0 + 1 : mw - 1, y1 = y0 + 1 < mh ? y0 + 1 : mh - 1;
+      const float top = warp_px(im, p + 1, H, W, x0, y0) * (1.f - fx) + warp_px(im, p + 1, H, W, x1, y0) * fx;
+      const float bot = warp_px(im, p + 1, H, W, x0, y1) * (1.f - fx) + warp_px(im, p + 1, H, W, x1, y1) * fx;
+      v = floorf(top * (1.f - fy) + bot * fy + 0.5f);
+      if (lab) {
+        int xn = (int)floorf((float)x * ((float)mw / (float)W)), yn = (int)floorf((float)y * ((float)mh / (float)H));
+        xn = xn < mw - 1 ? xn : mw - 1; yn = yn < mh - 1 ? yn : mh - 1;
+        const float* m = p + 1;
+        const float w = m[6] * xn + m[7] * yn + m[8];
+        const float iw = w != 0.f ? 1.f / w : 0.f;
+        const int us = (int)floorf((m[0] * xn + m[1] * yn + m[2]) * iw + 0.5f), vs = (int)floorf((m[3] * xn + m[4] * yn + m[5]) * iw + 0.5f);
+        if (us >= 0 && us < W && vs >= 0 && vs < H) l = lab[((size_t)n * H + vs) * W + us];
+      }
+    } else {
+      v = lvl(im, H, W, y, x);
+      if (lab) l = lab[i];
+    }
+    mid[i] = floorf(fminf(fmaxf(p[12] * v + p[13], 0.f), 255.f) + 0.5f);
+    if (out_lab) out_lab[i] = lut ? lut[l < 0 ? 0 : (l > 255 ? 255 : l)] : l;
+  }
+}
+
+// cv2.filter2D / cv2.blur with a 3 x 3 kernel on the uint8 image: correlation, BORDER_REFLECT_101, result rounded to the
+// nearest level with ties to even (cvRound) and saturated; identity when the group did not fire; ToTensor (/255)
+__global__ __launch_bounds__(256) void augment_stencil_kernel(const float* __restrict__ mid, const float* __restrict__ params,
+                                                              float* __restrict__ out, int N, int H, int W) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / ((int64_t)W * H));
+    const float* p = params + (size_t)n * NP2;
+    const float* im = mid + (size_t)n * H * W;
+    float v = im[(size_t)y * W + x];
+    if (p[14] != 0.f) {
+      float acc = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        int yy = y + ky - 1;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * H - 2 - yy : yy);
+        yy = yy < 0 ? 0 : yy;  // (H == 1)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          int xx = x + kx - 1;
+          xx = xx < 0 ? -xx : (xx >= W ? 2 * W - 2 - xx : xx);
+          xx = xx < 0 ? 0 : xx;
+          acc += p[15 + ky * 3 + kx] * im[(size_t)yy * W + xx];
+        }
+      }
+      v = rintf(fminf(fmaxf(acc, 0.f), 255.f));
+    }
+    out[i] = v * (1.f / 255.f);
+  }
+}
+
 }  // namespace
+
+extern "C" int ess_augment_perspective_filter(const float* img, const int64_t* label, const float* params, const int64_t* id_lut,
+                                              float* scratch, float* out_img, int64_t* out_label, int32_t N, int32_t H, int32_t W,
+                                              ess_stream_t stream) {
+  ESS_CHECK_ARG(img && params && scratch && out_img && N > 0 && H > 0 && W > 0, "augment_perspective_filter: bad arguments");
+  ESS_CHECK_ARG((label == nullptr) == (out_label == nullptr), "augment_perspective_filter: label and out_label come together");
+  ESS_CHECK_ARG(scratch != img && scratch != out_img && img != out_img, "augment_perspective_filter: img, scratch and out_img must be distinct buffers");
+  const int64_t total = (int64_t)N * H * W;
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(augment_warp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, label, params, scratch,
+                     out_label, id_lut, N, H, W);
+  hipLaunchKernelGGL(augment_stencil_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)scratch, params,
+                     out_img, N, H, W);
+  return ess_launch_status("augment_perspective_filter");
+}
 
 extern "C" int ess_augment_image_label(const float* img, const int64_t* label, const float* params, const int64_t* id_lut,
                                        float* out_img, int64_t* out_label, int32_t N, int32_t H_src, int32_t W_src, int32_t H,

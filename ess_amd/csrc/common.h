@@ -30,9 +30,13 @@ static inline int ess_launch_status(const char* what) {
 }
 
 // dynamic LDS above 64 KiB must be opted into per kernel (up to the 160 KiB of a CDNA4 CU)
+// (the attribute is per kernel function and device and only ever needs raising: it is set ONCE per (kernel, device, size
+// class) -- a mutex-guarded table lookup per launch instead of a runtime call; the table is a cache of what the runtime was
+// told, not state a caller can observe)
+void ess_allow_lds_impl(const void* kernel, size_t bytes);
 template <typename K>
 static inline void ess_allow_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > 64 * 1024) ess_allow_lds_impl((const void*)kernel, bytes);
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_bf16_stem7_kernel(const ConvKArgs a,
               typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
               f16x4 h;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) h[i] = (_Float16)q[i];
+              for (int i = 0; i < 4; ++i) h[i] = ess_f16_sat(q[i]);
               pk[jj] = __builtin_bit_cast(uint2, h);
             } else {
               bf16x4 b;

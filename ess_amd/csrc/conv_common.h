@@ -59,6 +59,9 @@ constexpr unsigned ESS_OOB = 0x80000000u;
 __device__ __forceinline__ ess_rsrc ess_make_rsrc(const void* p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)bytes, 0x00020000);
 }
+// fp32 -> IEEE half for the F16_C8 pre-norm tensors, SATURATING: a plain cast turns |v| > 65504 into +-inf, the norm's statistics
+// into NaN and with them the whole channel (BF16_C8 and the reference's fp32 have ~3e38 of range); one v_med3_f32 per element
+__device__ __forceinline__ _Float16 ess_f16_sat(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 __device__ __forceinline__ float ess_bload(ess_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
@@ -649,7 +652,7 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             f16x4 h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[nb][i];
+            for (int i = 0; i < 4; ++i) h[i] = ess_f16_sat(v[nb][i]);
             pk[jj][nb] = __builtin_bit_cast(uint2, h);
           } else {
             bf16x4 b;
@@ -766,7 +769,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
           if constexpr (F16) {
             f16x4 h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = (_Float16)v[i];
+            for (int i = 0; i < 4; ++i) h[i] = ess_f16_sat(v[i]);
             pk[jj][nb] = __builtin_bit_cast(uint2, h);
           } else {
             bf16x4 b;
@@ -1226,6 +1229,7 @@ inline Geom choose_geom(const EssConvDesc* d) {
   Geom best{};
   double best_cost = 1e300;
   const int KS = d->ksize, S = d->stride;
+  static const char* const force_geom = getenv("ESS_CONV_GEOM");  // (read once, not per candidate and launch)
   for (int bwl = 5; bwl >= 3; --bwl) {
     for (int wxl = 0; wxl <= 2; ++wxl) {
       const int BW = 1 << bwl, RB = 32 >> bwl;
@@ -1233,7 +1237,7 @@ inline Geom choose_geom(const EssConvDesc* d) {
       const int tx = ceil_div(d->W_out, TW), ty = ceil_div(d->H_out, TH);
       const int IH = (TH - 1) * S + KS, IW = (TW - 1) * S + KS;
       if (IH * IW > stage_kpc(KS, S) * 256) continue;  // would not fit the staging registers
-      { const char* e = getenv("ESS_CONV_GEOM"); if (e && (e[0] - '0' != bwl || e[1] - '0' != wxl)) continue; }  // tuning hook
+      if (force_geom && (force_geom[0] - '0' != bwl || force_geom[1] - '0' != wxl)) continue;  // tuning hook
       // pooled output: with 32-wide pixel blocks the vertical partner of a pixel is in the same lane (conv_epilogue_pool)
       if (d->act == ESS_ACT_SUMPOOL2 && d->W_out >= 32 && bwl != 5) continue;
       // padded MACs (dominant) + a small halo/staging term + a coalescing term: a tile row is one contiguous run of the

@@ -307,6 +307,22 @@ __global__ __launch_bounds__(256) void argmax_conf_kernel(const float* __restric
       if (hist[i]) atomicAdd(conf + i, (unsigned long long)hist[i]);
 }
 
+// confusion histogram of GIVEN predictions (evaluation/metrics.py:4-24: bincount of label * K + prediction over the
+// non-ignored pixels): the same LDS-privatised histogram as above without the argmax
+__global__ __launch_bounds__(256) void label_conf_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ lab,
+                                                         unsigned long long* conf, size_t total, int K, int ignore) {
+  extern __shared__ unsigned int hist[];  // K*K
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int64_t l = lab[i], q = pred[i];
+    if (l != ignore && l >= 0 && l < K && q >= 0 && q < K) atomicAdd(&hist[l * K + q], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K; i += blockDim.x)
+    if (hist[i]) atomicAdd(conf + i, (unsigned long long)hist[i]);
+}
+
 inline unsigned wave_uniform_grid(size_t total, int cap) {
   // blocks of 256 threads such that grid*256 divides the work into equal trip counts where possible
   size_t g = (total + 255) / 256;
@@ -429,4 +445,13 @@ extern "C" int ess_argmax_confusion(const float* logits, const int64_t* labels, 
   hipLaunchKernelGGL(argmax_conf_kernel, dim3(wave_uniform_grid((size_t)N * hw, 1024)), dim3(256), K * K * sizeof(unsigned),
                      (hipStream_t)stream, logits, labels, pred_lbl, (unsigned long long*)conf, N, K, hw, ignore_index);
   return ess_launch_status("argmax_confusion");
+}
+
+extern "C" int ess_label_confusion(const int64_t* pred_lbl, const int64_t* labels, int64_t* conf, int64_t total, int32_t K,
+                                   int32_t ignore_index, ess_stream_t stream) {
+  ESS_CHECK_ARG(pred_lbl && labels && conf && total > 0 && K > 0, "label_confusion: bad arguments");
+  ESS_CHECK_ARG(K <= 64, "label_confusion: K=%d too large", K);
+  hipLaunchKernelGGL(label_conf_kernel, dim3(wave_uniform_grid((size_t)total, 1024)), dim3(256), K * K * sizeof(unsigned),
+                     (hipStream_t)stream, pred_lbl, labels, (unsigned long long*)conf, (size_t)total, K, ignore_index);
+  return ess_launch_status("label_confusion");
 }

@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
       mean[j] = stats[2 * p];
       rstd[j] = stats[2 * p + 1];
       ma[j] = mb[j] = 0.f;
-      if (affine_mask) {  // (the expressions of bn_apply_c8_kernel)
-        ma[j] = rstd[j] * gamma[c];
-        mb[j] = beta[c] - mean[j] * ma[j];
+      if (affine_mask) {  // (the forward's own map, saved by bn_apply_c8_kernel behind the C (mean, rstd) pairs)
+        ma[j] = stats[2 * (C + c)];
+        mb[j] = stats[2 * (C + c) + 1];
       }
     }
   }
@@ -468,6 +468,9 @@ __global__ __launch_bounds__(256) void bn_apply_c8_kernel(const u32x4n* __restri
     const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
     if (g < CB && blockIdx.y == 0 && threadIdx.x == 0 && cb * 8 + j < C) {
       stats[2 * c] = mean; stats[2 * c + 1] = rstd;
+      // the affine map y = x a + b of THIS forward, for the backward's ReLU mask and dx scale: a later in-place change of
+      // gamma / beta (an optimiser writing through raw pointers bumps no version counter) cannot reach it
+      stats[2 * (C + c)] = rstd * gamma[c]; stats[2 * (C + c) + 1] = beta[c] - mean * (rstd * gamma[c]);
       if (running_mean) {
         const double unb = cnt > 1 ? var * cnt / (cnt - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -532,11 +535,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
     }
     m1[j] = (float)(t0[j] / cnt);
     m2[j] = (float)(t1[j] / cnt);
-    gr[j] = gamma[c] * rstd[j];
+    gr[j] = stats[2 * (C + c)];  // = gamma * rstd as the forward used it (saved map, see bn_apply_c8_kernel)
     ma[j] = mb[j] = 0.f;
-    if (mask_x) {  // (the expressions of bn_apply_c8_kernel)
-      ma[j] = rstd[j] * gamma[c];
-      mb[j] = beta[c] - mean[j] * ma[j];
+    if (mask_x) {
+      ma[j] = stats[2 * (C + c)];
+      mb[j] = stats[2 * (C + c) + 1];
     }
   }
   const size_t base = (size_t)g * hw;

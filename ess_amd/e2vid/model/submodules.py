@@ -213,22 +213,30 @@ class TransposedConvLayer(nn.Module):
             self.norm_layer = nl
         self._fold = _Fold()
 
-    def forward(self, x):
+    def forward(self, x, x1=None):
+        """x1: a second source -- the layer acts on the channel concat (x, x1) (skip_type 'concat'), read by the kernel's
+        two-source loader, both zero-inserted while staged: the concatenated tensor never exists."""
         _inference_only(x)
         _check_eval(self, self.norm)
         t = self.transposed_conv2d
         N, C, H, W = x.shape
+        C1 = 0 if x1 is None else x1.shape[1]
+        if x1 is not None and (x1.shape[0], x1.shape[2], x1.shape[3]) != (N, H, W):
+            raise hip.EssHipError('TransposedConvLayer: the two sources of a concat disagree on batch / extent')
         k, p = t.kernel_size[0], t.padding[0]
         if k != 2 * p + 1:
             raise hip.EssHipError('TransposedConvLayer: only k = 2p+1 geometries (output = 2x input) are supported')
-        spec = hip.conv_spec(N, 2 * H, 2 * W, C, 0, t.out_channels, k, 1, k - 1 - p, hip.SRC_ZERO_UP2,
-                             act=_ACT[self.activation])
+        spec = hip.conv_spec(N, 2 * H, 2 * W, C, C1, t.out_channels, k, 1, k - 1 - p, hip.SRC_ZERO_UP2,
+                             hip.SRC_ZERO_UP2 if x1 is not None else hip.SRC_DIRECT, act=_ACT[self.activation])
         scale, shift = self._fold.get(spec, t.bias, self.norm, getattr(self, 'norm_layer', None))
         out = torch.empty(N, t.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
-        return hip.conv_forward(spec, x, None, packed_weight(spec, t.weight, kind=hip.W_TRANSPOSED), scale, shift, out=out)
+        return hip.conv_forward(spec, x, x1, packed_weight(spec, t.weight, kind=hip.W_TRANSPOSED), scale, shift, out=out)
 
     def forward_sum(self, x, skip):
         return self.forward(hip.add(x, skip))
+
+    def forward_cat(self, x, skip):
+        return self.forward(x.contiguous(), skip.contiguous())
 
 
 class UpsampleConvLayer(nn.Module):

@@ -52,9 +52,7 @@ class BaseUNet(nn.Module):
         kw = {'c8_only': True} if c8_only else {}
         if self.skip_type == 'sum':
             return decoder.forward_sum(x, skip, **kw)
-        if hasattr(decoder, 'forward_cat'):
-            return decoder.forward_cat(x, skip, **kw)
-        return decoder(torch.cat([x, skip], dim=1))
+        return decoder.forward_cat(x, skip, **kw)  # (both decoder kinds read the concat through the kernel's two-source loader)
 
     def _tail(self, x, blocks, head):
         # bf16 arithmetic with upsample-conv decoders: the resblock outputs and every decoder output but the last are consumed by

@@ -53,7 +53,12 @@ class StreamingReconstructor:
 
     update(event_tensor [1, num_bins, H, W] or [num_bins, H, W]) -> (image [1, 1, H, W], latent dict) ; reset() drops the state."""
 
-    def __init__(self, model, height, width, options, device=None, graph=False):
+    def __init__(self, model, height, width, options, device=None, graph=False, copy=True):
+        """copy (graph mode): update() returns CLONES of the captured graph's static output buffers, like the eager path's fresh
+        tensors -- a caller that keeps frames across windows (the reference script's writer / display queue) must not see them
+        overwritten by the next replay.  copy=False hands out the static buffers themselves (70 KB - 1 MB less traffic per
+        window; valid until the next update())."""
+        self.copy_outputs = bool(copy)
         self.device = device if device is not None else torch.device('cuda:0')
         self.model = model.to(self.device).eval()
         self.rec = ImageReconstructor(self.model, height, width, model.num_bins, self.device, options)
@@ -89,7 +94,14 @@ class StreamingReconstructor:
         self._in.copy_(ev, non_blocking=True)
         self._g.replay()
         self.n_windows += 1
-        return self._out_img, self._out_latent
+        if not self.copy_outputs:
+            return self._out_img, self._out_latent
+        lat = self._out_latent
+        if isinstance(lat, dict):
+            lat = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in lat.items()}
+        elif torch.is_tensor(lat):
+            lat = lat.clone()
+        return self._out_img.clone(), lat
 
     # ---- hipGraph mode: static input, static state buffers; one recorded window = step + state carry
     def _state_tensors(self, states):

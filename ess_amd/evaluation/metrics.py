@@ -5,19 +5,16 @@ from .. import hip
 
 
 def semseg_compute_confusion(y_hat_lbl, y_lbl, num_classes, ignore_label):
-    """conf[label, prediction] as int64 (reference :4-24), via one histogram kernel instead of masked bincount."""
+    """conf[label, prediction] as int64 (reference :4-24), via one histogram kernel over the two label maps instead of a masked
+    bincount (no one-hot tensor: `ess_label_confusion`)."""
     assert torch.is_tensor(y_hat_lbl) and torch.is_tensor(y_lbl), 'Inputs must be torch tensors'
     assert y_lbl.device == y_hat_lbl.device, 'Input tensors have different device placement'
     if y_hat_lbl.dim() == 4:
         y_hat_lbl = y_hat_lbl.squeeze(1)
     if y_lbl.dim() == 4:
         y_lbl = y_lbl.squeeze(1)
-    # one-hot "logits" of the given predictions feed the fused argmax/confusion kernel
-    N, H, W = y_hat_lbl.shape
-    logits = torch.zeros(N, num_classes, H, W, dtype=torch.float32, device=y_lbl.device)
-    logits.scatter_(1, y_hat_lbl.long().unsqueeze(1), 1.0)
     conf = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=y_lbl.device)
-    hip.argmax_confusion(logits, y_lbl.long().contiguous(), conf, ignore_label, want_pred=False)
+    hip.label_confusion(y_hat_lbl.long().contiguous(), y_lbl.long().contiguous(), conf, ignore_label)
     return conf
 
 

@@ -223,6 +223,9 @@ class ForkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        # unused aliases (e.g. the image task backward consumes pred[1] only) must arrive as None in backward, not as
+        # materialised zero tensors: a zero fill plus an add pass per unused fork otherwise
+        ctx.set_materialize_grads(False)
         return tuple(x.detach() for _ in range(n))
 
     @staticmethod
@@ -414,7 +417,8 @@ class InstanceNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, relu, eps, x_f16=False):
-        """x_f16: x is an F16_C8 tensor (the producing convolution was asked for PRE_NORM storage)"""
+        """x_f16: x is an F16_C8 tensor (the producing convolution was asked for PRE_NORM storage; the tensor's own tag decides)"""
+        x_f16 = bool(x_f16) or hip.is_f16_c8(x)
         if _blocked(x):
             y, stats = hip.instnorm_forward_c8(x, _channels(x), residual, relu, eps, x_f16)
         else:
@@ -448,6 +452,7 @@ class BatchNormTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, x_f16=False):
+        x_f16 = bool(x_f16) or hip.is_f16_c8(x)
         ctx.x_f16 = x_f16
         if _blocked(x):
             y, stats = hip.batchnorm_train_forward_c8(x, _channels(x), residual, gamma.detach(), beta.detach(), running_mean,

@@ -45,6 +45,7 @@ EXPORTS = [
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
     'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices', 'ess_sum_scalars',
+    'ess_label_confusion', 'ess_augment_perspective_filter',
 ]
 
 
@@ -247,6 +248,10 @@ def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=No
     LSTM epilogue: out_fmt / aux_fmt FMT_F32_C8: out, out2 / aux0 are fp32 [N][hid/8][H][W][8] state tensors (f32_c8_empty);
     out_bf: additionally receives `out` in that format (the frozen encoder's staging copies);
     out_fmt FMT_BF16_C8: `out` / `out2` (and `residual`, if any) ARE BF16_C8 tensors, no fp32 tensor is written."""
+    if is_f16_c8(src0) or is_f16_c8(src1) or is_f16_c8(residual):
+        raise EssHipError('conv_forward: an F16_C8 (pre-norm) tensor is read by the norm kernels only, not as a BF16_C8 source / residual')
+    if out_fmt == FMT_F16_C8 and not is_f16_c8(out):
+        raise EssHipError('conv_forward: an F16_C8 output must come from f16_c8_empty (the tag is how its consumers know the format)')
     sdt = torch.bfloat16 if src_fmt == FMT_BF16_C8 else torch.float32
     odt = torch.bfloat16 if out_fmt in (FMT_BF16_C8, FMT_F16_C8) else torch.float32  # (an F16_C8 tensor travels in a bfloat16-typed container: see f16_c8_empty)
     rdt = torch.bfloat16 if out_fmt in (FMT_BF16_C8, FMT_F16_C8) else torch.float32  # (an F16_C8 output takes a BF16_C8 residual)
@@ -290,6 +295,8 @@ def to_bf16_c8(x):
 def from_bf16_c8(y, C):
     """BF16_C8 -> fp32 NCHW on the device (exact)."""
     N, nb, H, W, _ = y.shape
+    if is_f16_c8(y):
+        raise EssHipError('from_bf16_c8: the tensor holds IEEE half elements (F16_C8): use f16_c8_to_float')
     if not 0 < C <= nb * 8:
         raise EssHipError(f'from_bf16_c8: {C} channels do not fit {nb} blocks')
     x = torch.empty(N, C, H, W, dtype=torch.float32, device=y.device)
@@ -307,7 +314,14 @@ def f16_c8_empty(N, C, H, W, device):
     BF16_C8 layout, read by the norm kernels only).  The container is a BFLOAT16-typed torch tensor on purpose: autograd casts a
     gradient to the dtype of the tensor it belongs to, and the gradient of a pre-norm tensor is a BF16_C8 tensor -- a float16-typed
     container would make the engine insert dtype casts.  The format travels as an explicit flag (conv out_fmt, norm x_f16)."""
-    return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+    t = torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+    t.ess_f16 = True  # (python attribute: survives autograd.Function outputs; `is_f16_c8` reads it, the BF16_C8 consumers refuse it)
+    return t
+
+
+def is_f16_c8(t):
+    """Was `t` created by f16_c8_empty (IEEE half elements in a bfloat16-typed BF16_C8-shaped container)?"""
+    return t is not None and getattr(t, 'ess_f16', False)
 
 
 def f16_c8_to_float(t, C):
@@ -417,7 +431,7 @@ def instnorm_backward_c8(x, C, dy, stats, relu, x_f16=False):
 def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, x_f16=False):
     N, CB, H, W, _ = x.shape
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    stats = torch.empty(C, 2, dtype=torch.float32, device=x.device)
+    stats = torch.empty(2, C, 2, dtype=torch.float32, device=x.device)  # (mean, rstd) pairs, then the forward's (a, b) map
     L = lib()
     xdt, xf = torch.bfloat16, int(bool(x_f16))
     ws = workspace(L.ess_norm_workspace_c8(CB), x.device, 'norm8')
@@ -430,7 +444,10 @@ def batchnorm_train_forward_c8(x, C, residual, gamma, beta, running_mean, runnin
 
 def batchnorm_train_backward_c8(x, C, y, dy, gamma, stats, relu, need_dx=True, need_dres=False, dgamma=None, dbeta=None,
                                 accumulate=False, x_f16=False, beta=None):
-    """beta (with relu, a forward WITHOUT residual): the ReLU mask is recomputed from x, y is not read."""
+    """beta (with relu, a forward WITHOUT residual): the ReLU mask is recomputed from x with the affine map the forward saved
+    in `stats` (the pointer only selects the form; gamma / beta may have changed since the forward), y is not read."""
+    if stats.numel() != 4 * C:
+        raise EssHipError(f'batchnorm_train_backward_c8: stats must be the forward\'s [2, C, 2] tensor, got {tuple(stats.shape)}')
     N, CB, H, W, _ = x.shape
     dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dx else None
     dres = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if need_dres else None
@@ -641,6 +658,23 @@ def augment_image_label(img, label, params, height, width, id_lut=None):
     return out, out_l
 
 
+def augment_perspective_filter(img, label, params, id_lut=None):
+    """Second augmentation stage (ess_augment_perspective_filter): Perspective, brightness / contrast, the Sharpen / Blur /
+    MotionBlur stencil.  img fp32 [N, 1, H, W] in [0, 1] (stage 1's output), label int64 [N, H, W] raw ids or None, params fp32
+    [N, 24] (datasets/augment.py draws them) -> (fp32 [N, 1, H, W], int64 [N, H, W])."""
+    N, _, H, W = img.shape
+    if params.shape != (N, 24):
+        raise EssHipError('augment_perspective_filter: params must be [N, 24]')
+    if id_lut is not None and id_lut.numel() < 256:
+        raise EssHipError('augment_perspective_filter: id_lut must have 256 entries')
+    scratch = torch.empty(N, H, W, dtype=torch.float32, device=img.device)
+    out = torch.empty(N, 1, H, W, dtype=torch.float32, device=img.device)
+    out_l = torch.empty(N, H, W, dtype=torch.int64, device=img.device) if label is not None else None
+    _check(lib().ess_augment_perspective_filter(ptr(img), ptr(label, torch.int64), ptr(params), ptr(id_lut, torch.int64), ptr(scratch),
+                                                ptr(out), ptr(out_l, torch.int64), N, H, W, stream()), 'ess_augment_perspective_filter')
+    return out, out_l
+
+
 def radam_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step_size, n_sma_ge5):
     _check(lib().ess_radam_step(ptr(p), ptr(g), ptr(exp_avg), ptr(exp_avg_sq), p.numel(), c_float(lr), c_float(beta1),
                                 c_float(beta2), c_float(eps), c_float(step_size), int(n_sma_ge5), stream()),
@@ -662,6 +696,16 @@ def resize_nearest(x, size):
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
     _check(lib().ess_resize_nearest(ptr(x), ptr(y), N * C, h, w, H, W, stream()), 'ess_resize_nearest')
     return y
+
+
+def label_confusion(pred, labels, conf, ignore_index=255):
+    """conf[label, pred] += 1 over labels != ignore_index, for given int64 predictions (no argmax)."""
+    if pred.shape != labels.shape or pred.dtype != torch.int64 or labels.dtype != torch.int64:
+        raise EssHipError(f'label_confusion: int64 tensors of one shape expected, got {pred.dtype}{tuple(pred.shape)} / {labels.dtype}{tuple(labels.shape)}')
+    if pred.numel():
+        _check(lib().ess_label_confusion(ptr(pred, torch.int64), ptr(labels, torch.int64), ptr(conf, torch.int64),
+                                         c_int64(pred.numel()), conf.shape[0], int(ignore_index), stream()), 'ess_label_confusion')
+    return conf
 
 
 def argmax_confusion(logits, labels=None, conf=None, ignore_index=255, want_pred=True):

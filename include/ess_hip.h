@@ -174,8 +174,10 @@ int ess_instnorm_backward(const float* x, const float* dy, const float* stats, f
                           int32_t hw, int32_t relu, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 
 /* ---- the same norms on BF16_C8 tensors (bfloat16 [N][ceil(C/8)][hw][8]; bf16 configuration: the stored form of the trainable
- * networks' activations and activation gradients).  fp32 arithmetic and statistics; stats: fp32 [N*C][2] (InstanceNorm) /
- * [C][2] (BatchNorm) = (mean, rstd).  relu: 0 / 1 as above.  workspace: ess_norm_workspace_c8(N*ceil(C/8)) (InstanceNorm) /
+ * networks' activations and activation gradients).  fp32 arithmetic and statistics; stats: fp32 [N*C][2] (InstanceNorm) =
+ * (mean, rstd); BatchNorm: fp32 [2][C][2] = C pairs (mean, rstd) followed by C pairs (a, b), the affine map y = x a + b the
+ * forward applied (a = rstd gamma, b = beta - mean a): the backward takes its dx scale and -- beta != NULL -- its ReLU mask from
+ * that saved map, never from the live gamma / beta.  relu: 0 / 1 as above.  workspace: ess_norm_workspace_c8(N*ceil(C/8)) (InstanceNorm) /
  * ess_norm_workspace_c8(ceil(C/8)) (BatchNorm) bytes.                                                          */
 size_t ess_norm_workspace_c8(int32_t groups);
 int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C, int32_t hw,
@@ -287,6 +289,18 @@ int ess_augment_image_label(const float* img, const int64_t* label, const float*
                             int64_t* out_label, int32_t N, int32_t H_src, int32_t W_src, int32_t H, int32_t W,
                             ess_stream_t stream);
 
+/* second stage of the same pipeline (datasets/cityscapes_loader.py:45-57): A.Perspective(p=0.2) -- the homography of a jittered
+ * quadrilateral onto a max_w x max_h rectangle (bilinear, constant-0 border; label nearest) followed by the resize back to
+ * H x W (keep_size) --, then RandomBrightnessContrast, then A.OneOf([Sharpen, Blur(3), MotionBlur(3)], p=0.5) as one 3 x 3
+ * correlation with BORDER_REFLECT_101, rounded to nearest-even like cv2.filter2D; ToTensor.  When this stage follows, stage 1 runs
+ * with alpha = 1, beta = 0 and id_lut = NULL (the id -> trainId table is applied here, after the geometry, as the reference does).
+ * img: fp32 [N][1][H][W] in [0,1] (stage 1's output, levels / 255); label (nullable): int64 [N][H][W] raw ids;
+ * params: fp32 [N][24] = perspective fired, inverse homography (9, row-major: rectangle pixel -> source position), max_w, max_h,
+ * alpha, beta (levels), stencil fired, 3 x 3 kernel (9); scratch: fp32 [N][H][W]; out_img: fp32 [N][1][H][W]; out_label int64. */
+int ess_augment_perspective_filter(const float* img, const int64_t* label, const float* params, const int64_t* id_lut,
+                                   float* scratch, float* out_img, int64_t* out_label, int32_t N, int32_t H, int32_t W,
+                                   ess_stream_t stream);
+
 /* TaskLoss = Dice + CrossEntropy (utils/loss_functions.py:6-24,96-135), forward AND gradient w.r.t.
  * logits in one pass pair.  logits [N][K][H][W], labels int64 [N][H][W].  loss: 1 float.
  * dlogits (nullable): d(loss*loss_scale)/dlogits.  workspace: ess_task_loss_workspace(K) bytes.     */
@@ -328,6 +342,11 @@ int ess_resize_nearest(const float* x, float* y, int32_t planes, int32_t H_in, i
  * pred_lbl (nullable): int64 [N][H][W]; conf: int64 [K][K], accumulated (conf[label][pred]).         */
 int ess_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pred_lbl, int64_t* conf,
                          int32_t N, int32_t K, int32_t hw, int32_t ignore_index, ess_stream_t stream);
+
+/* confusion-matrix accumulation from GIVEN predictions (evaluation/metrics.py:4-24, semseg_compute_confusion): pred_lbl,
+ * labels int64 [total]; conf int64 [K][K] accumulated (conf[label][pred]) over labels != ignore_index.          */
+int ess_label_confusion(const int64_t* pred_lbl, const int64_t* labels, int64_t* conf, int64_t total, int32_t K,
+                        int32_t ignore_index, ess_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,11 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group(backend=os.environ.get('ESS_DIST_BACKEND', 'gloo'))
     from ess_amd import hip
-    shape = (2, 3, 2, 96, 128, 11)
+    # 'full': the config-3 shape (DSEC, T = 5, 2 x 480 x 640, K = 11) with B = 4 per rank -- capture-pool memory, the 3-graph split
+    # and `_graph_adopt_packed` at the size the bench runs; fewer steps
+    full = len(sys.argv) > 3 and sys.argv[3] == 'full'
+    shape = (4, 5, 2, 480, 640, 11) if full else (2, 3, 2, 96, 128, 11)
+    n_steps = 2 if full else 4
     runs = []
     for graph in (False, True):
         tr = _trainer(kind, mode, shape)
@@ -38,7 +42,7 @@ def main():
             tr.train_step(b0)
         hist, grads, weights = [], [], []
         opt = tr.optimizers_dict['optimizer_back']
-        for s in range(4):
+        for s in range(n_steps):
             losses, _, final = tr.train_step(_batch(kind, shape, 301 + s + 50 * rank))
             hist.append({k: v.item() for k, v in losses.items()} | {'final': final.item()})
             torch.cuda.synchronize()
@@ -65,6 +69,9 @@ def main():
     dist.broadcast(other, src=0)
     same_across = bool(torch.equal(flat, other))
     hip.set_compute('fp32')
+    finite = all(all(v == v and abs(v) < 1e30 for v in h.values()) for h in h0 + h1)
+    ok = ok and finite
+    print(f'RANK{rank} peak_memory_GiB {torch.cuda.max_memory_allocated() / 2 ** 30:.2f} losses_finite {finite} shape {shape}', flush=True)
     print(f'RANK{rank} eager~graph {ok} (grads {grads_ok}, first-step weights {w_first}, first-step losses {h0[0] == h1[0]}, '
           f'max loss rel diff {l_rel:.2e}, max weight diff {w_last:.2e}) ranks_agree {same_across}', flush=True)
     dist.destroy_process_group()

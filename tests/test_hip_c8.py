@@ -233,8 +233,54 @@ def test_batch_norm_train_c8(H, case):
         dx2, _ = H.batchnorm_train_backward_c8(x8, C, None if relu else y8, c8(H, dy), gamma.cuda(), stats, relu, True, False, dg2, db2,
                                                beta=beta.cuda())
         assert torch.equal(dx2.view(torch.int16), dx8.view(torch.int16)) and torch.equal(dg2, dg) and torch.equal(db2, db)
+        # scale and mask come from the affine map the forward saved in `stats`: parameters rewritten in place between forward
+        # and backward (the flat RAdam kernel writes through raw pointers, no version counter moves) must not change a bit
+        gam_d, bet_d = gamma.cuda(), beta.cuda()
+        gam_d.mul_(-1.75), bet_d.add_(3.0)
+        dg3, db3 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        dx3, _ = H.batchnorm_train_backward_c8(x8, C, None if relu else y8, c8(H, dy), gam_d, stats, relu, True, False, dg3, db3, beta=bet_d)
+        assert torch.equal(dx3.view(torch.int16), dx8.view(torch.int16)) and torch.equal(dg3, dg) and torch.equal(db3, db)
         with pytest.raises(H.EssHipError):  # a residual gradient needs the saved output's mask
             H.batchnorm_train_backward_c8(x8, C, y8, c8(H, dy), gamma.cuda(), stats, True, True, True, dg2, db2, beta=beta.cuda())
+
+
+def test_pre_norm_f16_saturates(H):
+    """F16_C8 pre-norm storage (ESS_FMT_F16_C8) must not overflow: |v| > 65504 is stored as +-65504, not +-inf -- an inf would turn
+    the following norm's statistics (and with them the whole channel, and its gradients) into NaN, a failure mode the BF16_C8 /
+    fp32 storage of the same tensor does not have.  Pre-norm values around 1e5: finite output, and the InstanceNorm of the F16_C8
+    tensor agrees with the InstanceNorm of the BF16_C8 one (`ESS_PRE_NORM_F16=0` storage) wherever nothing saturated."""
+    H.set_compute('bf16')
+    try:
+        dev = 'cuda'
+        g = torch.Generator(device=dev).manual_seed(5)
+        N, C, Hh, Ww = 2, 64, 24, 32
+        x = torch.randn(N, C, Hh, Ww, device=dev, generator=g)
+        w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+        b = torch.zeros(C, device=dev)
+        scale = torch.ones(C, device=dev)
+        scale[: C // 2] = 1e5  # the first half of the channels overflows IEEE half, the rest is ordinary
+        spec = H.conv_spec(N, Hh, Ww, C, 0, C, 3, 1, 1)
+        pw, pb = H.pack_weights(spec, w * scale.view(-1, 1, 1, 1)), H.pack_rows(spec, b)
+        x8 = H.to_bf16_c8(x)
+        o16 = H.f16_c8_empty(N, C, Hh, Ww, dev)
+        H.conv_forward(spec, x8, None, pw, None, pb, out=o16, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F16_C8)
+        o8 = H.bf16_c8_empty(N, C, Hh, Ww, dev)
+        H.conv_forward(spec, x8, None, pw, None, pb, out=o8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_BF16_C8)
+        v16, v8 = H.f16_c8_to_float(o16, C), H.from_bf16_c8(o8, C)
+        assert torch.isfinite(v16).all()
+        assert v16.abs().max().item() == 65504.0 and v8.abs().max().item() > 1e5  # the fixture does exceed the half range
+        sat = v8.abs() > 65504
+        assert torch.equal(v16[sat], torch.sign(v8[sat]) * 65504.0)
+        y16, st16 = H.instnorm_forward_c8(o16, C, None, True, x_f16=True)
+        y8, _ = H.instnorm_forward_c8(o8, C, None, True)
+        assert torch.isfinite(st16).all() and torch.isfinite(H.from_bf16_c8(y16, C)).all()
+        lo = slice(C // 2, C)  # channels without saturation: the two storages agree to bf16 / half rounding of the pre-norm values
+        d = (H.from_bf16_c8(y16, C)[:, lo] - H.from_bf16_c8(y8, C)[:, lo]).abs().max().item()
+        assert d < 5e-2, d
+        dy = H.to_bf16_c8(torch.randn(N, C, Hh, Ww, device=dev, generator=g))
+        assert torch.isfinite(H.from_bf16_c8(H.instnorm_backward_c8(o16, C, dy, st16, True, x_f16=True), C)).all()
+    finally:
+        H.set_compute('fp32')
 
 
 # ------------------------------------------------------------------------------------------------ weight gradients

@@ -842,6 +842,69 @@ def test_augment_image_label_vs_oracle(H, shape):
     assert torch.equal(l2.cpu(), rl2) and torch.equal((o2.cpu() * 255).round(), (r2 * 255).round())
 
 
+@pytest.mark.parametrize('hw', [(200, 352), (64, 96), (33, 47)])
+def test_augment_perspective_filter_vs_oracle(H, hw):
+    """SURVEY 8(f)4, second stage (datasets/cityscapes_loader.py:45-57): Perspective (homography warp onto the max_w x max_h rectangle
+    + resize back, bilinear image / nearest label), brightness / contrast, the Sharpen / Blur(3) / MotionBlur(3) stencil with
+    reflect-101 borders, id table -- against the oracle's restatement on the same parameter rows; then the whole two-stage pipeline
+    through DeviceAugmentation.  Labels exact except where a warped coordinate sits within fp32 noise of a .5 boundary (the host
+    draws the matrix in fp64, both sides evaluate it in fp32); image levels equal up to such ties."""
+    from ess_amd.datasets.augment import DeviceAugmentation, draw_params, draw_params2, perspective_matrix, _line3
+    Ho, Wo = hw
+    N = 8
+    g = torch.Generator().manual_seed(Ho * 3 + Wo)
+    img01 = torch.randint(0, 256, (N, 1, Ho, Wo), generator=g).float() / 255.0
+    # smooth label regions (a nearest-sampled label map of noise would turn every coordinate tie into a mismatch)
+    lab = (torch.arange(Ho).view(1, Ho, 1) // 7 + torch.arange(Wo).view(1, 1, Wo) // 9 + torch.arange(N).view(N, 1, 1)) % 34
+    lut = torch.full((256,), 255, dtype=torch.int64)
+    lut[:34] = torch.randint(0, 11, (34,), generator=g)
+    p2 = draw_params2(N, (Ho, Wo), g)
+    # make sure every branch is exercised whatever the draws were
+    pts = [[0.07 * Wo, 0.04 * Ho], [0.95 * Wo, 0.08 * Ho], [0.91 * Wo, 0.93 * Ho], [0.03 * Wo, 0.97 * Ho]]
+    minv, mw, mh = perspective_matrix(pts, Ho, Wo)
+    p2[0, 0], p2[0, 1:10], p2[0, 10], p2[0, 11] = 1.0, minv, mw, mh
+    p2[1, 12:14] = torch.tensor([1.15, -20.0])
+    a, light = 0.35, 0.8
+    k = torch.full((3, 3), -a); k[1, 1] = (1 - a) + a * (8 + light)
+    p2[2, 14], p2[2, 15:24] = 1.0, k.reshape(9)
+    p2[3, 14], p2[3, 15:24] = 1.0, torch.full((9,), 1.0 / 9.0)
+    ln = _line3(0, 0, 2, 1)
+    p2[4, 14], p2[4, 15:24] = 1.0, (ln / ln.sum()).reshape(9)
+    p2[5, 0], p2[5, 1:10], p2[5, 10], p2[5, 11] = 1.0, minv, mw, mh          # perspective AND stencil AND contrast on one sample
+    p2[5, 12:14] = torch.tensor([0.9, 11.0])
+    p2[5, 14], p2[5, 15:24] = 1.0, k.reshape(9)
+    ref_img, ref_lab = O.augment_perspective_filter(img01, lab, p2, lut)
+    out, out_l = H.augment_perspective_filter(dev(img01), dev(lab), dev(p2), dev(lut))
+    assert (out_l.cpu() != ref_lab).float().mean().item() < 1e-3
+    lv, lr = (out.cpu() * 255).round(), (ref_img * 255).round()
+    diff = (lv - lr).abs()
+    assert (diff > 1).float().mean().item() < 1e-4 and (diff > 0).float().mean().item() < 5e-3, \
+        ((diff > 1).float().mean().item(), (diff > 0).float().mean().item())
+    assert out.min().item() >= 0 and out.max().item() <= 1
+    # identity rows leave image and labels alone
+    ident = draw_params2(N, (Ho, Wo), g)
+    ident[:, 0], ident[:, 14] = 0.0, 0.0
+    o2, l2 = H.augment_perspective_filter(dev(img01), dev(lab), dev(ident), None)
+    assert torch.equal(l2.cpu(), lab) and torch.equal((o2.cpu() * 255).round(), (img01 * 255).round())
+    # the samples that were hit did change, the geometry is a zoom into the quadrilateral (no zero border appears)
+    assert (lv[0] != (img01[0] * 255).round()).float().mean().item() > 0.5
+    # the whole pipeline (stage 1 + stage 2) through the host class, against the two oracle stages on the same draws
+    Hs, Ws = Ho + 24, Wo + 40
+    src = torch.randint(0, 256, (N, Hs, Ws), generator=g).float()
+    slab = (torch.arange(Hs).view(1, Hs, 1) // 5 + torch.arange(Ws).view(1, 1, Ws) // 11).expand(N, Hs, Ws) % 34
+    aug = DeviceAugmentation(Ho, Wo, id_lut=lut, seed=11)
+    got, got_l = aug(dev(src), dev(slab))
+    gen = torch.Generator().manual_seed(11)
+    p1 = draw_params(N, (Hs, Ws), (Ho, Wo), 0.1, gen)
+    q2 = draw_params2(N, (Ho, Wo), gen, alpha_beta=p1[:, 8:10].clone())
+    p1[:, 8], p1[:, 9] = 1.0, 0.0
+    m_img, m_lab = O.augment_image_label(src, slab, p1, Ho, Wo, None)
+    r_img, r_lab = O.augment_perspective_filter(m_img, m_lab, q2, lut)
+    assert (got_l.cpu() != r_lab).float().mean().item() < 2e-3
+    d = ((got.cpu() * 255).round() - (r_img * 255).round()).abs()
+    assert (d > 0).float().mean().item() < 2e-2 and (d > 2).float().mean().item() < 2e-3
+
+
 @pytest.mark.parametrize('case', [(2, 2, 32, 37, 70, 1, 'fp32'), (1, 2, 32, 64, 96, 1, 'c8'), (2, 1, 32, 33, 41, 0, 'both'),
                                   (1, 2, 24, 40, 64, 1, 'c8'), (1, 2, 64, 35, 33, 1, 'both'), (2, 2, 20, 16, 31, 0, 'fp32'),
                                   (1, 5, 32, 44, 64, 1, 'c8'), (2, 5, 32, 37, 70, 1, 'both'), (1, 3, 32, 22, 36, 0, 'fp32'), (1, 4, 40, 33, 41, 1, 'both')])

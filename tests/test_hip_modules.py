@@ -77,6 +77,36 @@ def test_e2vid_sequence_vs_golden(golden, idx):
     assert torch.equal(img2, img) and all(torch.equal(lat2[k], latent[k]) for k in latent)
 
 
+@pytest.mark.parametrize('upsample', [True, False])
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_e2vid_concat_skips_vs_oracle(upsample, mode):
+    """skip_type='concat' (reference e2vid/model/unet.py:61-75 with torch.cat): both decoder kinds read the concat through the
+    conv kernel's two-source loader (bilinear / zero-insert per source) -- no concatenated tensor.  Checked against the oracle's
+    torch.cat form (the goldens hold skip_type='sum' only: this configuration is oracle-checked, not reference-pinned)."""
+    from ess_amd import hip
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.options.inference_options import default_options
+    B, T, C, H, W = 2, 3, 2, 32, 48
+    cfg = O.e2vid_config(num_bins=C, skip_type='concat', use_upsample_conv=upsample)
+    sd = O.synth_state_dict(O.e2vid_param_shapes(cfg), 77)
+    ev, _, _, _ = O.synth_batch(B, T, C, H, W, 6, seed=5)
+    img_o, _, lat_o = O.reconstruct_sequence(sd, cfg, ev, T)
+    hip.set_compute(mode)
+    try:
+        model = _e2vid(cfg, sd)
+        rec = ImageReconstructor(model, H, W, C, torch.device('cuda:0'), default_options())
+        rec.last_states_for_each_channel = {'grayscale': None}
+        evd = ev.cuda()
+        for t in range(T):
+            img, _, latent = rec.update_reconstruction(evd[:, t * C:(t + 1) * C])
+        tol = 1e-4 if mode == 'fp32' else 3e-2
+        assert relerr(img, img_o) < tol
+        for k in lat_o:
+            assert relerr(latent[k], lat_o[k]) < tol, k
+    finally:
+        hip.set_compute('fp32')
+
+
 @pytest.mark.parametrize('idx', range(3))
 def test_semseg_vs_golden(golden, idx):
     from ess_amd.models.style_networks import SemSegE2VID
@@ -639,6 +669,56 @@ def test_concat_conv_first_source_only_gradient():
         assert relerr(a.grad, torch.nn.functional.avg_pool2d(up.grad, 2) * 4) < 1e-4, it
         w.grad.copy_(gw)
         opt.step()  # rewrites w behind autograd's back: the cached slice and packed layouts must follow
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('owned', [True, False])
+def test_conv_bias_gradient_without_norm(mode, owned):
+    """The bias gradient of the decoder's convolutions, which every train-step comparison skips (`noise_key`: ahead of an
+    InstanceNorm it is mathematically zero, so any implementation returns rounding noise there).  Here the SAME module code path
+    (Fn.conv2d / Fn.conv2d_passthrough as ReLUINSConv2d / INSResBlock call them, reference models/style_networks.py:158-193) runs
+    with NO norm behind it, so weight AND bias gradients are real and are compared with torch's; `owned`: the parameters belong to
+    one of our RAdam optimisers (gradients accumulated straight into .grad by the weight-gradient launch) or not (returned to
+    autograd)."""
+    from ess_amd import functional as Fn, hip
+    from ess_amd.utils import radam
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17)
+    N, Cin, Cout, H, W = 2, 32, 48, 20, 24
+    w0 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b0 = torch.randn(Cout, generator=g)
+    x0 = torch.randn(N, Cin, H, W, generator=g)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    hip.set_compute(mode)
+    try:
+        c8 = mode == 'bf16'
+        rnd = (lambda t: t.bfloat16().float()) if c8 else (lambda t: t)
+        for passthrough in (False, True):
+            w = torch.nn.Parameter(w0.clone().cuda())
+            b = torch.nn.Parameter(b0.clone().cuda())
+            if owned:
+                opt = radam.RAdam([w, b], lr=1e-3)
+                opt.zero_grad()
+            x = x0.cuda().requires_grad_(True)
+            xin = Fn.as_c8(x) if c8 else x
+            if passthrough:
+                y, skip = Fn.conv2d_passthrough(xin, w, b, 1, 1)
+                y = y + 0 * skip if not c8 else y  # (fp32: keep the second output in the graph; BF16_C8: torch ops do not apply)
+            else:
+                y = Fn.conv2d(xin, w, b, 1, 1)
+            gyd = hip.to_bf16_c8(gy.cuda()) if c8 else gy.cuda()
+            y.backward(gyd)
+            # reference on the operands as the mode rounds them (bf16: x, w and the output gradient are bf16 values)
+            xr = rnd(x0).requires_grad_(True)
+            wr = rnd(w0).requires_grad_(True)
+            br = b0.clone().requires_grad_(True)
+            F.conv2d(xr, wr, br, padding=1).backward(rnd(gy))
+            tol = 2e-3 if c8 else 1e-4
+            assert relerr(b.grad, br.grad) < tol, (passthrough, 'bias')
+            assert relerr(w.grad, wr.grad) < tol, (passthrough, 'weight')
+            assert relerr(x.grad, xr.grad) < (2e-2 if c8 else 1e-4), (passthrough, 'input')
+    finally:
+        hip.set_compute('fp32')
 
 
 @pytest.mark.parametrize('shape', [(2, 5, 2, 48, 64), (3, 4, 5, 40, 56), (1, 3, 2, 22, 36)])

@@ -60,6 +60,7 @@ def test_streaming_reconstructor_eager_graph_and_reference_loop(rtype, mode):
         rec = ImageReconstructor(model(), H, W, C, torch.device('cuda:0'), default_options())
         rec.last_states_for_each_channel = {'grayscale': None}
         states = None
+        held = []  # graph-mode outputs kept across windows: update() must hand out copies, not the replay's static buffers
         for rep in range(2):
             for i, win in enumerate(iter_windows_fixed_size(ev, per)):
                 # (ONE grid for both: the voting kernel adds with fp32 atomics, two builds may differ in the last bit)
@@ -69,6 +70,7 @@ def test_streaming_reconstructor_eager_graph_and_reference_loop(rtype, mode):
                 img_g, lat_g = graph.update(grid_d)
                 assert torch.equal(img_e, img_g), (rep, i)
                 assert all(torch.equal(lat_e[k], lat_g[k]) for k in (1, 2, 4, 8)), (rep, i)
+                held.append((img_e, img_g, lat_e[8], lat_g[8]))
                 if rep == 0:
                     grid = O.events_to_voxel_grid(win, C, W, H)[None]
                     img_r, _, _ = rec.update_reconstruction(grid.cuda())
@@ -78,6 +80,8 @@ def test_streaming_reconstructor_eager_graph_and_reference_loop(rtype, mode):
                             img_o, states, _ = O.e2vid_step(sd, cfg, O.event_normalize(grid), states)
                         assert (img_o - img_e.cpu()).abs().max().item() < 1e-4, i
             assert eager.n_windows == graph.n_windows == n_win
+            assert all(torch.equal(a, b) and torch.equal(c, d) for a, b, c, d in held)  # frames of earlier windows are intact
+            assert len({t[1].data_ptr() for t in held}) == len(held)
             eager.reset()
             graph.reset()
     finally:

@@ -390,6 +390,54 @@ def test_augmentation_params_and_oracle_semantics():
     assert torch.equal((out[:, 0] * 255).round(), img.flip(-1)) and torch.equal(ol, lab.flip(-1))
 
 
+def test_augmentation_second_stage_params_and_oracle_semantics():
+    """SURVEY 8(f)4, second stage host side: Perspective fires with p = 0.2 and its inverse homography maps the rectangle's corners
+    back onto the jittered quadrilateral; OneOf fires with p = 0.5 and its kernels are the three the reference configures
+    (Sharpen sums to 1 + alpha (lightness - 1), box = 1/9, motion-blur lines normalised, 2-3 cells); the oracle's identity row is
+    the identity, a box blur of a constant image is that constant, a centred-quadrilateral warp keeps the image centre."""
+    from oracle import ess_oracle as O
+    from ess_amd.datasets.augment import draw_params2, perspective_matrix, _line3
+    g = torch.Generator().manual_seed(1)
+    H, W = 120, 160
+    p = draw_params2(3000, (H, W), g)
+    assert 0.17 < p[:, 0].mean() < 0.23 and 0.46 < p[:, 14].mean() < 0.54
+    k = p[p[:, 14] > 0][:, 15:24]
+    assert ((k.sum(1) - 1).abs() < 1e-5).float().mean() > 0.6  # box and motion kernels sum to 1 exactly, Sharpen to 1 + a*light
+    sharp = k[(k[:, 0] < 0)]
+    assert len(sharp) > 300 and (sharp[:, 0] <= -0.2).all() and (sharp[:, 0] >= -0.5).all()
+    light = (sharp.sum(1) - 1) / (-sharp[:, 0]) + 1  # rows sum to (1 - a) + a * (8 + lightness) - 8 a = 1 + a * (lightness - 1)
+    assert (light >= 0.5 - 1e-4).all() and (light <= 1.0 + 1e-4).all()
+    motion = k[(k[:, 0] >= 0) & ((k - 1.0 / 9).abs().max(1).values > 1e-6)]
+    cells = (motion > 0).sum(1)
+    assert len(motion) > 300 and ((cells == 2) | (cells == 3)).all()
+    pr = p[p[:, 0] > 0]
+    assert (pr[:, 10] <= 1.05 * W).all() and (pr[:, 10] >= 0.5 * W).all() and (pr[:, 11] <= 1.05 * H).all() and (pr[:, 11] >= 0.5 * H).all()
+    # inverse homography: rectangle corners -> the (ordered) quadrilateral
+    pts = [[10.0, 6.0], [150.0, 9.0], [146.0, 112.0], [5.0, 116.0]]
+    minv, mw, mh = perspective_matrix(pts, H, W)
+    m = minv.double().view(3, 3)
+    for (x, y), q in zip([(0, 0), (mw, 0), (mw, mh), (0, mh)], pts):
+        v = m @ torch.tensor([x, y, 1.0], dtype=torch.float64)
+        assert abs(v[0] / v[2] - q[0]) < 1e-3 and abs(v[1] / v[2] - q[1]) < 1e-3
+    assert _line3(0, 0, 2, 1).tolist() == [[1, 1, 0], [0, 0, 1], [0, 0, 0]] and _line3(2, 1, 0, 0).tolist() == _line3(0, 0, 2, 1).tolist()
+    assert _line3(1, 0, 1, 2).tolist() == [[0, 1, 0], [0, 1, 0], [0, 1, 0]] and _line3(0, 2, 2, 0).tolist() == [[0, 0, 1], [0, 1, 0], [1, 0, 0]]
+    # oracle semantics
+    img = torch.randint(0, 256, (2, 1, 12, 16)).float() / 255
+    lab = torch.randint(0, 34, (2, 12, 16))
+    ident = draw_params2(2, (12, 16), g)
+    ident[:, 0], ident[:, 14] = 0, 0
+    out, ol = O.augment_perspective_filter(img, lab, ident)
+    assert torch.equal((out * 255).round(), (img * 255).round()) and torch.equal(ol, lab)
+    box = ident.clone()
+    box[:, 14], box[:, 15:24] = 1, 1.0 / 9
+    const = torch.full((2, 1, 12, 16), 77 / 255.0)
+    assert ((O.augment_perspective_filter(const, None, box)[0] * 255).round() == 77).all()
+    # reflect-101 border of the box blur: a horizontal ramp keeps its interior mean, the first column sees (1, 0, 1)
+    ramp = (torch.arange(16).float() * 3).view(1, 1, 1, 16).expand(1, 1, 12, 16).contiguous() / 255
+    rb = (O.augment_perspective_filter(ramp, None, box[:1])[0] * 255).round()
+    assert rb[0, 0, 5, 7].item() == 21 and rb[0, 0, 5, 0].item() == 2
+
+
 def test_header_enums_match_the_binding():
     """Every enumerator of include/ess_hip.h that ess_amd/hip.py mirrors (ESS_X = n <-> hip.X) carries the same value."""
     header = open(os.path.join(ROOT, 'include', 'ess_hip.h')).read()
