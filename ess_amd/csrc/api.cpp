@@ -28,3 +28,17 @@ void ess_allow_lds_impl(const void* kernel, size_t bytes) {
   if (bytes <= g) return;
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) g = bytes;
 }
+
+// ---- tuning switches (process-wide; every setting gives identical results -- they choose between kernels of equal arithmetic)
+#include <string.h>
+namespace essconv { void set_wide_mode(int m); int wide_mode(); }
+extern "C" int ess_tuning_set(const char* key, int32_t value) {
+  if (key && !strcmp(key, "conv_wide")) { essconv::set_wide_mode(value); return ESS_OK; }
+  ess_set_error("tuning_set: unknown key '%s'", key ? key : "(null)");
+  return ESS_EINVAL;
+}
+extern "C" int ess_tuning_get(const char* key, int32_t* value) {
+  if (key && value && !strcmp(key, "conv_wide")) { *value = essconv::wide_mode(); return ESS_OK; }
+  ess_set_error("tuning_get: unknown key '%s'", key ? key : "(null)");
+  return ESS_EINVAL;
+}

@@ -9,6 +9,7 @@
 // Staging is software-pipelined: the global loads of chunk i+1 are issued before the MFMA phase of chunk i and
 // written to LDS after it, so HBM/L2 latency hides under the matrix work (one LDS buffer, two barriers per chunk).
 #include "conv_bf16_common.h"
+#include <atomic>
 
 namespace {
 
@@ -147,6 +148,66 @@ int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds,
   return ess_launch_status("pack_weights_multi");
 }
 
+// ---- wide-tile kernel (conv_bf16_wide.hip): chosen per launch by round count.
+// Mode: ESS_CONV_WIDE = 0 off | 1 by the cost model (default) | 2 whenever a variant applies; `ess_tuning_set("conv_wide", v)`
+// changes it at run time (tests compare the two kernels in one process: their results are bit-identical, both accumulate
+// chunk by chunk, tap by tap in the same order).
+static std::atomic<int> g_wide_mode{-1};
+int wide_mode() {
+  int m = g_wide_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("ESS_CONV_WIDE");
+    m = e ? atoi(e) : 1;
+    g_wide_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+void set_wide_mode(int m) { g_wide_mode.store(m < 0 ? 0 : m, std::memory_order_relaxed); }
+
+namespace {
+// Relative launch time in units of (output channel x pixel) per CU, from the round-3 wall-clock stamps: two
+// co-resident 64 x 256 tiles of the ws kernel take 33.8 us, a lone one 18.8 (0.56 of a round); the wide kernel runs one tile per CU
+// and round.  kappa scales the wide kernel's per-unit time against the ws kernel's (measured, ESS_WIDE_KAPPA).
+double std_cost(int tiles, int cot, int per_cu) {
+  const int slots = 256 * per_cu;
+  const int full = tiles / slots, rem = tiles % slots;
+  const double tail = rem == 0 ? 0.0 : (rem * 2 <= slots ? 0.56 : 1.0);
+  return (full + tail) * per_cu * cot * 256.0;
+}
+struct WidePick { int mbw, cw, th, tiles_x, tiles_y, tiles; };
+bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
+  const int mode = wide_mode();
+  if (!mode || !c8 || a.fmt_out != ESS_FMT_BF16_C8 || d->epilogue != ESS_EPI_LINEAR || a.out_bf) return false;
+  const bool relu = d->act == ESS_ACT_RELU, res = a.residual != nullptr;
+  if (!(d->act == ESS_ACT_NONE || relu)) return false;
+  if (a.out_f16 && (relu || res)) return false;
+  if (d->out_split > 0 && (relu || res || a.out_f16 || (d->out_split & 15) || a.scale)) return false;  // (conv_epilogue_c8_dgrad's form)
+  // kappa: margin the wide kernel must win by.  Measured (tools/wide_probe.py, B = 8): per unit of work and round it runs exactly
+  // as fast as the ws kernel (256 -> 256 @ 60 x 80: model 52.7 -> 42.2 us, measured 50.7 -> 42.4), but with one workgroup per CU
+  // its epilogue is exposed in multi-round launches: at model parity (two rounds against 2.34) it measures 4-18 % slower.
+  static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA"); return e ? atof(e) : 1.12; }();
+  const int mb = pl.cout_tile / 32;
+  const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
+  const double c_std = std_cost(std_tiles, pl.cout_tile, 2);
+  const int cands[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  double best = 1e300;
+  for (const auto& c : cands) {
+    const int mbw = c[0], cw = c[1], cot = mbw * cw * 32;
+    if ((mb == 2) != (cot >= 64) || mb > 2) continue;             // reads the plan's own weight pack (64- / 32-channel slabs)
+    if (d->C_out % cot) continue;                                 // every channel of a workgroup's tile is real
+    if (d->out_split > 0 && (d->out_split % (mbw * 32))) continue;  // (a wave's block pairs never straddle the split: % 16 above)
+    int th, tw;
+    conv_bf16_wide_tile(mbw, cw, &th, &tw);
+    const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
+    const int tiles = tx * ty * (d->C_out / cot) * d->N;
+    const double cost = kappa * ceil_div(tiles, 256) * (double)cot * th * tw;
+    if (cost < best) { best = cost; *out = WidePick{mbw, cw, th, tx, ty, tiles}; }
+  }
+  if (best >= 1e300) return false;
+  return mode >= 2 || best < c_std;
+}
+}  // namespace
+
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st) {
   ESS_CHECK_ARG(g.IH * g.IW <= kpc(d->ksize, d->stride) * 256, "conv(bf16): input tile of %d positions exceeds the staging capacity",
                 g.IH * g.IW);
@@ -184,6 +245,14 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   }
   if (ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
+    WidePick wp;
+    if (wide_pick(d, pl, g, a, c8, &wp)) {
+      ConvKArgs t = a;
+      t.tiles_x = wp.tiles_x; t.n_tiles = wp.tiles_x * wp.tiles_y;
+      t.persist = wp.tiles > 256 ? 1 : 0;
+      conv_bf16_launch_wide(wp.mbw, wp.cw, dim3((unsigned)(wp.tiles > 256 ? 256 : wp.tiles)), st, t);
+      return ess_launch_status("conv2d_forward(bf16, wide tile)");
+    }
     if (lds2 <= 160 * 1024) {
       // persistent launch when the grid exceeds one resident set of workgroups (2 per CU by registers -- 1 for the 128-row
       // instance -- and by LDS): see the tile schedule in conv_bf16_ws.hip.  ESS_WS_PERSIST=0: one workgroup per tile (tuning).

@@ -512,15 +512,15 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
 // (r & 3) + 8 (r >> 2) + 4 half, so four float4 loads per block fill both pixel blocks.  The loads ride in the matrix waves' wait
 // for the first staged chunk; the epilogue then has no shift to fetch (in the LSTM epilogue that was one dependent round trip
 // per 32-row block in front of the gate arithmetic).
-template <int MB>
-__device__ __forceinline__ void conv_bias_init(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int half) {
+template <int MB, int NB>
+__device__ __forceinline__ void conv_bias_init(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int half) {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 v = *(const float4*)(a.shift + ct * (MB * 32) + mb * 32 + 8 * g + 4 * half);
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) { acc[mb][nb][4 * g] = v.x; acc[mb][nb][4 * g + 1] = v.y; acc[mb][nb][4 * g + 2] = v.z; acc[mb][nb][4 * g + 3] = v.w; }
+      for (int nb = 0; nb < NB; ++nb) { acc[mb][nb][4 * g] = v.x; acc[mb][nb][4 * g + 1] = v.y; acc[mb][nb][4 * g + 2] = v.z; acc[mb][nb][4 * g + 3] = v.w; }
     }
 }
 
@@ -688,9 +688,9 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
 // straight-line code: the general function spends 2.5-4 k cycles per 32-channel block in uniform branches, channel masks and
 // selects (cycle stamps, round 3: 7.3-8.5 k cycles per 64 x 64 tile of a bias-only layer with nothing to load), this one is
 // per block 64 optional v_max, 32 packed conversions, 8 half-wave swaps and four 16-byte stores.
-template <int MB, bool SC, bool SH, bool F16, bool RELU, bool RES>
-__device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                       int x, int y0, const int (&ly)[NBW]) {
+template <int MB, bool SC, bool SH, bool F16, bool RELU, bool RES, int NB>
+__device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
+                                                       int x, int y0, const int (&ly)[NB]) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
@@ -699,9 +699,9 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
   const int nblk = a.Cout >> 3;
   const ess_rsrc r_o = ess_make_rsrc((const char*)a.out + (size_t)n * nblk * HW * 16, (size_t)nblk * HW * 16);
   const ess_rsrc r_rs = ess_make_rsrc((const char*)(RES ? a.residual : a.out) + (size_t)n * nblk * HW * 16, RES ? (size_t)nblk * HW * 16 : 0);
-  unsigned pix16[NBW];
+  unsigned pix16[NB];
 #pragma unroll
-  for (int nb = 0; nb < NBW; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     const int y = y0 + ly[nb];
     pix16[nb] = ((y < a.Hout) & (x < a.Wout)) ? (unsigned)(y * a.Wout + x) * 16u : ESS_OOB;
   }
@@ -709,7 +709,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
   for (int mb = 0; mb < MB; ++mb) {
     const int rowbase = ct * COT + mb * 32;
     float4 scv[4], shv[4];
-    u32x4e rva[2][NBW];  // residual vectors of this lane's two store blocks (block pair jp: block jp + half), per pixel block
+    u32x4e rva[2][NB];  // residual vectors of this lane's two store blocks (block pair jp: block jp + half), per pixel block
     if constexpr (SC || SH || RES) {
       asm volatile("" ::: "memory");  // (one block's vectors at a time, see above)
 #pragma unroll
@@ -722,7 +722,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) {
+          for (int nb = 0; nb < NB; ++nb) {
             const unsigned pl = (unsigned)((rowbase >> 3) + 2 * jh + half) * HW * 16u;
             rva[jh][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, (int)(pix16[nb] != ESS_OOB ? pl + pix16[nb] : ESS_OOB), 0, 0);
           }
@@ -730,11 +730,11 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
     }
 #pragma unroll
     for (int jp = 0; jp < 4; jp += 2) {
-      uint2 pk[2][NBW];
-      uint2 rr[2][NBW];  // residual, exchanged to the accumulator layout: [block of the pair][pixel block] = this lane's 4 channels
+      uint2 pk[2][NB];
+      uint2 rr[2][NB];  // residual, exchanged to the accumulator layout: [block of the pair][pixel block] = this lane's 4 channels
       if constexpr (RES) {
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           const u32x4e rv = rva[jp >> 1][nb];
           const auto s0 = __builtin_amdgcn_permlane32_swap(rv[0], rv[2], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(rv[1], rv[3], false, false);
@@ -746,7 +746,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
       for (int jj = 0; jj < 2; ++jj) {
         const int j = jp + jj;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = acc[mb][nb][4 * j + i];
@@ -781,7 +781,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
       }
       const unsigned plane = (unsigned)((rowbase >> 3) + jp + half) * HW * 16u;
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
         const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
@@ -794,10 +794,10 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
 // The data-gradient forms as straight-line code: an optional second output (out_split, a multiple of 16 channels so that a
 // block pair never straddles it) and / or a 2x2-sum-pooled first output with 32-wide pixel blocks (the two pixel blocks of a
 // wave are vertical neighbours: one add in the lane, one across lane^1; only the even-x / even-y lanes of block 0 store).
-template <int MB, bool POOL>
-__device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                       int x, int y0, const int (&ly)[NBW]) {
-  static_assert(NBW == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
+template <int MB, bool POOL, int NB>
+__device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
+                                                       int x, int y0, const int (&ly)[NB]) {
+  static_assert(!POOL || NB == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
   constexpr int COT = MB * 32;
@@ -809,9 +809,9 @@ __device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x1
   const ess_rsrc r_o1 = ess_make_rsrc((const char*)a.out + (size_t)n * nb_first * HW1 * 16, (size_t)nb_first * HW1 * 16);
   const ess_rsrc r_o2 = ess_make_rsrc(split > 0 ? (const char*)a.out2 + (size_t)n * nb_second * HW * 16 : (const char*)a.out,
                                       split > 0 ? (size_t)nb_second * HW * 16 : 0);
-  unsigned pix16[NBW];
+  unsigned pix16[NB];
 #pragma unroll
-  for (int nb = 0; nb < NBW; ++nb) {
+  for (int nb = 0; nb < NB; ++nb) {
     const int y = y0 + ly[nb];
     pix16[nb] = ((y < a.Hout) & (x < a.Wout)) ? (unsigned)(y * a.Wout + x) * 16u : ESS_OOB;
   }
@@ -848,11 +848,11 @@ __device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x1
         const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
         __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, (int)(st_pool != ESS_OOB ? (unsigned)(blk0 + half) * HW1 * 16u + st_pool : ESS_OOB), 0, 0);
       } else {
-        uint2 pk[2][NBW];
+        uint2 pk[2][NB];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) {
+          for (int nb = 0; nb < NB; ++nb) {
             bf16x4 b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) b[i] = (__bf16)acc[mb][nb][4 * (jp + jj) + i];
@@ -860,7 +860,7 @@ __device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x1
           }
         const unsigned plane = (unsigned)(blk0 + half - (first ? 0 : nb_first)) * HW * 16u;
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][nb].x, pk[1][nb].x, false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
           const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
@@ -925,6 +925,40 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
   } else {
     if (a.shift) conv_epilogue_c8_impl<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
     else conv_epilogue_c8_impl<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+  }
+}
+
+// Epilogue of the wide-tile kernel (conv_bf16_wide.hip; NB = 5 pixel blocks per wave): the straight-line forms only.  The
+// dispatcher routes a launch to that kernel only when one of them applies (conv_bf16.hip, wide_epilogue_ok): one output with
+// every channel of the tile real (scale / shift / residual / ReLU / F16 options), or the two outputs of a concat's data-gradient.
+template <int MB, bool SC, bool SH, int NB>
+__device__ __forceinline__ void conv_epilogue_c8_wide_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half, int x,
+                                                          int y0, const int (&ly)[NB]) {
+  const bool relu = a.act == ESS_ACT_RELU, res = a.residual != nullptr;
+  if constexpr (!SC && !SH) {
+    if (a.out_split > 0) { conv_epilogue_c8_dgrad<MB, false>(a, acc, ct, n, half, x, y0, ly); return; }
+  }
+  if (a.out_f16) {
+    conv_epilogue_c8_plain<MB, SC, SH, true, false, false>(a, acc, ct, n, half, x, y0, ly);
+  } else if (res) {
+    if (relu) conv_epilogue_c8_plain<MB, SC, SH, false, true, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_plain<MB, SC, SH, false, false, true>(a, acc, ct, n, half, x, y0, ly);
+  } else {
+    if (relu) conv_epilogue_c8_plain<MB, SC, SH, false, true, false>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_plain<MB, SC, SH, false, false, false>(a, acc, ct, n, half, x, y0, ly);
+  }
+}
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_c8_wide(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half, int x,
+                                                      int y0, const int (&ly)[NB], bool biased) {
+  if (biased) {  // (uniform; the accumulators started from the shift vector)
+    conv_epilogue_c8_wide_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+  } else if (a.scale) {
+    if (a.shift) conv_epilogue_c8_wide_sel<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_wide_sel<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
+  } else {
+    if (a.shift) conv_epilogue_c8_wide_sel<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_wide_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
   }
 }
 

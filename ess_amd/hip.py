@@ -45,7 +45,7 @@ EXPORTS = [
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
     'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices', 'ess_sum_scalars',
-    'ess_label_confusion', 'ess_augment_perspective_filter',
+    'ess_label_confusion', 'ess_augment_perspective_filter', 'ess_tuning_set', 'ess_tuning_get',
 ]
 
 
@@ -696,6 +696,17 @@ def resize_nearest(x, size):
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
     _check(lib().ess_resize_nearest(ptr(x), ptr(y), N * C, h, w, H, W, stream()), 'ess_resize_nearest')
     return y
+
+
+def tuning_set(key, value):
+    """Process-wide kernel-choice switch (include/ess_hip.h: results are identical for every setting)."""
+    _check(lib().ess_tuning_set(key.encode(), int(value)), 'ess_tuning_set')
+
+
+def tuning_get(key):
+    v = c_int32(0)
+    _check(lib().ess_tuning_get(key.encode(), byref(v)), 'ess_tuning_get')
+    return v.value
 
 
 def label_confusion(pred, labels, conf, ignore_index=255):

@@ -348,6 +348,12 @@ int ess_argmax_confusion(const float* logits, const int64_t* labels, int64_t* pr
 int ess_label_confusion(const int64_t* pred_lbl, const int64_t* labels, int64_t* conf, int64_t total, int32_t K,
                         int32_t ignore_index, ess_stream_t stream);
 
+/* ---- tuning switches: process-wide kernel choices that never change a result (every setting runs the same arithmetic in the
+ * same order).  "conv_wide": 0 = the 64 x 256-pixel-tile 3x3 kernel always, 1 = the wide-tile kernel where its round count wins
+ * (default; environment ESS_CONV_WIDE), 2 = the wide-tile kernel wherever it applies.                               */
+int ess_tuning_set(const char* key, int32_t value);
+int ess_tuning_get(const char* key, int32_t* value);
+
 #ifdef __cplusplus
 }
 #endif

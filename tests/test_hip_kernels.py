@@ -640,6 +640,96 @@ def test_conv_c8_epilogue_forms_agree(H, form, geom):
         assert relerr(a[1], ref[:, 32:]) < tol
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Wide-tile 3x3 kernel (round 4, conv_bf16_wide.hip: five pixel blocks per matrix wave, 128 x 320 / 64 x 640 / 64 x 320 / 32 x 640
+# tiles, one workgroup per CU) against the 64 x 256-tile kernel it replaces where its round count wins: both accumulate chunk by
+# chunk, tap by tap in the same order and share the epilogue code, so the outputs must be BIT-identical -- every variant, every
+# epilogue form it serves, both source modes, a persistent (> 256 tiles) launch, ragged extents.
+WIDE_CASES = [
+    # N, C0, C1, Cout, H, W, mode0, form
+    (2, 256, 0, 256, 20, 32, 0, 'bias'),                 # <2,2> exact tiles
+    (1, 64, 0, 128, 27, 44, 0, 'bias_f16'),              # <2,2> ragged rows and columns, F16_C8 output
+    (2, 128, 128, 128, 24, 32, 1, 'bias'),               # <2,2> cat(nearest_up2(x), skip)
+    (2, 64, 0, 64, 40, 48, 0, 'residual_relu'),          # 64 channels: <2,1> / <1,2>
+    (2, 96, 0, 64, 33, 20, 0, 'scale_shift_relu'),
+    (1, 64, 0, 32, 64, 96, 1, 'bias'),                   # <1,1>: nearest-up source, 32 output channels
+    (2, 128, 0, 192, 20, 16, 0, 'split'),                # data-gradient of a concat: two outputs (64 + 128)
+    (8, 32, 0, 128, 80, 96, 0, 'relu'),                  # 8 * 4 * 6 = 192 ... with 64-channel variants 240+: persistent launch below
+    (8, 32, 0, 64, 120, 160, 0, 'bias'),                 # 64 x 640: 3 * 10 * 8 = 240; 64 x 320: 480 tiles -> persistent
+    (2, 48, 0, 128, 20, 16, 2, 'bias'),                  # zero-insert source (data-gradient of a stride-2 convolution)
+]
+
+
+@pytest.mark.parametrize('case', WIDE_CASES)
+def test_conv_wide_tile_bit_identical(H, case):
+    N, C0, C1, Co, Hh, Ww, m0, form = case
+    g = torch.Generator().manual_seed(Hh * 13 + Co + len(form))
+    relu = form.endswith('relu')
+    split = 64 if form == 'split' else 0
+    f16 = form == 'bias_f16'
+    has_scale, has_shift, has_res = 'scale' in form, form != 'split', form.startswith('residual')
+    hs, ws_ = (Hh // 2, Ww // 2) if m0 else (Hh, Ww)
+    x0 = torch.randn(N, C0, hs, ws_, generator=g)
+    x1 = torch.randn(N, C1, Hh, Ww, generator=g) if C1 else None
+    w = torch.randn(Co, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5
+    b, sc = torch.randn(Co, generator=g), torch.rand(Co, generator=g) + 0.5
+    spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, mode0=m0, act=H.ACT_RELU if relu else H.ACT_NONE, out_split=split,
+                       compute=H.COMPUTE_BF16)
+    pw = H.pack_weights(spec, dev(w))
+    psc = H.pack_rows(spec, dev(sc)) if has_scale else None
+    psh = H.pack_rows(spec, dev(b)) if has_shift else None
+    xs0, xs1 = H.to_bf16_c8(dev(x0)), (H.to_bf16_c8(dev(x1)) if C1 else None)
+    res = H.to_bf16_c8(dev(torch.randn(N, Co, Hh, Ww, generator=g))) if has_res else None
+    prev = H.tuning_get('conv_wide')
+    outs = []
+    try:
+        for mode in (0, 2):
+            H.tuning_set('conv_wide', mode)
+            mk = H.f16_c8_empty if f16 else H.bf16_c8_empty
+            c1 = split if split else Co
+            o1 = mk(N, c1, Hh, Ww, 'cuda')
+            o1.view(torch.int16).fill_(0x7e00 if f16 else 0x7fc0)  # NaN patterns: every element must be written
+            o2 = H.bf16_c8_empty(N, Co - split, Hh, Ww, 'cuda') if split else None
+            if o2 is not None:
+                o2.view(torch.int16).fill_(0x7fc0)
+            H.conv_forward(spec, xs0, xs1, pw, psc, psh, residual=res, out=o1, out2=o2, src_fmt=H.FMT_BF16_C8,
+                           out_fmt=H.FMT_F16_C8 if f16 else H.FMT_BF16_C8)
+            torch.cuda.synchronize()
+            outs.append((o1.view(torch.int16).clone(), None if o2 is None else o2.view(torch.int16).clone()))
+    finally:
+        H.tuning_set('conv_wide', prev)
+    (a1, a2), (b1, b2) = outs
+    assert not (a1 == (0x7e00 if f16 else 0x7fc0)).all()
+    assert torch.equal(a1, b1), (a1 != b1).float().mean().item()
+    if split:
+        assert torch.equal(a2, b2)
+    # ... and both are the convolution (fp32 math on bf16-rounded operands, rounded to the stored type)
+    xin = x0.bfloat16().float()
+    if m0 == 1:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    elif m0 == 2:
+        z = torch.zeros(N, C0, Hh, Ww)
+        z[:, :, ::2, ::2] = xin
+        xin = z
+    if C1:
+        xin = torch.cat([xin, x1.bfloat16().float()], 1)
+    ref = F.conv2d(xin, w.bfloat16().float(), None, padding=1)
+    if has_scale:
+        ref = ref * sc.view(1, -1, 1, 1)
+    if has_shift:
+        ref = ref + b.view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + H.from_bf16_c8(res, Co).cpu()
+    if relu:
+        ref = F.relu(ref)
+    o1 = outs[1][0].view(torch.bfloat16)
+    v1 = (o1.view(torch.float16).float().permute(0, 1, 4, 2, 3).reshape(N, -1, Hh, Ww)[:, :(split if split else Co)].cpu()
+          if f16 else _un8(o1, split if split else Co))
+    assert relerr(v1, ref[:, :(split if split else Co)]) < (2e-3 if f16 else 1.2e-2)
+    if split:
+        assert relerr(_un8(outs[1][1].view(torch.bfloat16), Co - split), ref[:, split:]) < 1.2e-2
+
+
 @pytest.mark.parametrize('case', [(2, 32, 11, 24, 40, True, False), (1, 32, 11, 17, 34, True, True), (2, 24, 3, 9, 14, False, False), (1, 64, 16, 12, 20, True, False),
                                   (1, 40, 1, 6, 10, True, True)])
 def test_conv_pred1x1_c8_to_planes(H, case):
