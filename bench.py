@@ -46,8 +46,9 @@ def parse():
     ap.add_argument('--recurrent', default='convlstm', choices=['convlstm', 'convgru'],
                     help='recurrent block of the frozen E2VID encoder (reference e2vid/model/submodules.py:175-273); BASELINE config 5 '
                          'names the ConvGRU variant')
-    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32'],
-                    help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3) or exact fp32 MFMA')
+    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32', 'bf16x3'],
+                    help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3), exact fp32 MFMA, or '
+                         'split-operand bf16 (fp32 tensors, three bf16 MFMAs per product: the parity-grade configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue every step eagerly (default on one GPU: the step is captured '
@@ -253,7 +254,7 @@ def roofline_blocks(args, device):
     tag = f'{args.compute}/{B}/{args.height}x{args.width}'
     conv_t = conv_fl / conv_ms / 1e9
     return {'bound': 'mfma',
-            'kernel': ('conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> (plain 3x3 conv of the trainable networks)' if bf16
+            'kernel': ('conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> | conv_bf16_wide_kernel<MBW, CW> (plain 3x3 conv of the trainable networks; picked per launch by round count)' if bf16
                        else 'conv_f32_kernel<3,1,MB,LINEAR,8>') + ': the 16 launches of one decoder forward',
             'achieved': round(conv_t, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(conv_t / peak, 4),
             'traffic': _traffic_from_profiles('conv3x3/' + tag), 'ms_per_launch_set': round(conv_ms, 4), 'per_layer': per_layer,
@@ -482,6 +483,27 @@ def main():
         extra['fp32_ms_per_step'] = round(ms32, 3)
         extra['fp32_voxel_grids_per_s'] = round(args.batch * args.T / ms32 * 1e3, 2)
         del tr32
+        torch.cuda.empty_cache()
+        # ... and the split-operand bf16 configuration (ESS_COMPUTE_BF16X3: fp32 tensors, w_hi x_hi + w_hi x_lo + w_lo x_hi on the bf16
+        # matrix cores for every 3x3 / stride-1 contraction, exact fp32 elsewhere): parity-grade predictions
+        # (tests/test_hip_bf16_separated.py, tests/test_hip_modules.py::test_dsec_size_parity_vs_oracle in that mode) at a
+        # matrix-core-rate step; 1 warm-up + 3 steps
+        try:
+            hip.set_compute('bf16x3')
+            torch.manual_seed(6)
+            trx = ESSModel(st) if args.trainer == 'ess' else ESSSupervisedModel(st)
+            trx.train_step(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                trx.train_step(batch)
+            torch.cuda.synchronize()
+            msx = (time.perf_counter() - t1) / 3 * 1e3
+            extra['bf16x3_ms_per_step'] = round(msx, 3)
+            extra['bf16x3_voxel_grids_per_s'] = round(args.batch * args.T / msx * 1e3, 2)
+            del trx
+        except Exception as e:  # noqa: BLE001
+            extra['bf16x3_error'] = f'{type(e).__name__}: {e}'
         torch.cuda.empty_cache()
         hip.set_compute(args.compute)
 

@@ -15,8 +15,9 @@ namespace {
 
 using namespace essconv;
 
+// split (ESS_COMPUTE_BF16X3): every (tile, chunk) block is followed by a second one holding lo = bf16(w - float(bf16(w)))
 __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16* out, int64_t total, int cot, int ck,
-                                         int n_chunks, int ks, int cin, int cout, int epi, int hid, int w_kind) {
+                                         int n_chunks, int ks, int cin, int cout, int epi, int hid, int w_kind, int split) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int64_t t = i;
@@ -25,6 +26,8 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
   const int cb8 = ck >> 3;
   const int cb = t % cb8; t /= cb8;
   const int tap = t % (ks * ks); t /= ks * ks;
+  int lo = 0;
+  if (split) { lo = (int)(t & 1); t >>= 1; }
   const int ch = t % n_chunks;
   const int ct = t / n_chunks;
   const int c = ch * ck + cb * 8 + kp;
@@ -37,7 +40,8 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
     if (w_kind == ESS_W_CONV) v = src[(((size_t)row * cin + c) * ks + ky) * ks + kx];
     else v = src[(((size_t)c * cout + row) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
   }
-  out[i] = (__bf16)v;
+  const __bf16 hi = (__bf16)v;
+  out[i] = lo ? (__bf16)(v - (float)hi) : hi;
 }
 
 // weights for the tap-paired kernel: [tile][chunk of 8 channels][pair][half][cout][8]
@@ -67,15 +71,16 @@ __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64
 namespace essconv {
 
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
-                           hipStream_t st) {
+                           hipStream_t st, bool split) {
   const int64_t total = pl.packed_elems;
+  ESS_CHECK_ARG(!split || !is_paired(d), "pack_weights: split operands exist for the 3x3 / stride-1 kernel only");
   if (is_paired(d)) {
     hipLaunchKernelGGL(pack_weights_bf16_pair_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, (__bf16*)packed, total,
                        pl.cout_tile, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, w_kind);
     return ess_launch_status("pack_weights_bf16(paired)");
   }
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, w2, (__bf16*)packed,
-                     total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue, d->hidden, w_kind);
+                     total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue, d->hidden, w_kind, split ? 1 : 0);
   return ess_launch_status("pack_weights_bf16");
 }
 
@@ -188,7 +193,9 @@ bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const
   static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA"); return e ? atof(e) : 1.12; }();
   const int mb = pl.cout_tile / 32;
   const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
-  const double c_std = std_cost(std_tiles, pl.cout_tile, 2);
+  // (32-channel tiles of the ws kernel stage a weight slab per 256 pixels and read one weight fragment per two MFMAs: measured
+  // 6.8 us per round of 64^ -> 32 @ 480 x 640 against 5.0 for half a 64-channel round -- 1.35)
+  const double c_std = std_cost(std_tiles, pl.cout_tile, 2) * (mb == 1 ? 1.35 : 1.0);
   const int cands[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   double best = 1e300;
   for (const auto& c : cands) {
@@ -217,6 +224,8 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const bool c8 = a.fmt0 == ESS_FMT_BF16_C8;
+  ESS_CHECK_ARG(!a.split || (ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16 && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
+                "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised kernel with fp32 tensors");
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
   if (!c8 && !a.residual && conv_bf16_stem_applies(d, pl)) {  // 1-channel 7x7 / stride 2 stem: K = the filter rows
     conv_bf16_launch_stem(d, pl, st, a);

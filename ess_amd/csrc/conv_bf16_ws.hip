@@ -216,8 +216,14 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     struct Raw8 { float v[8]; };
     Raw8 pre[CB8][KPC];
     u32x4 wpre[WV];
-    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
-    auto load_chunk = [&](int ch) {
+    // split operands (a.split, ESS_COMPUTE_BF16X3): the K loop runs over 3 * n_chunks VIRTUAL chunks -- chunk vc / 3 staged three
+    // times as (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi); hi = bf16(v), lo = bf16(v - hi).  The matrix waves do not know: same
+    // fragments, same accumulators, three times the chunks.  The weight pack holds a hi and a lo slab per (tile, chunk).
+    const int nvc = a.split ? 3 * a.n_chunks : a.n_chunks;
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ * (a.split ? 2 : 1);
+    auto load_chunk = [&](int vc) {
+      const int ch = a.split ? vc / 3 : vc;
+      const int w_lo = a.split && (vc - 3 * ch) == 2 ? 1 : 0;
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;
@@ -233,29 +239,39 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
         }
       }
-      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+      const u32x4* wsrc = wbase + (size_t)(a.split ? 2 * ch + w_lo : ch) * WSZ;
 #pragma unroll
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
     };
-    auto commit = [&](int buf) {
-      u32x4* in_t = smem16 + buf * bufsz;
+    auto commit = [&](int vc) {  // (the values `pre` holds belong to virtual chunk vc)
+      u32x4* in_t = smem16 + (vc & 1) * bufsz;
       u32x4* w_t = in_t + CB8 * a.plane;
+      const bool x_lo = a.split && (vc % 3) == 1;
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb)
 #pragma unroll
         for (int k = 0; k < KPC; ++k)
-          if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = pack8(pre[cb][k].v);
+          if (v_lds[k] >= 0) {
+            if (x_lo) {
+              float lo[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) lo[j] = pre[cb][k].v[j] - (float)(__bf16)pre[cb][k].v[j];
+              in_t[cb * a.plane + v_lds[k]] = pack8(lo);
+            } else {
+              in_t[cb * a.plane + v_lds[k]] = pack8(pre[cb][k].v);
+            }
+          }
 #pragma unroll
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
     };
     load_chunk(0);
     commit(0);
-    if (a.n_chunks > 1) load_chunk(1);
+    if (nvc > 1) load_chunk(1);
     __syncthreads();  // stage 0 is ready
-    for (int ch = 0; ch < a.n_chunks; ++ch) {
-      if (ch + 1 < a.n_chunks) {
-        commit((ch + 1) & 1);
-        if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+    for (int vc = 0; vc < nvc; ++vc) {
+      if (vc + 1 < nvc) {
+        commit(vc + 1);
+        if (vc + 2 < nvc) load_chunk(vc + 2);
       }
       __syncthreads();
     }
@@ -314,7 +330,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     for (int ky = 0; ky < KS; ++ky) b_base[nb][ky] = (unsigned)((boff[nb] + ky * a.row_pitch) * 16);
   const unsigned w_off = (unsigned)(CB8 * a.plane * 16), buf_bytes = (unsigned)(bufsz * 16);
   struct Frags { u32x4 a[MB]; u32x4 b[NBW]; };
-  for (int ch = 0; ch < a.n_chunks; ++ch) {
+  const int nvc_c = a.split ? 3 * a.n_chunks : a.n_chunks;  // (split operands: three virtual chunks per chunk, see the staging waves)
+  for (int ch = 0; ch < nvc_c; ++ch) {
     if (ch < 40) ESS_CT(3 + ch);
     const unsigned stage_b = lds0 + (ch & 1) * buf_bytes;
     const unsigned wa = stage_b + w_off + a_base;
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #undef ESS_READ_TAP
 #undef ESS_WAIT
 #undef ESS_MMA
-    if (ch == a.n_chunks - 1) ESS_CT(44);
+    if (ch == nvc_c - 1) ESS_CT(44);
     ESS_SYNC_ACC(cbar_acc);
   }
   ESS_CT_VAL(42, cbar_acc);

@@ -40,6 +40,7 @@ struct ConvKArgs {
   int fmt_res;     // format of `residual`
   int out_f16;     // BF16_C8-output epilogue: store IEEE half instead of bfloat16 (ESS_FMT_F16_C8: a pre-norm tensor, read by the norm kernels only)
   int persist;     // 3x3 wave-specialised kernel: the grid is one resident set of workgroups, each walking several tiles
+  int split;       // split-operand bf16 (ESS_COMPUTE_BF16X3): every 16-channel chunk is contracted three times -- (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
   int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
 };
 
@@ -1210,6 +1211,19 @@ struct Geom {
 };
 
 inline bool is_bf16(const EssConvDesc* d) { return d->compute == ESS_COMPUTE_BF16; }
+inline bool ws_enabled();
+// ESS_COMPUTE_BF16X3 resolves, per convolution, to the arithmetic that runs: the bf16 3x3 / stride-1 wave-specialised kernel with
+// split operands (`split`), or the exact-fp32 kernels for every other geometry.  The entry points work on the resolved copy.
+struct ResolvedDesc { EssConvDesc d; bool split; };
+inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
+  ResolvedDesc r{*d, false};
+  if (d->compute == ESS_COMPUTE_BF16X3) {
+    const bool ws = d->ksize == 3 && d->stride == 1 && ws_enabled();
+    r.d.compute = ws ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
+    r.split = ws;
+  }
+  return r;
+}
 
 // bf16 5x5 convolutions run on the tap-paired wave-specialised kernel (conv_bf16.hip): 8-channel chunks, two taps per MFMA
 inline bool is_paired(const EssConvDesc* d) {
@@ -1332,7 +1346,10 @@ inline int validate(const EssConvDesc* d) {
     if (m != ESS_SRC_DIRECT) ESS_CHECK_ARG(!(d->H_in & 1) && !(d->W_in & 1), "conv: x2 source needs even extent");
   }
   ESS_CHECK_ARG(d->epilogue >= 0 && d->epilogue <= 3, "conv: bad epilogue");
-  ESS_CHECK_ARG(d->compute == ESS_COMPUTE_FP32 || d->compute == ESS_COMPUTE_BF16, "conv: bad compute type");
+  ESS_CHECK_ARG(d->compute == ESS_COMPUTE_FP32 || d->compute == ESS_COMPUTE_BF16 || d->compute == ESS_COMPUTE_BF16X3, "conv: bad compute type");
+  if (d->compute == ESS_COMPUTE_BF16X3)
+    ESS_CHECK_ARG(d->fmt0 == ESS_FMT_F32_NCHW && d->fmt1 == ESS_FMT_F32_NCHW && d->fmt_out == ESS_FMT_F32_NCHW && d->fmt_res == ESS_FMT_F32_NCHW,
+                  "conv: split-operand bf16 (ESS_COMPUTE_BF16X3) works on fp32 NCHW tensors");
   if (d->epilogue == ESS_EPI_LSTM) ESS_CHECK_ARG(d->C_out == 4 * d->hidden, "conv: LSTM needs C_out = 4*hidden");
   if (d->epilogue == ESS_EPI_GRU_UR) ESS_CHECK_ARG(d->C_out == 2 * d->hidden, "conv: GRU_UR needs C_out = 2*hidden");
   if (d->epilogue == ESS_EPI_GRU_OUT) ESS_CHECK_ARG(d->C_out == d->hidden, "conv: GRU_OUT needs C_out = hidden");
@@ -1390,7 +1407,7 @@ inline int packed_rows(const EssConvDesc* d) {
   }
 }
 
-inline void make_plan(const EssConvDesc* d, EssConvPlan* pl) {
+inline void make_plan(const EssConvDesc* d, EssConvPlan* pl, bool split = false) {
   const int mb = pick_mb(d);
   pl->cout_tile = mb * 32;
   pl->ck = pick_ck(d);
@@ -1405,6 +1422,7 @@ inline void make_plan(const EssConvDesc* d, EssConvPlan* pl) {
     pl->packed_bytes = pl->packed_elems * 2;
     pl->lds_bytes = (g.plane + np * 2 * pl->cout_tile) * 16;  // one stage; the kernel double-buffers
   } else if (is_bf16(d)) {
+    if (split) pl->packed_elems *= 2;  // a hi and a lo slab per (channel tile, chunk): [tile][chunk][hi | lo][tap][c/8][cout][8]
     pl->packed_bytes = pl->packed_elems * 2;
     pl->lds_bytes = ((pl->ck / 8) * g.plane + d->ksize * d->ksize * (pl->ck / 8) * pl->cout_tile) * 16;
   } else {
@@ -1470,7 +1488,7 @@ static __global__ void pack_rows_kernel(const float* v, const float* v2, float f
 // bf16-MFMA variant (conv_bf16.hip)
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st);
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
-                           hipStream_t st);
+                           hipStream_t st, bool split = false);
 int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds, const float* const* w, void* const* packed, int count,
                                  hipStream_t st);
 

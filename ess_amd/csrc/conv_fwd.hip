@@ -183,7 +183,8 @@ extern "C" int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan) {
   int rc = validate(d);
   if (rc) return rc;
   ESS_CHECK_ARG(plan != nullptr, "conv: null plan");
-  make_plan(d, plan);
+  const ResolvedDesc rd = resolve_compute(d);
+  make_plan(&rd.d, plan, rd.split);
   return ESS_OK;
 }
 
@@ -194,9 +195,11 @@ extern "C" int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const f
   ESS_CHECK_ARG(w && packed, "pack_weights: null pointer");
   ESS_CHECK_ARG(d->epilogue != ESS_EPI_GRU_UR || w2, "pack_weights: GRU_UR needs the reset-gate weight as w2");
   ESS_CHECK_ARG(w_kind == ESS_W_CONV || w_kind == ESS_W_TRANSPOSED, "pack_weights: bad w_kind");
+  const ResolvedDesc rd = resolve_compute(d);
+  d = &rd.d;
   EssConvPlan pl;
-  make_plan(d, &pl);
-  if (is_bf16(d)) return conv_bf16_pack_weights(d, pl, w_kind, w, w2, packed, (hipStream_t)stream);
+  make_plan(d, &pl, rd.split);
+  if (is_bf16(d)) return conv_bf16_pack_weights(d, pl, w_kind, w, w2, packed, (hipStream_t)stream, rd.split);
   const int64_t total = pl.packed_elems;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, w2,
                      (float*)packed, total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue,
@@ -216,8 +219,10 @@ extern "C" int ess_conv2d_pack_rows(const EssConvDesc* d, const float* v, const 
   if (rc) return rc;
   ESS_CHECK_ARG(v && packed, "pack_rows: null pointer");
   ESS_CHECK_ARG(d->epilogue != ESS_EPI_GRU_UR || v2, "pack_rows: GRU_UR needs the reset-gate vector as v2");
+  const ResolvedDesc rd = resolve_compute(d);
+  d = &rd.d;
   EssConvPlan pl;
-  make_plan(d, &pl);
+  make_plan(d, &pl, rd.split);
   hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(pl.rows_padded, 256)), dim3(256), 0, (hipStream_t)stream, v, v2, fill,
                      packed, pl.rows_padded, d->epilogue, d->hidden, d->C_out);
   return ess_launch_status("pack_rows");
@@ -240,6 +245,8 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   }
   int rc = validate(d);
   if (rc) return rc;
+  const ResolvedDesc rd = resolve_compute(d);
+  d = &rd.d;
   ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
   ESS_CHECK_ARG(out || (out_bf16 && d->out_split == 0 && (d->epilogue == ESS_EPI_LINEAR || d->epilogue == ESS_EPI_LSTM || d->epilogue == ESS_EPI_GRU_OUT)),
                 "conv: `out` may only be NULL when the BF16_C8 copy is requested (LINEAR / LSTM / GRU_OUT epilogues)");
@@ -260,7 +267,7 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   }
   ESS_CHECK_ARG(!residual || d->fmt_res == d->fmt_out, "conv: the residual must come in the output's format");
   EssConvPlan pl;
-  make_plan(d, &pl);
+  make_plan(d, &pl, rd.split);
   ESS_CHECK_ARG(pl.lds_bytes <= 160 * 1024, "conv: LDS tile %d B exceeds 160 KiB", pl.lds_bytes);
   const Geom g = choose_geom(d);
   ConvKArgs a{};
@@ -271,6 +278,7 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   { static const int abl = [] { const char* b = getenv("ESS_WS_ABL"); return b ? atoi(b) & ~1 : 0; }(); a.deep = abl; }
 #endif
   a.out_f16 = out_f16 ? 1 : 0;
+  a.split = rd.split ? 1 : 0;
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;

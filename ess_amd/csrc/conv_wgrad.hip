@@ -312,7 +312,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
   float bsum = 0.f;
   const size_t HWo = (size_t)a.Hout * a.Wout;
 
-  for (int tile = split; tile < a.ntiles; tile += nsplit) {
+  // split operands (b.split): each tile three times -- pass 0 (dY_hi, X_hi), 1 (dY_hi, X_lo), 2 (dY_lo, X_hi)
+  const int npass = b.split ? 3 : 1;
+  for (int tile = split; tile < a.ntiles; tile += nsplit)
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool d_lo = pass == 2, x_lo = pass == 1;
     const int n = tile / (a.tiles_x * a.tiles_y);
     const int tr = tile - n * a.tiles_x * a.tiles_y;
     const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
         const int v = tid + i * 256;
         const int xv = v % TV, r = v / TV;
         const int qy = r % THp, co = r / THp;
-        dy_t[co * b.pyv + qy * TV + xv] = cvt8(f[i]);
+        dy_t[co * b.pyv + qy * TV + xv] = d_lo ? cvt8_lo(f[i]) : cvt8(f[i]);
       }
     }
     {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
           if (v < nxv) {
             const int xv = v % b.rv, r = v / b.rv;
             const int iy = r % IH, ci = r / IH;
-            x_t[ci * b.pxv + iy * b.rv + xv] = cvt8(f[i]);
+            x_t[ci * b.pxv + iy * b.rv + xv] = x_lo ? cvt8_lo(f[i]) : cvt8(f[i]);
           }
         }
       }
@@ -425,8 +429,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_kernel(const WgradBArgs b
       for (int xs = 0; xs < TV; xs += 2) {  // one 16-pixel k-step
         const u32x4w av = ap[qy * TV + xs];
         const bf16x8w af = __builtin_bit_cast(bf16x8w, av);
+        if (!x_lo) {  // (bias gradient = sum of dY: its hi part in pass 0, its lo part in pass 2)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+          for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const u32x4w* row = xp + (qy + ky) * b.rv + xs;
@@ -548,11 +554,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     }
   };
   // convert + store ONE staged vector of the next tile into LDS stage `st` (i is a compile-time index after unrolling)
+  // split operands (b.split): iteration `it` of the K loop is (tile it / npass, pass it % npass); the pass of the STAGED tile picks
+  // the part: pass 0 (dY_hi, X_hi), 1 (dY_hi, X_lo), 2 (dY_lo, X_hi).  Tile-major, so the three passes re-read one tile from L2.
+  const int npass = b.split ? 3 : 1;
+  int cpass = 0;  // pass of the tile being committed
   auto commit_d = [&](int i, int st) {
     float f[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { f[j] = dreg[i][0][j]; f[4 + j] = dreg[i][1][j]; }
-    u32x4w v = cvt8(f);
+    u32x4w v = cpass == 2 ? cvt8_lo(f) : cvt8(f);
     v[0] &= dmask[i]; v[1] &= dmask[i]; v[2] &= dmask[i]; v[3] &= dmask[i];
     dy_t[st * stage + d_lds[i]] = v;
   };
@@ -565,7 +575,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
 #pragma unroll
       for (int j = 0; j < 4; ++j) { f[j] = xreg[i][0][j]; f[4 + j] = xreg[i][1][j]; }
     }
-    u32x4w v = cvt8(f);
+    u32x4w v = cpass == 1 ? cvt8_lo(f) : cvt8(f);
     v[0] &= xmask[i]; v[1] &= xmask[i]; v[2] &= xmask[i]; v[3] &= xmask[i];
     if (x_lds[i] >= 0) x_t[st * stage + x_lds[i]] = v;
   };
@@ -592,8 +602,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
   }
   __syncthreads();
   int st = 0;
-  for (int tile = split; tile < a.ntiles; tile += nsplit, st ^= 1) {
-    const bool more = tile + nsplit < a.ntiles;
+  const int my_tiles = split < a.ntiles ? (a.ntiles - split + nsplit - 1) / nsplit : 0;
+  for (int it = 0; it < my_tiles * npass; ++it, st ^= 1) {
+    const int pass = it % npass;
+    const bool more = it + 1 < my_tiles * npass;
+    const int next_tile = split + ((it + 1) / npass) * nsplit;
+    cpass = (it + 1) % npass;
     const u32x4w* ap = dy_t + st * stage + (cb * 32 + p) * b.pyv + half;
     const u32x4w* xp = x_t + st * stage + (ib * 32 + p) * b.pxv + half;
     auto read_frag = [&](int ks, Frag& f) {
@@ -610,8 +624,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     };
     auto mma = [&](const Frag& f) {
       const bf16x8w af = __builtin_bit_cast(bf16x8w, f.a);
+      if (pass != 1) {  // (bias gradient = sum of dY: its hi part in pass 0, its lo part in pass 2)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+        for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+      }
       if constexpr (TAPS == 1) {  // 1x1 convolution = the centre tap of the same pixel-tile geometry
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8w, f.v[1][1]), acc[0], 0, 0, 0);
       } else {
@@ -631,7 +647,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_k3s1_fast_kernel(const WgradBA
     for (int ks = 0; ks < 8; ++ks) {
       if (ks + 1 < 8) read_frag(ks + 1, fr[(ks + 1) & 1]);
       mma(fr[ks & 1]);
-      if (ks == 0 && more) issue(tile + nsplit);  // address arithmetic + 28 loads, behind the first k-step's MFMAs
+      if (ks == 0 && more) issue(next_tile);  // address arithmetic + 28 loads, behind the first k-step's MFMAs
       if (more) {  // wave-uniform; the slice of the next tile's staging that rides on this k-step
         if (ks == 4) { commit_d(0, st ^ 1); commit_d(1, st ^ 1); commit_d(2, st ^ 1); commit_d(3, st ^ 1); }
         if (ks == 5) { commit_x(0, st ^ 1); commit_x(1, st ^ 1); commit_x(2, st ^ 1); }
@@ -865,6 +881,7 @@ int wvalidate(const EssConvDesc* d) {
   ESS_CHECK_ARG(d->stride == 1 || d->stride == 2, "wgrad: stride %d unsupported", d->stride);
   // storage formats: fmt0 (= fmt1) is X's, fmt_out is dY's
   const bool xc8 = d->fmt0 == ESS_FMT_BF16_C8, dc8 = d->fmt_out == ESS_FMT_BF16_C8;
+  ESS_CHECK_ARG(d->compute == ESS_COMPUTE_FP32 || d->compute == ESS_COMPUTE_BF16 || d->compute == ESS_COMPUTE_BF16X3, "wgrad: bad compute type");
   if (xc8 || dc8) {
     ESS_CHECK_ARG(d->compute == ESS_COMPUTE_BF16, "wgrad: BF16_C8 tensors need bf16 compute");
     ESS_CHECK_ARG(d->C1 == 0 || d->fmt1 == d->fmt0, "wgrad: both sources of a concat must use the same format");
@@ -959,8 +976,22 @@ int raise_lds(K kernel, int bytes) {
 
 }  // namespace
 
+// ESS_COMPUTE_BF16X3: 3x3 / stride 1 / pad 1 on the fp32-staged bf16 kernels with split operands, everything else exact fp32
+static EssConvDesc wresolve(const EssConvDesc* d, bool* split) {
+  EssConvDesc r = *d;
+  *split = false;
+  if (d->compute == ESS_COMPUTE_BF16X3) {
+    *split = d->ksize == 3 && d->stride == 1 && d->pad == 1;
+    r.compute = *split ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
+  }
+  return r;
+}
+
 extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   if (wvalidate(d)) return 0;
+  bool osplit;
+  const EssConvDesc dres = wresolve(d, &osplit);
+  d = &dres;
   const EssConvDesc dp = s2_phases(d) ? s2_phase_desc(d) : *d;
   const WPlan w = wplan(&dp);
   return (size_t)w.nsplit * w.slab_floats * 4;
@@ -971,6 +1002,9 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
   const float* src0 = (const float*)src0_; const float* src1 = (const float*)src1_; const float* dy = (const float*)dy_;
   int rc = wvalidate(d);
   if (rc) return rc;
+  bool osplit;
+  const EssConvDesc dres = wresolve(d, &osplit);
+  d = &dres;
   ESS_CHECK_ARG(src0 && dy && dw && workspace, "wgrad: null pointer");
   ESS_CHECK_ARG(d->C1 == 0 || src1, "wgrad: second source missing");
   if (s2_phases(d)) {
@@ -1050,6 +1084,7 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
   } else if (w.bf16) {
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
+    bb.split = osplit ? 1 : 0;
     const bool fast = (d->W_in % 8) == 0 && (d->W_out % 8) == 0 && d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2;
     if (w.bf16_1x1) {
       bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile

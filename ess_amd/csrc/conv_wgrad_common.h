@@ -31,6 +31,13 @@ __device__ __forceinline__ u32x4w cvt8(const float (&v)[8]) {
   for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
   return __builtin_bit_cast(u32x4w, b);
 }
+// split operands: the low part lo = bf16(v - float(bf16(v))) of eight values
+__device__ __forceinline__ u32x4w cvt8_lo(const float (&v)[8]) {
+  bf16x8w b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = (__bf16)(v[j] - (float)(__bf16)v[j]);
+  return __builtin_bit_cast(u32x4w, b);
+}
 // bytes [off, off+16) of the 32-byte concatenation lo|hi
 __device__ __forceinline__ u32x4w shift_left1(u32x4w lo, u32x4w hi) {  // window starting 14 bytes into lo (one pixel earlier than hi)
   u32x4w r;
@@ -53,6 +60,8 @@ __device__ __forceinline__ u32x4w shift_right1(u32x4w lo, u32x4w hi) {  // windo
 struct WgradBArgs {
   WgradArgs w;
   int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
+  int split;         // split-operand bf16 (ESS_COMPUTE_BF16X3, fp32-staged kernels): every pixel tile is contracted three times --
+                     // (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) -- into the same accumulators
 };
 
 // conv_wgrad_c8.hip: launchers (the caller has validated the geometry and sized the workspace)

@@ -18,7 +18,7 @@ SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED = 0, 1
-COMPUTE_FP32, COMPUTE_BF16 = 0, 1
+COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
 
 _default_compute = COMPUTE_FP32
@@ -26,14 +26,18 @@ _default_compute = COMPUTE_FP32
 
 def set_compute(kind):
     """Arithmetic of the convolution contractions for specs created without an explicit `compute`:
-    'fp32' (exact fp32 MFMA; BASELINE config 2) or 'bf16' (bf16 MFMA operands, fp32 accumulate, fp32 tensors in HBM;
-    BASELINE config 3).  Weight gradients always run on the fp32 MFMA path."""
+    'fp32' (exact fp32 MFMA; BASELINE config 2), 'bf16' (bf16 MFMA operands, fp32 accumulate, BF16_C8 tensors in the trainable
+    networks; BASELINE config 3), or 'bf16x3' (split-operand bf16, ESS_COMPUTE_BF16X3: fp32 tensors exactly as in the 'fp32'
+    configuration, every 3x3 / stride-1 contraction -- forward, data-gradient, recurrent gates, weight gradient -- as
+    w_hi x_hi + w_hi x_lo + w_lo x_hi on the bf16 matrix cores with fp32 accumulators, ~2^-16 relative operand error; every other
+    convolution on the exact-fp32 kernels: the parity-grade configuration at a matrix-core-rate step)."""
     global _default_compute
-    _default_compute = {'fp32': COMPUTE_FP32, 'bf16': COMPUTE_BF16, COMPUTE_FP32: COMPUTE_FP32, COMPUTE_BF16: COMPUTE_BF16}[kind]
+    _default_compute = {'fp32': COMPUTE_FP32, 'bf16': COMPUTE_BF16, 'bf16x3': COMPUTE_BF16X3, COMPUTE_FP32: COMPUTE_FP32,
+                        COMPUTE_BF16: COMPUTE_BF16, COMPUTE_BF16X3: COMPUTE_BF16X3}[kind]
 
 
 def get_compute():
-    return 'bf16' if _default_compute == COMPUTE_BF16 else 'fp32'
+    return {COMPUTE_FP32: 'fp32', COMPUTE_BF16: 'bf16', COMPUTE_BF16X3: 'bf16x3'}[_default_compute]
 
 EXPORTS = [
     'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',

@@ -44,7 +44,13 @@ enum {
 enum { ESS_ACT_NONE = 0, ESS_ACT_RELU = 1, ESS_ACT_SIGMOID = 2, ESS_ACT_TANH = 3, ESS_ACT_SUMPOOL2 = 4 };
 /* arithmetic of the convolution contraction.  Tensors in HBM are fp32 either way; BF16 rounds the MFMA operands
  * (activations while staging the LDS tile, weights at pack time) to bfloat16 and accumulates in fp32.         */
-enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1 };
+enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1,
+       /* split-operand bf16 ("bf16x3"): fp32 tensors; every operand x of a 3x3 / stride-1 contraction (forward, data-gradient,
+        * recurrent gates, weight gradient) enters the matrix cores as hi = bf16(x), lo = bf16(x - hi), and a product is
+        * w_hi x_hi + w_hi x_lo + w_lo x_hi in fp32 accumulators: ~2^-16 relative operand error against bf16's 2^-8, at three bf16
+        * MFMAs per product (the exact fp32 MFMA costs sixteen).  Every other convolution of such a descriptor runs the exact-fp32
+        * kernels.  The parity-grade configuration with a matrix-core-rate step.                                          */
+       ESS_COMPUTE_BF16X3 = 2 };
 /* storage format of a convolution source.  BF16_C8 = the "staging copy" a producing kernel can emit next to its
  * fp32 NCHW output (out_bf16 of ess_conv2d_forward, or ess_to_bf16_c8): bfloat16 [N][ceil(C/8)][H][W][8], i.e. the
  * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv

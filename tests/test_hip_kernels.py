@@ -641,6 +641,112 @@ def test_conv_c8_epilogue_forms_agree(H, form, geom):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Split-operand bf16 (round 4, ESS_COMPUTE_BF16X3): fp32 tensors, every 3x3 / stride-1 contraction as w_hi x_hi + w_hi x_lo + w_lo x_hi
+# on the bf16 matrix cores (hi = bf16(v), lo = bf16(v - hi)), fp32 accumulate.  Against fp64 math on the UNROUNDED operands the
+# error must sit at the 2^-16 level -- three orders of magnitude under plain bf16 (2^-8), within ~10x of the exact-fp32 kernels.
+@pytest.mark.parametrize('case', [(2, 64, 0, 64, 24, 40, 0, 'linear'), (1, 40, 24, 72, 18, 30, 1, 'linear_relu_res'), (2, 32, 32, 128, 20, 24, 0, 'lstm'),
+                                  (1, 48, 48, 96, 16, 24, 0, 'gru'), (2, 32, 0, 48, 12, 20, 2, 'linear')])
+def test_conv_split_operand_bf16x3(H, case):
+    N, C0, C1, Co, Hh, Ww, m0, form = case
+    g = torch.Generator().manual_seed(Co * 3 + Hh)
+    hs, ws_ = (Hh // 2, Ww // 2) if m0 else (Hh, Ww)
+    # operands with a large common offset: the case plain bf16 handles worst (|mean| / sigma ~ 10, like the event latents)
+    x0 = torch.randn(N, C0, hs, ws_, generator=g) + 8.0
+    x1 = (torch.randn(N, C1, Hh, Ww, generator=g) - 5.0) if C1 else None
+    cin = C0 + C1
+    xin = x0.double()
+    if m0 == 1:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    elif m0 == 2:
+        z = torch.zeros(N, C0, Hh, Ww, dtype=torch.float64)
+        z[:, :, ::2, ::2] = xin
+        xin = z
+    if C1:
+        xin = torch.cat([xin, x1.double()], 1)
+    errs = {}
+    for comp in (H.COMPUTE_BF16X3, H.COMPUTE_BF16, H.COMPUTE_FP32):
+        if form.startswith('linear'):
+            relu, res = 'relu' in form, 'res' in form
+            w = torch.randn(Co, cin, 3, 3, generator=torch.Generator().manual_seed(1)) / (9 * cin) ** 0.5
+            b = torch.randn(Co, generator=torch.Generator().manual_seed(2))
+            r = torch.randn(N, Co, Hh, Ww, generator=torch.Generator().manual_seed(3)) if res else None
+            spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, mode0=m0, act=H.ACT_RELU if relu else H.ACT_NONE, compute=comp)
+            out = torch.full((N, Co, Hh, Ww), float('nan'), device='cuda')
+            H.conv_forward(spec, dev(x0), dev(x1) if C1 else None, H.pack_weights(spec, dev(w)), None, H.pack_rows(spec, dev(b)),
+                           residual=dev(r) if res else None, out=out)
+            ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+            if res:
+                ref = ref + r.double()
+            if relu:
+                ref = F.relu(ref)
+            errs[comp] = relerr(out.cpu().double(), ref)
+        elif form == 'lstm':
+            hid = Co // 4
+            w = torch.randn(Co, cin, 3, 3, generator=torch.Generator().manual_seed(1)) / (9 * cin) ** 0.5
+            b = torch.randn(Co, generator=torch.Generator().manual_seed(2))
+            c = torch.randn(N, hid, Hh, Ww, generator=torch.Generator().manual_seed(3))
+            spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=comp)
+            ho, co = torch.empty(N, hid, Hh, Ww, device='cuda'), torch.empty(N, hid, Hh, Ww, device='cuda')
+            H.conv_forward(spec, dev(x0 * 0.1), dev(x1 * 0.1), H.pack_weights(spec, dev(w)), None, H.pack_rows(spec, dev(b)), aux0=dev(c), out=ho, out2=co)
+            gates = F.conv2d(xin * 0.1, w.double(), b.double(), padding=1)
+            gi, gf, go, gc = gates.chunk(4, 1)
+            cn = torch.sigmoid(gf) * c.double() + torch.sigmoid(gi) * torch.tanh(gc)
+            hn = torch.sigmoid(go) * torch.tanh(cn)
+            errs[comp] = max(relerr(ho.cpu().double(), hn), relerr(co.cpu().double(), cn))
+        else:  # gru: the (update, reset) kernel; r*h and u against fp64
+            hid = Co // 2
+            wu = torch.randn(hid, cin, 3, 3, generator=torch.Generator().manual_seed(1)) / (9 * cin) ** 0.5
+            wr = torch.randn(hid, cin, 3, 3, generator=torch.Generator().manual_seed(4)) / (9 * cin) ** 0.5
+            bu, br = torch.randn(hid, generator=torch.Generator().manual_seed(2)), torch.randn(hid, generator=torch.Generator().manual_seed(5))
+            spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, epi=H.EPI_GRU_UR, hidden=hid, compute=comp)
+            assert C1 == hid
+            u, rh = torch.empty(N, hid, Hh, Ww, device='cuda'), torch.empty(N, hid, Hh, Ww, device='cuda')
+            H.conv_forward(spec, dev(x0 * 0.1), dev(x1 * 0.1), H.pack_weights(spec, dev(wu), dev(wr)), None, H.pack_rows(spec, dev(bu), dev(br)),
+                           aux0=dev(x1 * 0.1), out=u, out2=rh)
+            uu = torch.sigmoid(F.conv2d(xin * 0.1, wu.double(), bu.double(), padding=1))
+            rr = torch.sigmoid(F.conv2d(xin * 0.1, wr.double(), br.double(), padding=1))
+            errs[comp] = max(relerr(u.cpu().double(), uu), relerr(rh.cpu().double(), rr * (x1 * 0.1).double()))
+    e3, e1, e0 = errs[H.COMPUTE_BF16X3], errs[H.COMPUTE_BF16], errs[H.COMPUTE_FP32]
+    print(f'{form}: max rel err vs fp64 -- bf16x3 {e3:.2e}, bf16 {e1:.2e}, fp32 {e0:.2e}')
+    assert e3 < 2e-5 and e3 < e1 / 50, (e3, e1, e0)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 0, 64, 24, 40, 0), (2, 32, 32, 96, 16, 24, 1), (1, 24, 0, 40, 17, 30, 0), (2, 128, 0, 128, 12, 24, 0)])
+def test_conv_wgrad_split_operand_bf16x3(H, case):
+    """The weight gradient of a 3x3 / stride-1 / pad-1 convolution with split operands (three passes of the fp32-staged bf16 kernels
+    into the same accumulators: dY_hi X_hi + dY_hi X_lo + dY_lo X_hi; both the 8-pixel-row fast form and the general one) and the
+    bias gradient (sum of dY_hi + dY_lo) against fp64 on the unrounded operands."""
+    N, C0, C1, Co, Hh, Ww, m0 = case
+    g = torch.Generator().manual_seed(Co + Hh)
+    hs, ws_ = (Hh // 2, Ww // 2) if m0 else (Hh, Ww)
+    x0 = torch.randn(N, C0, hs, ws_, generator=g) + 6.0
+    x1 = (torch.randn(N, C1, Hh, Ww, generator=g) - 3.0) if C1 else None
+    dy = torch.randn(N, Co, Hh, Ww, generator=g) + 0.7
+    xin = x0.double()
+    if m0 == 1:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    if C1:
+        xin = torch.cat([xin, x1.double()], 1)
+    wref = torch.zeros(Co, C0 + C1, 3, 3, dtype=torch.float64, requires_grad=True)
+    bref = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, wref, bref, padding=1).backward(dy.double())
+    errs = {}
+    for comp in (H.COMPUTE_BF16X3, H.COMPUTE_BF16):
+        spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, mode0=m0, compute=comp)
+        dw, db = torch.full((Co, C0 + C1, 3, 3), float('nan'), device='cuda'), torch.full((Co,), float('nan'), device='cuda')
+        H.conv_wgrad(spec, dev(x0), dev(x1) if C1 else None, dev(dy), dw, db)
+        errs[comp] = (relerr(dw.cpu().double(), wref.grad), relerr(db.cpu().double(), bref.grad))
+    (ew3, eb3), (ew1, eb1) = errs[H.COMPUTE_BF16X3], errs[H.COMPUTE_BF16]
+    print(f'wgrad max rel err vs fp64 -- bf16x3 dw {ew3:.2e} db {eb3:.2e}; bf16 dw {ew1:.2e} db {eb1:.2e}')
+    assert ew3 < 3e-5 and eb3 < 3e-5 and ew3 < ew1 / 30, (errs,)
+    # accumulate=True adds onto what is there
+    dw2 = torch.ones(Co, C0 + C1, 3, 3, device='cuda')
+    spec = H.conv_spec(N, Hh, Ww, C0, C1, Co, 3, 1, 1, mode0=m0, compute=H.COMPUTE_BF16X3)
+    H.conv_wgrad(spec, dev(x0), dev(x1) if C1 else None, dev(dy), dw2, None, accumulate=True)
+    assert relerr(dw2.cpu().double() - 1.0, wref.grad) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # Wide-tile 3x3 kernel (round 4, conv_bf16_wide.hip: five pixel blocks per matrix wave, 128 x 320 / 64 x 640 / 64 x 320 / 32 x 640
 # tiles, one workgroup per CU) against the 64 x 256-tile kernel it replaces where its round count wins: both accumulate chunk by
 # chunk, tap by tap in the same order and share the epilogue code, so the outputs must be BIT-identical -- every variant, every
