@@ -46,7 +46,7 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
 
 // weights for the tap-paired kernel: [tile][chunk of 8 channels][pair][half][cout][8]
 __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64_t total, int cot, int n_chunks, int ks, int cin,
-                                              int cout, int w_kind) {
+                                              int cout, int w_kind, int split) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int nt = ks * ks, np = (nt + 1) / 2;
@@ -55,6 +55,8 @@ __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64
   const int col = t % cot; t /= cot;
   const int hf = t & 1; t >>= 1;
   const int pr = t % np; t /= np;
+  int lo = 0;
+  if (split) { lo = (int)(t & 1); t >>= 1; }  // [tile][chunk][hi | lo][pair][half][cout][8]
   const int ch = t % n_chunks;
   const int ct = t / n_chunks;
   const int tap = 2 * pr + hf, c = ch * 8 + kp, row = ct * cot + col;
@@ -64,7 +66,8 @@ __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64
     if (w_kind == ESS_W_CONV) v = w[(((size_t)row * cin + c) * ks + ky) * ks + kx];
     else v = w[(((size_t)c * cout + row) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
   }
-  out[i] = (__bf16)v;
+  const __bf16 hi = (__bf16)v;
+  out[i] = lo ? (__bf16)(v - (float)hi) : hi;
 }
 }  // namespace
 
@@ -73,10 +76,9 @@ namespace essconv {
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
                            hipStream_t st, bool split) {
   const int64_t total = pl.packed_elems;
-  ESS_CHECK_ARG(!split || !is_paired(d), "pack_weights: split operands exist for the 3x3 / stride-1 kernel only");
   if (is_paired(d)) {
     hipLaunchKernelGGL(pack_weights_bf16_pair_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, (__bf16*)packed, total,
-                       pl.cout_tile, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, w_kind);
+                       pl.cout_tile, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, w_kind, split ? 1 : 0);
     return ess_launch_status("pack_weights_bf16(paired)");
   }
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, w2, (__bf16*)packed,
@@ -224,14 +226,14 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const bool c8 = a.fmt0 == ESS_FMT_BF16_C8;
-  ESS_CHECK_ARG(!a.split || (ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16 && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
-                "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised kernel with fp32 tensors");
+  ESS_CHECK_ARG(!a.split || (((ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) || is_paired(d)) && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
+                "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised and the 5x5 tap-paired kernels with fp32 tensors");
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
   if (!c8 && !a.residual && conv_bf16_stem_applies(d, pl)) {  // 1-channel 7x7 / stride 2 stem: K = the filter rows
     conv_bf16_launch_stem(d, pl, st, a);
     return ess_launch_status("conv2d_forward(bf16, 7x7 stem)");
   }
-  if (is_paired(d) && !c8 && !a.residual && conv_bf16_head_applies(d, pl)) {  // 2-channel 5x5 head: K = the filter rows
+  if (is_paired(d) && !c8 && !a.residual && !a.split && conv_bf16_head_applies(d, pl)) {  // 2-channel 5x5 head: K = the filter rows
     conv_bf16_launch_head(d, pl, st, a);
     return ess_launch_status("conv2d_forward(bf16, 5x5 head)");
   }

@@ -169,7 +169,13 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
       struct Raw8 { float v[8]; };
       Raw8 pre[KPC];
       u32x4 wpre[WV];
-      auto load_chunk = [&](int ch) {
+      // split operands (a.split, ESS_COMPUTE_BF16X3): 3 * n_chunks virtual chunks, chunk vc / 3 staged as (w_hi, x_hi), (w_hi, x_lo),
+      // (w_lo, x_hi) -- conv_bf16_ws.hip has the same scheme; the weight pack holds a hi and a lo slab per (tile, chunk)
+      const int nvc = a.split ? 3 * a.n_chunks : a.n_chunks;
+      const u32x4* wbase_s = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ * (a.split ? 2 : 1);
+      auto load_chunk = [&](int vc) {
+        const int ch = a.split ? vc / 3 : vc;
+        const int w_lo = a.split && (vc - 3 * ch) == 2 ? 1 : 0;
         const int c0 = ch * 8;
         const bool first = c0 < a.C0 || a.C1 == 0;
         const unsigned pls = first ? pl0 : pl1;
@@ -181,27 +187,37 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
           for (int j = 0; j < 8; ++j)
             pre[k].v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
         }
-        const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+        const u32x4* wsrc = wbase_s + (size_t)(a.split ? 2 * ch + w_lo : ch) * WSZ;
 #pragma unroll
         for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
       };
-      auto commit = [&](int buf) {
-        u32x4* in_t = smem16 + buf * bufsz;
+      auto commit = [&](int vc) {  // (the values `pre` holds belong to virtual chunk vc)
+        u32x4* in_t = smem16 + (vc & 1) * bufsz;
         u32x4* w_t = in_t + a.plane;
+        const bool x_lo = a.split && (vc % 3) == 1;
 #pragma unroll
         for (int k = 0; k < KPC; ++k)
-          if (v_lds[k] >= 0) in_t[v_lds[k]] = pack8(pre[k].v);
+          if (v_lds[k] >= 0) {
+            if (x_lo) {
+              float lo[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) lo[j] = pre[k].v[j] - (float)(__bf16)pre[k].v[j];
+              in_t[v_lds[k]] = pack8(lo);
+            } else {
+              in_t[v_lds[k]] = pack8(pre[k].v);
+            }
+          }
 #pragma unroll
         for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
       };
       load_chunk(0);
       commit(0);
-      if (a.n_chunks > 1) load_chunk(1);
+      if (nvc > 1) load_chunk(1);
       __syncthreads();
-      for (int ch = 0; ch < a.n_chunks; ++ch) {
-        if (ch + 1 < a.n_chunks) {
-          commit((ch + 1) & 1);
-          if (ch + 2 < a.n_chunks) load_chunk(ch + 2);
+      for (int vc = 0; vc < nvc; ++vc) {
+        if (vc + 1 < nvc) {
+          commit(vc + 1);
+          if (vc + 2 < nvc) load_chunk(vc + 2);
         }
         __syncthreads();
       }
@@ -254,7 +270,8 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
   struct Frags { u32x4 a[MB]; u32x4 b[NBW]; };
   constexpr int NR = MB + NBW;  // LDS reads per pair
   constexpr int D = MB == 1 ? 2 : 1;  // pairs the reads run ahead (64-row tiles: a pair is 128 cycles of MFMAs, and 128 registers hold two sets)
-  for (int ch = 0; ch < a.n_chunks; ++ch) {
+  const int nvc_c = a.split ? 3 * a.n_chunks : a.n_chunks;  // (split operands: three virtual chunks per chunk, see the staging waves)
+  for (int ch = 0; ch < nvc_c; ++ch) {
     const unsigned stage_b = lds0 + (unsigned)((ch & 1) * bufsz * 16);
     const unsigned wa = stage_b + a_base;
     unsigned ba[NBW];

@@ -1218,9 +1218,14 @@ struct ResolvedDesc { EssConvDesc d; bool split; };
 inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
   ResolvedDesc r{*d, false};
   if (d->compute == ESS_COMPUTE_BF16X3) {
+    // 3x3 / stride 1 (any epilogue): the wave-specialised kernel; 5x5 LINEAR with at least one 8-channel chunk of input (the
+    // frozen E2VID's stride-2 encoder convolutions and upsample-conv decoders): the tap-paired kernel.  The 2-channel 5x5 head
+    // stays exact fp32 -- three passes over a chunk that is 6/8 padding would cost twice the fp32 kernel
+    static const bool pair_on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
     const bool ws = d->ksize == 3 && d->stride == 1 && ws_enabled();
-    r.d.compute = ws ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
-    r.split = ws;
+    const bool pair = d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR && d->C0 + d->C1 >= 8 && pair_on;
+    r.d.compute = (ws || pair) ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
+    r.split = ws || pair;
   }
   return r;
 }
@@ -1418,7 +1423,7 @@ inline void make_plan(const EssConvDesc* d, EssConvPlan* pl, bool split = false)
   const Geom g = choose_geom(d);
   if (is_paired(d)) {
     const int np = (d->ksize * d->ksize + 1) / 2;  // tap pairs; 16 k-values each
-    pl->packed_elems = (int64_t)pl->rows_padded * pl->n_chunks * np * 16;
+    pl->packed_elems = (int64_t)pl->rows_padded * pl->n_chunks * np * 16 * (split ? 2 : 1);  // (split: a hi and a lo slab per chunk)
     pl->packed_bytes = pl->packed_elems * 2;
     pl->lds_bytes = (g.plane + np * 2 * pl->cout_tile) * 16;  // one stage; the kernel double-buffers
   } else if (is_bf16(d)) {

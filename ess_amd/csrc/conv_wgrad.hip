@@ -987,8 +987,40 @@ static EssConvDesc wresolve(const EssConvDesc* d, bool* split) {
   return r;
 }
 
+// Split operands through the BF16_C8 kernel (conv_wgrad_c8.hip: LDS-DMA staging, twice the rate of the fp32-staged kernels): X and
+// dY are split ONCE into hi / lo BF16_C8 copies (workspace), then three accumulating launches -- (dY_hi, X_hi), (dY_hi, X_lo),
+// (dY_lo, X_hi).  Needs whole 8-channel blocks where the BF16_C8 kernels do; otherwise the fp32-staged kernels make three passes.
+int ess_split_bf16_c8_internal(const float* x, void* hi, void* lo, int N, int C, int H, int W, hipStream_t st);
+static bool split_via_c8(const EssConvDesc* d) {
+  static const bool on = [] { const char* e = getenv("ESS_X3_WGRAD_C8"); return !(e && e[0] == '0'); }();
+  return on && d->compute == ESS_COMPUTE_BF16X3 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && (d->C1 == 0 || (d->C0 % 8) == 0) &&
+         d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2 && (d->C1 == 0 || d->mode1 == ESS_SRC_DIRECT);
+}
+static EssConvDesc c8_desc(const EssConvDesc* d) {
+  EssConvDesc c = *d;
+  c.compute = ESS_COMPUTE_BF16;
+  c.fmt0 = c.fmt1 = c.fmt_out = ESS_FMT_BF16_C8;
+  return c;
+}
+static size_t c8_copy_bytes(int N, int C, int H, int W) { return (((size_t)N * ((C + 7) / 8) * H * W * 16) + 255) & ~(size_t)255; }
+struct SplitCopies { size_t x0, x1, dy, total; };
+static SplitCopies split_copies(const EssConvDesc* d) {
+  SplitCopies s{};
+  const int s0 = d->mode0 != ESS_SRC_DIRECT ? 1 : 0, s1 = d->mode1 != ESS_SRC_DIRECT ? 1 : 0;
+  s.x0 = c8_copy_bytes(d->N, d->C0, d->H_in >> s0, d->W_in >> s0);
+  s.x1 = d->C1 ? c8_copy_bytes(d->N, d->C1, d->H_in >> s1, d->W_in >> s1) : 0;
+  s.dy = c8_copy_bytes(d->N, d->C_out, d->H_out, d->W_out);
+  s.total = 2 * (s.x0 + s.x1 + s.dy);
+  return s;
+}
+
 extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   if (wvalidate(d)) return 0;
+  if (split_via_c8(d)) {
+    const EssConvDesc dc = c8_desc(d);
+    const size_t slabs = (ess_conv2d_wgrad_workspace(&dc) + 255) & ~(size_t)255;
+    return slabs ? slabs + split_copies(d).total : 0;
+  }
   bool osplit;
   const EssConvDesc dres = wresolve(d, &osplit);
   d = &dres;
@@ -1002,6 +1034,27 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
   const float* src0 = (const float*)src0_; const float* src1 = (const float*)src1_; const float* dy = (const float*)dy_;
   int rc = wvalidate(d);
   if (rc) return rc;
+  if (split_via_c8(d)) {
+    ESS_CHECK_ARG(src0 && dy && dw && workspace, "wgrad: null pointer");
+    ESS_CHECK_ARG(d->C1 == 0 || src1, "wgrad: second source missing");
+    ESS_CHECK_ARG((((uintptr_t)workspace) & 255) == 0, "wgrad: the workspace must be 256-byte aligned");
+    const EssConvDesc dc = c8_desc(d);
+    const size_t slabs = (ess_conv2d_wgrad_workspace(&dc) + 255) & ~(size_t)255;
+    const SplitCopies sc = split_copies(d);
+    ESS_CHECK_ARG(slabs && workspace_bytes >= slabs + sc.total, "wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace + slabs;
+    char* x0h = base; char* x0l = x0h + sc.x0;
+    char* x1h = x0l + sc.x0; char* x1l = x1h + sc.x1;
+    char* dyh = x1l + sc.x1; char* dyl = dyh + sc.dy;
+    const int s0 = d->mode0 != ESS_SRC_DIRECT ? 1 : 0, s1 = d->mode1 != ESS_SRC_DIRECT ? 1 : 0;
+    if ((rc = ess_split_bf16_c8_internal(src0, x0h, x0l, d->N, d->C0, d->H_in >> s0, d->W_in >> s0, st))) return rc;
+    if (d->C1 && (rc = ess_split_bf16_c8_internal(src1, x1h, x1l, d->N, d->C1, d->H_in >> s1, d->W_in >> s1, st))) return rc;
+    if ((rc = ess_split_bf16_c8_internal(dy, dyh, dyl, d->N, d->C_out, d->H_out, d->W_out, st))) return rc;
+    if ((rc = ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyh, dw, db, accumulate, workspace, slabs, stream))) return rc;
+    if ((rc = ess_conv2d_wgrad(&dc, x0l, d->C1 ? x1l : nullptr, dyh, dw, nullptr, 1, workspace, slabs, stream))) return rc;
+    return ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyl, dw, db, 1, workspace, slabs, stream);
+  }
   bool osplit;
   const EssConvDesc dres = wresolve(d, &osplit);
   d = &dres;

@@ -529,6 +529,39 @@ extern "C" int ess_resize_nearest(const float* x, float* y, int32_t planes, int3
   return ess_launch_status("resize_nearest");
 }
 
+// split operands (ESS_COMPUTE_BF16X3): fp32 NCHW -> TWO BF16_C8 tensors, hi = bf16(v) and lo = bf16(v - hi); v = hi + lo to ~2^-17
+namespace {
+__global__ __launch_bounds__(256) void split_bf16_c8_kernel(const float* __restrict__ x, uint4* __restrict__ yh, uint4* __restrict__ yl,
+                                                            int C, int64_t hw, int64_t total) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int nblk = (C + 7) >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % hw, nb = i / hw;
+    const int blk = (int)(nb % nblk);
+    const int64_t n = nb / nblk;
+    const float* p = x + ((size_t)n * C + (size_t)blk * 8) * hw + pix;
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = blk * 8 + j < C ? p[(size_t)j * hw] : 0.f;
+      h[j] = (__bf16)v;
+      l[j] = (__bf16)(v - (float)h[j]);
+    }
+    yh[i] = __builtin_bit_cast(uint4, h);
+    yl[i] = __builtin_bit_cast(uint4, l);
+  }
+}
+}  // namespace
+
+// (library-internal: used by ess_conv2d_wgrad's split-operand path; not part of the C ABI)
+int ess_split_bf16_c8_internal(const float* x, void* hi, void* lo, int N, int C, int H, int W, hipStream_t st) {
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * ((C + 7) / 8) * hw;
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(split_bf16_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (uint4*)hi, (uint4*)lo, C, hw, total);
+  return ess_launch_status("split_bf16_c8");
+}
+
 extern "C" int ess_to_bf16_c8(const float* x, void* y, int N, int C, int H, int W, ess_stream_t stream) {
   ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "to_bf16_c8: bad arguments");
   const int64_t hw = (int64_t)H * W, total = (int64_t)N * ((C + 7) / 8) * hw;

@@ -711,6 +711,27 @@ def test_conv_split_operand_bf16x3(H, case):
     assert e3 < 2e-5 and e3 < e1 / 50, (e3, e1, e0)
 
 
+@pytest.mark.parametrize('case', [(2, 32, 64, 24, 40, 2), (1, 64, 32, 20, 36, 1), (2, 2, 32, 16, 24, 1)])
+def test_conv5x5_split_operand_bf16x3(H, case):
+    """5x5 convolutions under ESS_COMPUTE_BF16X3: with at least one 8-channel chunk of input the tap-paired kernel runs them with
+    split operands (the frozen E2VID's stride-2 encoder convolutions and upsample-conv decoders); the 2-channel head stays on the
+    exact-fp32 kernel.  Either way the result is within ~1e-5 of fp64 on the unrounded operands."""
+    N, Ci, Co, Hh, Ww, st = case
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(N, Ci, Hh, Ww, generator=g) + 4.0
+    w = torch.randn(Co, Ci, 5, 5, generator=g) / (25 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=st, padding=2))
+    errs = {}
+    for comp in (H.COMPUTE_BF16X3, H.COMPUTE_BF16):
+        spec = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 5, st, 2, act=H.ACT_RELU, compute=comp)
+        out = torch.full((N, Co, spec.H_out, spec.W_out), float('nan'), device='cuda')
+        H.conv_forward(spec, dev(x), None, H.pack_weights(spec, dev(w)), None, H.pack_rows(spec, dev(b)), out=out)
+        errs[comp] = relerr(out.cpu().double(), ref)
+    print(f'5x5 s{st} {Ci}->{Co}: max rel err vs fp64 -- bf16x3 {errs[H.COMPUTE_BF16X3]:.2e}, bf16 {errs[H.COMPUTE_BF16]:.2e}')
+    assert errs[H.COMPUTE_BF16X3] < 2e-5 and errs[H.COMPUTE_BF16X3] < errs[H.COMPUTE_BF16] / 50
+
+
 @pytest.mark.parametrize('case', [(2, 64, 0, 64, 24, 40, 0), (2, 32, 32, 96, 16, 24, 1), (1, 24, 0, 40, 17, 30, 0), (2, 128, 0, 128, 12, 24, 0)])
 def test_conv_wgrad_split_operand_bf16x3(H, case):
     """The weight gradient of a 3x3 / stride-1 / pad-1 convolution with split operands (three passes of the fp32-staged bf16 kernels
