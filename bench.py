@@ -146,14 +146,38 @@ def decoder_conv3x3_layers(args):
 
 
 def _traffic_from_profiles(tag):
-    """HBM bytes per launch set from the PMC passes of tools/pmc_traffic.py (rocprofv3 --pmc, separate passes, the guide's gfx950
-    unit corrections), committed as profiles/r3_traffic.json (builder-side PMC passes, not re-measured in this run); None when this shape / kernel was not profiled."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r3_traffic.json')) as f:
-            t = json.load(f).get(tag)
-    except (OSError, ValueError):
-        return None
-    return t
+    """HBM bytes per launch set and the SQ-counter readings of the same launches (mfma_busy, sclk, LDS) from the PMC passes of
+    tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r4_traffic.json
+    (builder-side PMC passes over tools/traffic_probe.py, not re-measured in this run -- rocprofv3 cannot wrap a process from the
+    inside); falls back to round 3's file; None when this shape / kernel was not profiled."""
+    for name in ('r4_traffic.json', 'r3_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                t = json.load(f).get(tag)
+        except (OSError, ValueError):
+            t = None
+        if t is not None:
+            t = dict(t)
+            t['file'] = 'profiles/' + name
+            return t
+    return None
+
+
+def _pmc_summary(t):
+    """the scalar counter readings of a traffic record, for the top of a `roofline` block"""
+    if not t:
+        return {}
+    out = {k: t[k] for k in ('mfma_busy', 'hbm_GBps') if k in t}
+    clk = [l['sclk_GHz'] for l in t.get('layers', []) if 'sclk_GHz' in l]
+    if clk:
+        out['sclk_GHz'] = round(sum(clk) / len(clk), 3)
+        if 'mfma_busy' in out:
+            out['mfma_busy_at_sclk'] = round(out['mfma_busy'] * 2.4 / out['sclk_GHz'], 4)
+    if out:
+        out['pmc_note'] = ('rocprofv3 --pmc passes (profiles/r4_conv_pmc.txt): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) -- matrix-pipe '
+                           'issue slots used at the NOMINAL clock; sclk_GHz = SQ_BUSY_CYCLES / 32 shader engines / kernel time, the clock the launches ran at; '
+                           'mfma_busy_at_sclk = the same slots against that clock; hbm_GBps = (2 FETCH_SIZE + WRITE_SIZE) / kernel time against the 8 TB/s HBM3E peak')
+    return out
 
 
 def roofline_blocks(args, device):
@@ -253,25 +277,26 @@ def roofline_blocks(args, device):
         gru_ms += ms1 + ms2; gru_fl += fl
     tag = f'{args.compute}/{B}/{args.height}x{args.width}'
     conv_t = conv_fl / conv_ms / 1e9
-    return {'bound': 'mfma',
+    t_conv, t_gate, t_gru, t_wg = [_traffic_from_profiles(g_ + '/' + tag) for g_ in ('conv3x3', 'gate', 'gru', 'wgrad')]
+    return {'bound': 'mfma', **_pmc_summary(t_conv),
             'kernel': ('conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> | conv_bf16_wide_kernel<MBW, CW> (plain 3x3 conv of the trainable networks; picked per launch by round count)' if bf16
                        else 'conv_f32_kernel<3,1,MB,LINEAR,8>') + ': the 16 launches of one decoder forward',
             'achieved': round(conv_t, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(conv_t / peak, 4),
-            'traffic': _traffic_from_profiles('conv3x3/' + tag), 'ms_per_launch_set': round(conv_ms, 4), 'per_layer': per_layer,
+            'traffic': t_conv, 'ms_per_launch_set': round(conv_ms, 4), 'per_layer': per_layer,
             'others': {
                 'convlstm_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
                                   'achieved': round(gate_fl / gate_ms / 1e9, 1), 'frac': round(gate_fl / gate_ms / 1e9 / peak, 4),
-                                  'per_level': gate_levels, 'traffic': _traffic_from_profiles('gate/' + tag)},
+                                  **_pmc_summary(t_gate), 'per_level': gate_levels, 'traffic': t_gate},
                 'convgru_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, GRU_UR | GRU_OUT, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,GRU_UR | GRU_OUT,8>',
                                  'achieved': round(gru_fl / gru_ms / 1e9, 1), 'frac': round(gru_fl / gru_ms / 1e9 / peak, 4),
-                                 'per_level': gru_levels, 'traffic': _traffic_from_profiles('gru/' + tag)},
+                                 **_pmc_summary(t_gru), 'per_level': gru_levels, 'traffic': t_gru},
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
-                          'ms_per_launch_set': round(wg_ms, 4)}},
+                          **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
                     '; HIP events on the launch stream, inside this process after the timed steps; launch sets repeated back to back, i.e. '
                     'at the sustained-matrix-load clock (the same kernels inside the step, between HBM-bound launches, run 5-20 % faster: '
-                    'rocprofv3 averages in profiles/r3_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7c)'}
+                    'rocprofv3 averages in profiles/r4_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7d)'}
 
 
 def executed_flops_per_step(args):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""HBM traffic of the dominant kernels from hardware counters -> profiles/r3_traffic.json (read by bench.py's `roofline.traffic`).
+"""(round 3 tool, superseded by tools/pmc_r4.py, which also handles the probe's warm-up launches and the wide-tile kernel.)
+HBM traffic of the dominant kernels from hardware counters -> profiles/r3_traffic.json (read by bench.py's `roofline.traffic`).
 
 Run ON THE GPU BOX from the repo root:   python tools/pmc_traffic.py [outdir=gpurun_out/pmc_traffic]
 Recipe (MI355X_MICROARCH.md, section HBM / rocprofv3): two SEPARATE rocprofv3 --pmc passes over tools/traffic_probe.py

@@ -17,6 +17,7 @@ import bench  # noqa: E402
 from ess_amd import hip  # noqa: E402
 
 REPS = 4
+WARM = 3  # unmeasured launches in front of every block (the first launches after an idle gap run at a cold clock)
 hip.lib()
 hip.set_compute('bf16')
 args = bench.parse() if False else type('A', (), dict(batch=8, height=480, width=640))()
@@ -38,14 +39,24 @@ for (C0, C1, Cout, Hv, Wv, m0, cnt) in bench.decoder_conv3x3_layers(args):
     pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(Cout, generator=g).to(dev))
     out = hip.bf16_c8_empty(B, Cout, Hv, Wv, dev)
     torch.cuda.synchronize()
-    for _ in range(REPS):
+    for _ in range(WARM + REPS):
         hip.conv_forward(spec, x0, x1, pw, None, pb, out=out, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)
     torch.cuda.synchronize()
     px_in = B * (C0 * (Hv * Wv // (4 if m0 else 1)) + C1 * Hv * Wv)
-    plan.append({'group': 'conv3x3', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
-                 'count': cnt, 'reps': REPS, 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 2 * 9 * (C0 + C1) * Cout,
+    plan.append({'group': 'conv3x3', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
+                 'count': cnt, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 2 * 9 * (C0 + C1) * Cout,
                  'flops': 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout})
-    del x0, x1, out
+    # weight gradient of the same layer (BF16_C8 X and dY; split-K slabs + reduce = two dispatches per call)
+    dy = act(Cout, Hv, Wv)
+    dw, db = torch.empty_like(w), torch.empty(Cout, device=dev)
+    for _ in range(WARM + REPS):
+        hip.conv_wgrad(spec, x0, x1, dy, dw, db)
+    torch.cuda.synchronize()
+    plan.append({'group': 'wgrad', 'kernel': 'wgrad_c8_ws_kernel|wgrad_reduce_kernel|wgrad_c8_kernel', 'disp_per_rep': 2, 'warm': WARM,
+                 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''), 'count': cnt, 'reps': REPS,
+                 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 4 * 9 * (C0 + C1) * Cout,
+                 'flops': 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout})
+    del x0, x1, out, dy
 for lvl, hid in enumerate((64, 128, 256)):
     H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
     spec = hip.conv_spec(B, H, W, hid, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid)
@@ -56,12 +67,12 @@ for lvl, hid in enumerate((64, 128, 256)):
     c = torch.randn(B, hid, H, W, generator=g).to(dev).view(B, hid // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
     co, hb = hip.f32_c8_empty(B, hid, H, W, dev), hip.bf16_c8_empty(B, hid, H, W, dev)
     torch.cuda.synchronize()
-    for _ in range(REPS):
+    for _ in range(WARM + REPS):
         hip.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_bf=hb, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_F32_C8,
                          aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     n = B * hid * H * W
-    plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS,
+    plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS, 'warm': WARM,
                  'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 4 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)})
 # ---- ConvGRU pair (lean launches of ConvGRU.forward): (update, reset) kernel, then candidate kernel
@@ -79,18 +90,18 @@ for lvl, hid in enumerate((64, 128, 256)):
     rh8, hn8 = hip.bf16_c8_empty(B, hid, H, W, dev), hip.bf16_c8_empty(B, hid, H, W, dev)
     n = B * hid * H * W
     torch.cuda.synchronize()
-    for _ in range(REPS):
+    for _ in range(WARM + REPS):
         hip.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_F32_C8,
                          aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} update+reset', 'count': 1,
-                 'reps': REPS, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
+                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (2 * hid)})
-    for _ in range(REPS):
+    for _ in range(WARM + REPS):
         hip.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=hip.FMT_BF16_C8,
                          out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} candidate', 'count': 1,
-                 'reps': REPS, 'algorithmic_bytes': 2 * 2 * n + (4 + 4) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
+                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + (4 + 4) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * hid})
 print('PLAN ' + json.dumps(plan))
