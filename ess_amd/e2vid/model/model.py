@@ -6,7 +6,7 @@ BaseE2VID (model.py:9-44): skip_type 'sum', num_encoders 4, base_num_channels 32
 norm None, use_upsample_conv True, recurrent_block_type 'convlstm'.
 """
 from ..base import BaseModel
-from .unet import UNet, UNetDecoder, UNetRecurrent
+from .unet import UNet, UNetDecoder, UNetRecurrent, UNetTask
 
 
 class BaseE2VID(BaseModel):
@@ -64,4 +64,17 @@ class E2VIDDecoder(BaseE2VID):
         return self.unetrecurrent.forward(x, blocks, head)
 
 
-ARCHS = {'E2VID': E2VID, 'E2VIDRecurrent': E2VIDRecurrent, 'E2VIDDecoder': E2VIDDecoder}
+class E2VIDTask(BaseE2VID):
+    """E2VID's decoder half with a 13-class semantic head on the latents (reference model.py:135-166)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        kw = self._unet_kwargs()
+        kw['num_output_channels'] = 13
+        self.unetrecurrent = UNetTask(recurrent_block_type=self.recurrent_block_type, **kw)
+
+    def forward(self, input_dict):
+        return self.unetrecurrent.forward(input_dict)
+
+
+ARCHS = {'E2VID': E2VID, 'E2VIDRecurrent': E2VIDRecurrent, 'E2VIDDecoder': E2VIDDecoder, 'E2VIDTask': E2VIDTask}

@@ -191,3 +191,49 @@ class UNetDecoder(BaseUNet):
 
     def forward(self, x, blocks, head):
         return self._tail(x, blocks, head)
+
+
+class UNetTask(BaseUNet):
+    """resblocks + decoders + a two-layer 1x1 semantic head on E2VID latents (reference unet.py:222-279): the decoder half of an E2VID
+    checkpoint re-purposed as a task network.  forward({1, 2, 4, 8}) -> {8: the input latent, 4 / 2: decoder outputs, 1: logits}.
+    The reference adds an all-zero "head" skip of hard-coded size (N, 32, 256, 512) ahead of the prediction layers (unet.py:264,276):
+    for 'sum' skips that is the identity, for 'concat' a block of zero channels -- here a zero tensor of the decoder output's own
+    size, read through the convolution's second source."""
+
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', recurrent_block_type='convlstm',
+                 activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
+                 use_upsample_conv=True):
+        super().__init__(num_input_channels, num_output_channels, skip_type, activation, num_encoders, base_num_channels,
+                         num_residual_blocks, norm, use_upsample_conv)
+        self.build_resblocks()
+        self.build_decoders()
+        self.build_prediction_layer_semseg()
+
+    def build_prediction_layer_semseg(self):
+        c = self.base_num_channels if self.skip_type == 'sum' else 2 * self.base_num_channels
+        self.pred_semseg = nn.Sequential(ConvLayer(c, c, 1, activation='relu', norm=self.norm),
+                                         ConvLayer(c, self.num_output_channels, 1, activation=None, norm=None))
+
+    def update_skip_dict(self, skips, x, sz_in):
+        rem, scale = sz_in % x.shape[3], sz_in // x.shape[3]
+        assert rem == 0
+        skips[scale] = x
+
+    def forward(self, input_dict):
+        sz_in = input_dict[1].shape[3]
+        x = input_dict[8]
+        out = {8: x}
+        blocks = [input_dict[2], input_dict[4], input_dict[8]]
+        for resblock in self.resblocks:
+            x = resblock(x)
+        for i, decoder in enumerate(self.decoders):
+            x = self._skip_decode(decoder, x, blocks[self.num_encoders - i - 1])
+            self.update_skip_dict(out, x, sz_in)
+        if self.skip_type == 'sum':
+            y = self.pred_semseg[0](x)  # (x + zeros)
+        else:
+            y = self.pred_semseg[0](x, x1=torch.zeros(x.shape[0], self.base_num_channels, x.shape[2], x.shape[3], device=x.device))
+        pred = self.pred_semseg[1](y)
+        self.update_skip_dict(out, pred, sz_in)
+        return out
+

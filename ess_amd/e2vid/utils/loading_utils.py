@@ -3,11 +3,11 @@ from collections import OrderedDict
 
 import torch
 
-from ..model.model import ARCHS, E2VIDDecoder
+from ..model.model import ARCHS, E2VIDDecoder, E2VIDTask
 
 
 def load_model(path_to_model, return_task=False):
-    """E2VID checkpoint -> (model, decoder).  Checkpoint layout as the reference expects (loading_utils.py:5-38):
+    """E2VID checkpoint -> (model, decoder) or, with return_task, (model, decoder, task).  Checkpoint layout as the reference expects (loading_utils.py:5-38):
     {'arch': class name, 'model' | 'config'['model']: config dict, 'state_dict': weights}.  `arch` is looked up
     in a table instead of being eval()'d."""
     print('Loading model {}...'.format(path_to_model))
@@ -21,8 +21,12 @@ def load_model(path_to_model, return_task=False):
     decoder = E2VIDDecoder(model_type)
     decoder.load_state_dict(raw_model['state_dict'], strict=False)
     if return_task:
-        raise NotImplementedError('E2VIDTask is not on the ESS training path (training/ess_trainer.py:51 uses '
-                                  'load_model(path) only)')
+        # E2VIDTask: the checkpoint's residual blocks and decoders under a fresh semantic head; the image prediction layer's
+        # weights are dropped (reference loading_utils.py:25-37)
+        task = E2VIDTask(model_type)
+        new_dict = copyStateDict(raw_model['state_dict'])
+        task.load_state_dict({k: v for k, v in new_dict.items() if not k.startswith('unetrecurrent.pred')}, strict=False)
+        return model, decoder, task
     return model, decoder
 
 

@@ -167,6 +167,30 @@ def gold_e2vid(R, out):
     out['e2vid'] = gold
 
 
+def gold_e2vid_task(R, out):
+    """E2VIDTask / UNetTask (e2vid/model/model.py:135-166, unet.py:222-279) on seeded latents.  The reference hard-codes the zero head
+    skip at (N, 32, 256, 512), so the decoder output must be 256 x 512 with 32 base channels: latents at 32 x 64 / 64 x 128 / 128 x 256.
+    Stored: the two decoder outputs and the logits on an 8 x 8 pixel grid + sum / abs-sum / L2 of the full tensors."""
+    gold = []
+    for i, (norm, skip) in enumerate((('BN', 'sum'), ('none', 'sum'))):
+        cfg = O.e2vid_config(num_bins=2, norm=norm, skip_type=skip, base_num_channels=32, num_encoders=3)
+        model = R.model.E2VIDTask(dict(cfg))
+        model.unetrecurrent.device = torch.device('cpu')
+        shapes = O.e2vid_task_param_shapes(cfg)
+        check_layout(model, shapes, f'E2VIDTask {norm} {skip}')
+        sd = O.synth_state_dict(shapes, seed=300 + i)
+        model.load_state_dict(sd)
+        model.eval()
+        g = torch.Generator().manual_seed(400 + i)
+        lat = {1: torch.zeros(1, 1, 256, 512), 2: torch.randn(1, 64, 128, 256, generator=g), 4: torch.randn(1, 128, 64, 128, generator=g),
+               8: torch.randn(1, 256, 32, 64, generator=g)}
+        res = model(lat)
+        assert sorted(res) == [1, 2, 4, 8] and res[8] is lat[8]
+        gold.append(dict(cfg=cfg, wseed=300 + i, lseed=400 + i,
+                         grid={k: res[k][:, :, ::8, ::8].clone() for k in (1, 2, 4)}, stats={k: stats(res[k]) for k in (1, 2, 4)}))
+    out['e2vid_task'] = gold
+
+
 def gold_normalize(R, out):
     pre = R.iu.EventPreprocessor(e2vid_options())
     g = torch.Generator().manual_seed(7)
@@ -480,6 +504,8 @@ def main():
             gold_e2vid(R, out)
         if want('metrics'):
             gold_metrics(R, out)
+        if want('e2vid_task'):
+            gold_e2vid_task(R, out)
     if want('semseg'):
         gold_semseg(R, out)
     if want('losses'):

@@ -158,3 +158,70 @@ def test_bf16_vs_fp32_loss_trajectory_20_steps():
         assert last < max(3 * first, 1e-2)
     finally:
         hip.set_compute('fp32')
+
+
+@pytest.mark.parametrize('kind', ['ess', 'ess_supervised'])
+def test_bf16x3_train_steps_track_fp32(kind):
+    """The split-operand configuration as a TRAINING arithmetic (forward, data-gradients, weight gradients of every 3x3 / stride-1
+    convolution through hi / lo bf16 parts): five train steps on the same batches from the same weights as the exact-fp32 HIP path.
+    SGD phase of RAdam (steps 1-5): every loss term within 2e-5 relative (1e-6 absolute for the terms near zero), first-step decoder
+    gradients within 5e-2 (rel-L2 per parameter: a gross-error guard, ReLU mask flips dominate -- see below), post-step weights
+    within 1e-5.  Also under the captured step (hipGraph): bit-identical to its own eager run."""
+    from ess_amd import hip
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_supervised_trainer import ESSSupervisedModel
+    from ess_amd.training.ess_trainer import ESSModel
+    from tests.test_hip_bf16_train import _noise_key
+    B, T, C, H, W, K = 2, 3, 2, 96, 128, 11
+    cfg = O.e2vid_config(num_bins=C)
+
+    def make(mode):
+        hip.set_compute(mode)
+        torch.manual_seed(6)
+        st = synthetic_settings(kind, 'DSEC_events', (H, W), K, B, T, C, train_on_event_labels=kind == 'ess_supervised')
+        tr = (ESSModel if kind == 'ess' else ESSSupervisedModel)(st)
+        tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), 161))
+        tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, K), 162, decoder_style=True))
+        if kind == 'ess':
+            tr.front_end_sensor_a.load_state_dict(O.synth_state_dict(O.style_encoder_param_shapes(1), 163))
+        return tr
+
+    def batch(s):
+        ev, img, lab_a, lab_b = O.synth_batch(B, T, C, H, W, K, seed=700 + s)
+        return [[img.cuda(), lab_a.cuda()], [ev.cuda(), lab_b.cuda()]] if kind == 'ess' else [ev.cuda(), lab_b.cuda()]
+
+    try:
+        runs = {}
+        for mode in ('fp32', 'bf16x3'):
+            tr = make(mode)
+            hist, g0 = [], None
+            for s in range(5):
+                losses, _, final = tr.train_step(batch(s))
+                hist.append({k: v.item() for k, v in losses.items()} | {'final': final.item()})
+                if s == 0:
+                    g0 = {n: p.grad.detach().clone() for n, p in tr.task_backend.named_parameters() if p.grad is not None}
+            torch.cuda.synchronize()
+            runs[mode] = (hist, g0, {k: v.detach().clone() for k, v in tr.task_backend.state_dict().items()})
+        (h32, g32, w32), (hx3, gx3, wx3) = runs['fp32'], runs['bf16x3']
+        worst = max(abs(a[k] - b[k]) / max(abs(a[k]), 5e-2) for a, b in zip(h32, hx3) for k in a)
+        gl = sorted(((gx3[n].double() - g32[n].double()).norm() / g32[n].double().norm().clamp(min=1e-20)).item() for n in g32 if not _noise_key(n))
+        gerr, gmed = gl[-1], gl[len(gl) // 2]
+        werr = max((wx3[k].double() - w32[k].double()).abs().max().item() for k in w32 if not _noise_key(k))
+        print(f'bf16x3 vs fp32 ({kind}): worst loss-term gap over 5 steps {worst:.2e}, first-step gradient rel-L2 worst {gerr:.2e} / median {gmed:.2e}, post-step weights {werr:.2e}')
+        # (gradients of this network are only piecewise continuous: at 96x128 the deep InstanceNorm planes have 192 pixels, ReLU
+        # pre-activations within rounding distance of zero flip their masks between ANY two arithmetics and move every upstream weight
+        # gradient by a percent while the loss moves 1e-6 -- DESIGN.md section 5 measured 5-16 % for a 1e-5 perturbation of the latents;
+        # the exact-fp32 HIP path against the fp32 oracle is held to 0.1 on the same quantity.  Gross-error guard here; the kernels'
+        # own accuracy is test_conv_split_operand_bf16x3 / test_conv_wgrad_split_operand_bf16x3: 1e-6 .. 9e-6 of fp64)
+        assert worst < 2e-5 and gerr < 5e-2 and werr < 1e-5, (worst, gerr, gmed, werr)
+        # captured step == eager step, bit for bit, in this configuration too
+        tr_e, tr_g = make('bf16x3'), make('bf16x3')
+        tr_g.enable_step_graph(batch(0), warmup=2)
+        tr_e.train_step(batch(0)), tr_e.train_step(batch(0))
+        for s in range(1, 4):
+            le, _, fe = tr_e.train_step(batch(s))
+            lg, _, fg = tr_g.train_step(batch(s))
+            assert fe.item() == fg.item() and all(le[k].item() == lg[k].item() for k in le), s
+    finally:
+        hip.set_compute('fp32')
+

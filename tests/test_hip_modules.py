@@ -107,6 +107,37 @@ def test_e2vid_concat_skips_vs_oracle(upsample, mode):
         hip.set_compute('fp32')
 
 
+@pytest.mark.parametrize('idx', range(2))
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_e2vid_task_vs_golden(golden, idx, mode):
+    """E2VIDTask (reference e2vid/model/model.py:135-166; loading_utils.load_model(..., return_task=True)) on the HIP kernels against
+    the outputs of the reference class: fp32 to 1e-4, bf16 operands to 3e-2 of the tensor's scale."""
+    from ess_amd import hip
+    from ess_amd.e2vid.model.model import E2VIDTask
+    g = golden('e2vid_task')[idx]
+    cfg = g['cfg']
+    sd = O.synth_state_dict(O.e2vid_task_param_shapes(cfg), g['wseed'])
+    gen = torch.Generator().manual_seed(g['lseed'])
+    lat = {1: torch.zeros(1, 1, 256, 512), 2: torch.randn(1, 64, 128, 256, generator=gen), 4: torch.randn(1, 128, 64, 128, generator=gen),
+           8: torch.randn(1, 256, 32, 64, generator=gen)}
+    hip.set_compute(mode)
+    try:
+        m = E2VIDTask(dict(cfg))
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+        m.load_state_dict(sd)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            res = m({k: v.cuda() for k, v in lat.items()})
+        assert sorted(res) == [1, 2, 4, 8] and res[1].shape == (1, 13, 256, 512)
+        tol = 1e-4 if mode == 'fp32' else 3e-2
+        for k in (1, 2, 4):
+            assert relerr(res[k][:, :, ::8, ::8], g['grid'][k]) < tol, k
+            if mode == 'fp32':
+                assert stats_close(stats(res[k]), g['stats'][k], 1e-4), k
+    finally:
+        hip.set_compute('fp32')
+
+
 @pytest.mark.parametrize('idx', range(3))
 def test_semseg_vs_golden(golden, idx):
     from ess_amd.models.style_networks import SemSegE2VID

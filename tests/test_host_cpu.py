@@ -259,6 +259,14 @@ def test_load_model_reads_the_reference_checkpoint_layout(tmp_path):
         assert all(torch.equal(got[k], sd[k]) for k in sd)
         assert model.num_bins == 2 and model.num_encoders == 3
         assert decoder is not None
+        # return_task (loading_utils.py:25-37): the checkpoint's resblocks / decoders under a fresh 13-class head; the image
+        # prediction layer's weights are not taken over, 'module.'-prefixed keys are accepted
+        m2, d2, task = load_model(str(path), return_task=True)
+        tsd = task.state_dict()
+        assert set(tsd) == set(O.e2vid_task_param_shapes(cfg)) and tsd['unetrecurrent.pred_semseg.1.conv2d.weight'].shape[0] == 13
+        shared = [k for k in tsd if k in sd]
+        assert shared and all(k.startswith(('unetrecurrent.resblocks.', 'unetrecurrent.decoders.')) for k in shared)
+        assert all(torch.equal(tsd[k], sd[k]) for k in shared)
     torch.save({'arch': '__import__("os").system("true")', 'model': dict(cfg), 'state_dict': sd}, tmp_path / 'bad.pth.tar')
     with pytest.raises(ValueError):
         load_model(str(tmp_path / 'bad.pth.tar'))

@@ -58,6 +58,28 @@ def test_e2vid_sequence(golden, idx):
     assert torch.equal(img2, img) and all(torch.equal(lat2[k], latent[k]) for k in latent)
 
 
+def _task_latents(seed):
+    g = torch.Generator().manual_seed(seed)
+    return {1: torch.zeros(1, 1, 256, 512), 2: torch.randn(1, 64, 128, 256, generator=g), 4: torch.randn(1, 128, 64, 128, generator=g),
+            8: torch.randn(1, 256, 32, 64, generator=g)}
+
+
+@pytest.mark.parametrize('idx', range(2))
+def test_e2vid_task(golden, idx):
+    """E2VIDTask / UNetTask (reference e2vid/model/model.py:135-166, unet.py:222-279): the oracle's restatement against the outputs of
+    the reference class itself (decoder outputs and logits on a pixel grid + whole-tensor statistics)."""
+    g = golden('e2vid_task')[idx]
+    cfg = g['cfg']
+    sd = O.synth_state_dict(O.e2vid_task_param_shapes(cfg), g['wseed'])
+    lat = _task_latents(g['lseed'])
+    with torch.no_grad():
+        res = O.e2vid_task(sd, cfg, lat)
+    assert sorted(res) == [1, 2, 4, 8] and res[8] is lat[8] and res[1].shape == (1, 13, 256, 512)
+    for k in (1, 2, 4):
+        assert close(res[k][:, :, ::8, ::8], g['grid'][k]), k
+        assert stats_close(stats(res[k]), g['stats'][k]), k
+
+
 @pytest.mark.parametrize('idx', range(3))
 def test_semseg_fwd_bwd(golden, idx):
     g = golden('semseg')[idx]
