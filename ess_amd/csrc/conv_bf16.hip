@@ -182,7 +182,31 @@ double std_cost(int tiles, int cot, int per_cu) {
   return (full + tail) * per_cu * cot * 256.0;
 }
 struct WidePick { int mbw, cw, th, tiles_x, tiles_y, tiles; };
+// the lean ConvLSTM step (BF16_C8 x / h, F32_C8 cell state in and out, bias in the accumulators: conv_epilogue_lstm_c8's form) on
+// the 128 x 320 tile.  One workgroup per CU exposes its epilogue per TILE, so the wide kernel pays on long-K launches: measured on
+// the lean launches themselves (trace_tmp-style A/B, B = 8, 480 x 640): level 0 386 -> 356 us, level 1 346 -> 328, level 2 (against the
+// ws kernel's 128-row instance) 347 -> 311: + 8 / 5 / 11 % -- the long K loops (8 - 32 chunks) amortise the exposed epilogue, and on real
+// data the wide tile's lower traffic per MFMA is worth more than its coarser rounds (power probe).  The round model
+// decides with a margin of its own (ESS_WIDE_KAPPA_REC, 0.9: the three levels at B = 8 pass, a quarter-filled single round does not).
+bool wide_pick_lstm(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
+  const int mode = wide_mode();
+  if (!mode || !c8 || d->epilogue != ESS_EPI_LSTM) return false;
+  if (a.fmt_out != ESS_FMT_F32_C8 || (a.aux0 && a.fmt_res != ESS_FMT_F32_C8) || !a.shift || a.scale || a.residual) return false;
+  if ((d->hidden % 32) || (pl.cout_tile != 64 && pl.cout_tile != 128)) return false;
+  static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA_REC"); return e ? atof(e) : 0.9; }();
+  const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
+  const double c_std = std_cost(std_tiles, pl.cout_tile, pl.cout_tile == 128 ? 1 : 2);
+  int th, tw;
+  conv_bf16_wide_tile(2, 2, &th, &tw);
+  const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
+  if (pl.rows_padded % 128) return false;
+  const int tiles = tx * ty * (pl.rows_padded / 128) * d->N;
+  *out = WidePick{2, 2, th, tx, ty, tiles};
+  return mode >= 2 || kappa * ceil_div(tiles, 256) * 128.0 * th * tw < c_std;
+}
+
 bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
+  if (d->epilogue == ESS_EPI_LSTM) return wide_pick_lstm(d, pl, g, a, c8, out);
   const int mode = wide_mode();
   if (!mode || !c8 || a.fmt_out != ESS_FMT_BF16_C8 || d->epilogue != ESS_EPI_LINEAR || a.out_bf) return false;
   const bool relu = d->act == ESS_ACT_RELU, res = a.residual != nullptr;
@@ -261,7 +285,8 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
       ConvKArgs t = a;
       t.tiles_x = wp.tiles_x; t.n_tiles = wp.tiles_x * wp.tiles_y;
       t.persist = wp.tiles > 256 ? 1 : 0;
-      conv_bf16_launch_wide(wp.mbw, wp.cw, dim3((unsigned)(wp.tiles > 256 ? 256 : wp.tiles)), st, t);
+      t.slab = pl.cout_tile;
+      conv_bf16_launch_wide(wp.mbw, wp.cw, d->epilogue, dim3((unsigned)(wp.tiles > 256 ? 256 : wp.tiles)), st, t);
       return ess_launch_status("conv2d_forward(bf16, wide tile)");
     }
     if (lds2 <= 160 * 1024) {

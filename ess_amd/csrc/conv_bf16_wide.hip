@@ -36,7 +36,9 @@ constexpr int WIDE_NB = 5;    // pixel blocks per matrix wave
 constexpr int WIDE_RP = 32;   // LDS row pitch in 16-byte vectors: 18 used; rows of a pixel block must start 0 mod 16 vectors apart (ds_read_b128 lane groups)
 constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
 
-template <int MBW, int CW>
+// EPI: ESS_EPI_LINEAR (BF16_C8 outputs) or ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h',
+// bias in the accumulators -- conv_epilogue_lstm_c8)
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16, NB = WIDE_NB, RP = WIDE_RP;
@@ -45,8 +47,6 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
   constexpr int IH = TH + 2, IW = WIDE_IW;
   constexpr int PLANE = IH * RP;             // one 8-channel block of the input tile (16-byte vectors)
   constexpr int COT = MBW * CW * 32;         // output channels per workgroup
-  constexpr int SLAB = MBW * CW >= 2 ? 64 : 32;  // channels of one packed weight slab (the plan's cout_tile)
-  constexpr int NSLAB = COT / SLAB;          // 1, or 2 for the 128-channel tile
   constexpr int WSZ = KS * KS * CB8 * COT;   // weight vectors per stage
   constexpr int WV = (WSZ + 255) / 256;
   constexpr int NPOS = IH * IW;
@@ -54,6 +54,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
   constexpr int BUFSZ = CB8 * PLANE + WSZ;   // one stage (16-byte vectors)
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   // tile schedule: as conv_bf16_ws.hip (persistent: workgroup b walks every (grid / 8)-th tile of its XCD's contiguous range)
+  const int SLAB = a.slab;                   // rows of one packed weight slab (the plan's cout_tile; <= COT, a power of two)
+  const int NSLAB = COT / SLAB;              // slabs a workgroup stages side by side (2 for a 128-row tile over 64-row slabs)
   const int n_ct = a.n_cout_tiles / NSLAB;   // workgroup-level channel tiles
   int t_start, t_count, t_first = 0, t_step = 1;
   if (a.persist) {
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const int i = tid + it * 256;
       const int ic = i < WSZ ? i : 0;
       const int c = ic % COT, tc = ic / COT;
-      w_src[it] = (unsigned)((c / SLAB) * a.n_chunks * (KS * KS * CB8 * SLAB) + tc * SLAB + (c % SLAB));
+      w_src[it] = (unsigned)((c / SLAB) * a.n_chunks * (KS * KS * CB8 * SLAB) + tc * SLAB + (c % SLAB));  // (SLAB is wave-uniform)
     }
     struct Set { u32x4 pre[CB8][KPC]; u32x4 wpre[WV]; };
     Set sa;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
   for (int nb = 0; nb < NB; ++nb) ly[nb] = (pw * NB + nb) * 2 + oy;
   const int ct_w = ct * CW + cw;             // this wave's channel tile in units of MBW * 32 channels
   f32x16 acc[MBW][NB];
-  const bool biased = a.scale == nullptr && a.shift != nullptr;
+  const bool biased = (EPI != ESS_EPI_LINEAR || a.scale == nullptr) && a.shift != nullptr;
   if (biased) {
     conv_bias_init<MBW>(a, acc, ct_w, half);
   } else {
@@ -284,19 +286,29 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #ifdef ESS_ABLATE
   if (a.deep & 8) continue;  // (ablation build only: no epilogue)
 #endif
-  conv_epilogue_c8_wide<MBW>(a, acc, ct_w, n, half, x0 + ox, y0, ly, biased);
+  if constexpr (EPI == ESS_EPI_LSTM) {
+    int pixi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int y = y0 + ly[nb], x = x0 + ox;
+      pixi[nb] = (y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1;
+    }
+    conv_epilogue_lstm_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+  } else {
+    conv_epilogue_c8_wide<MBW>(a, acc, ct_w, n, half, x0 + ox, y0, ly, biased);
+  }
   }  // tile loop
 #undef ESS_TILE_LOOP
 #undef ESS_TILE_DECODE
 }
 
-template <int MBW, int CW>
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
 void launch_wide_t(dim3 grid, hipStream_t st, const ConvKArgs& a) {
   constexpr int PW = 4 / CW, TH = PW * WIDE_NB * 2, PLANE = (TH + 2) * WIDE_RP, COT = MBW * CW * 32;
   constexpr size_t lds = 2 * (size_t)(2 * PLANE + 9 * 2 * COT) * 16;
   static_assert(lds <= 160 * 1024, "two stages must fit the 160 KiB LDS");
-  ess_allow_lds(conv_bf16_wide_kernel<MBW, CW>, lds);
-  hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW>), grid, dim3(512), lds, st, a);
+  ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI>, lds);
+  hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI>), grid, dim3(512), lds, st, a);
 }
 
 }  // namespace
@@ -309,7 +321,8 @@ void conv_bf16_wide_tile(int mbw, int cw, int* th, int* tw) {
   (void)mbw;
 }
 
-void conv_bf16_launch_wide(int mbw, int cw, dim3 grid, hipStream_t st, const ConvKArgs& a) {
+void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a) {
+  if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a); return; }  // (the dispatcher offers <2, 2> only)
   if (mbw == 2 && cw == 2) launch_wide_t<2, 2>(grid, st, a);
   else if (mbw == 2 && cw == 1) launch_wide_t<2, 1>(grid, st, a);
   else if (mbw == 1 && cw == 2) launch_wide_t<1, 2>(grid, st, a);

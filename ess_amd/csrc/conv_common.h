@@ -40,6 +40,7 @@ struct ConvKArgs {
   int fmt_res;     // format of `residual`
   int out_f16;     // BF16_C8-output epilogue: store IEEE half instead of bfloat16 (ESS_FMT_F16_C8: a pre-norm tensor, read by the norm kernels only)
   int persist;     // 3x3 wave-specialised kernel: the grid is one resident set of workgroups, each walking several tiles
+  int slab;        // wide-tile kernel: output rows of one packed weight slab (the plan's cout_tile: 32, 64 or 128)
   int split;       // split-operand bf16 (ESS_COMPUTE_BF16X3): every 16-channel chunk is contracted three times -- (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
   int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
 };
@@ -970,9 +971,9 @@ __device__ __forceinline__ void conv_epilogue_c8_wide(const ConvKArgs& a, f32x16
 // arithmetic per 64 x 256 tile, 15-26 % of a matrix wave's tile.  Here the four activations that do not need c_prev (80 % of
 // the transcendental work) run, in place in the accumulators, while the loads are in flight.  The BF16_C8 copy of h' leaves as
 // whole 16-byte pixel vectors (half-wave swap between the two hidden blocks of a pair, as in conv_epilogue_c8).
-template <int MB>
-__device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                      const int (&pixi)[NBW], unsigned HW) {
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
+                                                      const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int nbh = a.hid >> 3;
@@ -981,12 +982,12 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
   const ess_rsrc r_c = ess_make_rsrc(a.out2 + (size_t)n * nbh * 8 * HW, state_b);
   const ess_rsrc r_h = ess_make_rsrc(a.out ? a.out + (size_t)n * nbh * 8 * HW : a.out2, a.out ? state_b : 0);
   const ess_rsrc r_hb = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.out2, a.out_bf ? (size_t)nbh * HW * 16 : 0);
-  unsigned vo[MB][NBW];
-  u32x4c cp[MB][NBW];
+  unsigned vo[MB][NB];
+  u32x4c cp[MB][NB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       vo[mb][nb] = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb) * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
       cp[mb][nb] = __builtin_amdgcn_raw_buffer_load_b128(r_prev, (int)vo[mb][nb], 0, ESS_EPI_AUX);  // (no previous state: zeros)
     }
@@ -995,22 +996,22 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
   // (written as two phases -- the activations that do not need c_prev, then the rest; hipcc interleaves them per row to stay
   // inside 128 registers, and a scheduling barrier between the phases made it spill ~100: the first row's 12 activations are what
   // covers the load latency)
-  float igc[MB][NBW][4], gf[MB][NBW][4], go[MB][NBW][4];
+  float igc[MB][NB][4], gf[MB][NB][4], go[MB][NB][4];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         igc[mb][nb][jj] = ess_sigmoid(acc[mb][nb][jj]) * ess_tanh(acc[mb][nb][12 + jj]);
         gf[mb][nb][jj] = ess_sigmoid(acc[mb][nb][4 + jj]);
         go[mb][nb][jj] = ess_sigmoid(acc[mb][nb][8 + jj]);
       }
-  float hn[MB][NBW][4];
+  float hn[MB][NB][4];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       u32x4c cv;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -1025,7 +1026,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) {
+      for (int nb = 0; nb < NB; ++nb) {
         const u32x4c hv = {__builtin_bit_cast(unsigned, hn[mb][nb][0]), __builtin_bit_cast(unsigned, hn[mb][nb][1]),
                            __builtin_bit_cast(unsigned, hn[mb][nb][2]), __builtin_bit_cast(unsigned, hn[mb][nb][3])};
         __builtin_amdgcn_raw_buffer_store_b128(hv, r_h, (int)vo[mb][nb], 0, ESS_EPI_AUX);
@@ -1042,7 +1043,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
 #pragma unroll
       for (int mb = 0; mb < MB; mb += 2)
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
           const uint2 p0 = pack(mb, nb), p1 = pack(mb + 1, nb);
           const auto s0 = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
@@ -1052,7 +1053,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
         }
     } else {
 #pragma unroll
-      for (int nb = 0; nb < NBW; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
         if (pixi[nb] >= 0) ess_store_bf16x4(a.out_bf, (size_t)n * nbh, ct, HW, pixi[nb], half, hn[0][nb][0], hn[0][nb][1], hn[0][nb][2], hn[0][nb][3]);
     }
   }

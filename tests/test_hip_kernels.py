@@ -787,6 +787,55 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize('case', [(2, 64, 64, 40, 48, True), (1, 256, 256, 20, 32, True), (2, 64, 0, 40, 32, False), (1, 32, 32, 27, 44, True),
+                                  (8, 64, 64, 120, 160, True)])
+def test_conv_wide_tile_lstm_bit_identical(H, case):
+    """The lean ConvLSTM step (BF16_C8 x / h, F32_C8 cell state in and out, BF16_C8 copy of h' only -- or no previous state: the
+    first time step contracts x alone) on the wide-tile kernel against the ws kernel: same accumulation order, same epilogue code
+    (conv_epilogue_lstm_c8 on five pixel blocks per wave instead of two) -> bit-identical c' and h'.  hid = 256 takes the
+    128-row weight pack (the ws kernel's MB = 4 instance), the others the 64-row pack; the last case is a persistent launch."""
+    N, hid, C1, Hh, Ww, has_prev = case
+    g = torch.Generator().manual_seed(hid + Hh)
+    Cx = hid
+    x = H.to_bf16_c8(dev(torch.randn(N, Cx, Hh, Ww, generator=g)))
+    h = H.to_bf16_c8(dev(torch.randn(N, hid, Hh, Ww, generator=g))) if C1 else None
+    w = torch.randn(4 * hid, Cx + C1, 3, 3, generator=g) / (9 * (Cx + C1)) ** 0.5
+    b = torch.randn(4 * hid, generator=g)
+    c = dev(torch.randn(N, hid // 8, Hh, Ww, 8, generator=g)) if has_prev else None
+    spec = H.conv_spec(N, Hh, Ww, Cx, C1, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=H.COMPUTE_BF16)
+    pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
+    prev = H.tuning_get('conv_wide')
+    outs = []
+    try:
+        for mode in (0, 2):
+            H.tuning_set('conv_wide', mode)
+            co = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda')
+            co.fill_(float('nan'))
+            hb = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
+            hb.view(torch.int16).fill_(0x7fc0)
+            H.conv_forward(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_bf=hb, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8,
+                           aux_fmt=H.FMT_F32_C8)
+            torch.cuda.synchronize()
+            outs.append((co.clone(), hb.view(torch.int16).clone()))
+    finally:
+        H.tuning_set('conv_wide', prev)
+    (c0, h0), (c1, h1) = outs
+    assert torch.isfinite(c0).all() and not (h0 == 0x7fc0).any()
+    assert torch.equal(c0, c1) and torch.equal(h0, h1)
+    # ... and it is the ConvLSTM step (fp64 math on bf16-rounded operands)
+    xin = _un8(x, Cx).double()
+    if C1:
+        xin = torch.cat([xin, _un8(h, hid).double()], 1)
+    gates = F.conv2d(xin, w.bfloat16().double(), b.double(), padding=1)
+    gi, gf, go, gc = gates.chunk(4, 1)
+    cprev = c.cpu().permute(0, 1, 4, 2, 3).reshape(N, hid, Hh, Ww).double() if has_prev else 0.0
+    cn = torch.sigmoid(gf) * cprev + torch.sigmoid(gi) * torch.tanh(gc)
+    hn = torch.sigmoid(go) * torch.tanh(cn)
+    got_c = c1.cpu().permute(0, 1, 4, 2, 3).reshape(N, hid, Hh, Ww)
+    assert relerr(got_c, cn) < 1e-4
+    assert relerr(_un8(h1.view(torch.bfloat16), hid), hn) < 1.2e-2
+
+
 @pytest.mark.parametrize('case', WIDE_CASES)
 def test_conv_wide_tile_bit_identical(H, case):
     N, C0, C1, Co, Hh, Ww, m0, form = case
