@@ -190,9 +190,24 @@ struct WidePick { int mbw, cw, th, tiles_x, tiles_y, tiles; };
 // decides with a margin of its own (ESS_WIDE_KAPPA_REC, 0.9: the three levels at B = 8 pass, a quarter-filled single round does not).
 bool wide_pick_lstm(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
   const int mode = wide_mode();
-  if (!mode || !c8 || d->epilogue != ESS_EPI_LSTM) return false;
-  if (a.fmt_out != ESS_FMT_F32_C8 || (a.aux0 && a.fmt_res != ESS_FMT_F32_C8) || !a.shift || a.scale || a.residual) return false;
-  if ((d->hidden % 32) || (pl.cout_tile != 64 && pl.cout_tile != 128)) return false;
+  if (!mode || !c8 || !a.shift || a.scale || a.residual) return false;
+  // the conditions under which the ws kernel takes the straight-line recurrent epilogues (conv_epilogue in conv_common.h), for a
+  // wave that owns two 32-row blocks of a 128-row tile
+  if (d->epilogue == ESS_EPI_LSTM) {
+    if (a.fmt_out != ESS_FMT_F32_C8 || (a.aux0 && a.fmt_res != ESS_FMT_F32_C8)) return false;
+  } else if (d->epilogue == ESS_EPI_GRU_UR) {
+    if (!a.out || a.out2 || a.fmt_out != ESS_FMT_F32_C8 || (a.aux0 && a.fmt_res != ESS_FMT_F32_C8)) return false;
+  } else if (d->epilogue == ESS_EPI_GRU_OUT) {
+    if (a.fmt_res != ESS_FMT_F32_C8 || !a.aux1 || (a.out && a.fmt_out != ESS_FMT_F32_C8)) return false;
+  } else {
+    return false;
+  }
+  if (pl.cout_tile != 64 && pl.cout_tile != 128) return false;
+  // ConvGRU: measured (B = 8, lean launches) the wide tile wins only where the ws kernel itself runs one workgroup per CU (its
+  // 128-row instance, the deepest level: (update, reset) 197 -> 171 us, candidate 139 -> 96 us); on the large planes the pair moves
+  // 14 + 12 bytes per hidden element and an exposed epilogue costs more than the rounds gain (level 0 / 1: 0.87 - 0.99 x)
+  if (d->epilogue != ESS_EPI_LSTM && pl.cout_tile != 128 && mode < 2) return false;
+  if (packed_rows(d) % 128) return false;  // every row of a workgroup's tile is a real gate row (hid % 32 / 64 / 128 by epilogue)
   static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA_REC"); return e ? atof(e) : 0.9; }();
   const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
   const double c_std = std_cost(std_tiles, pl.cout_tile, pl.cout_tile == 128 ? 1 : 2);
@@ -206,7 +221,7 @@ bool wide_pick_lstm(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, 
 }
 
 bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
-  if (d->epilogue == ESS_EPI_LSTM) return wide_pick_lstm(d, pl, g, a, c8, out);
+  if (d->epilogue != ESS_EPI_LINEAR) return wide_pick_lstm(d, pl, g, a, c8, out);
   const int mode = wide_mode();
   if (!mode || !c8 || a.fmt_out != ESS_FMT_BF16_C8 || d->epilogue != ESS_EPI_LINEAR || a.out_bf) return false;
   const bool relu = d->act == ESS_ACT_RELU, res = a.residual != nullptr;

@@ -36,8 +36,8 @@ constexpr int WIDE_NB = 5;    // pixel blocks per matrix wave
 constexpr int WIDE_RP = 32;   // LDS row pitch in 16-byte vectors: 18 used; rows of a pixel block must start 0 mod 16 vectors apart (ds_read_b128 lane groups)
 constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
 
-// EPI: ESS_EPI_LINEAR (BF16_C8 outputs) or ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h',
-// bias in the accumulators -- conv_epilogue_lstm_c8)
+// EPI: ESS_EPI_LINEAR (BF16_C8 outputs), ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h', bias in
+// the accumulators -- conv_epilogue_lstm_c8) or ESS_EPI_GRU_UR / ESS_EPI_GRU_OUT (the lean ConvGRU kernel pair: conv_epilogue_gru_*_c8)
 template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -294,6 +294,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       pixi[nb] = (y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1;
     }
     conv_epilogue_lstm_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+  } else if constexpr (EPI == ESS_EPI_GRU_UR || EPI == ESS_EPI_GRU_OUT) {
+    int pixi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int y = y0 + ly[nb], x = x0 + ox;
+      pixi[nb] = (y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1;
+    }
+    if constexpr (EPI == ESS_EPI_GRU_UR) conv_epilogue_gru_ur_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+    else conv_epilogue_gru_out_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
   } else {
     conv_epilogue_c8_wide<MBW>(a, acc, ct_w, n, half, x0 + ox, y0, ly, biased);
   }
@@ -322,7 +331,9 @@ void conv_bf16_wide_tile(int mbw, int cw, int* th, int* tw) {
 }
 
 void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a) {
-  if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a); return; }  // (the dispatcher offers <2, 2> only)
+  if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a); return; }  // (recurrent epilogues: the dispatcher offers <2, 2> only)
+  if (epi == ESS_EPI_GRU_UR) { launch_wide_t<2, 2, ESS_EPI_GRU_UR>(grid, st, a); return; }
+  if (epi == ESS_EPI_GRU_OUT) { launch_wide_t<2, 2, ESS_EPI_GRU_OUT>(grid, st, a); return; }
   if (mbw == 2 && cw == 2) launch_wide_t<2, 2>(grid, st, a);
   else if (mbw == 2 && cw == 1) launch_wide_t<2, 1>(grid, st, a);
   else if (mbw == 1 && cw == 2) launch_wide_t<1, 2>(grid, st, a);

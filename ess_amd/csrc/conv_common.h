@@ -408,9 +408,9 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
 // ---- the two ConvGRU epilogues of the lean time steps as straight-line code (what conv_epilogue_lstm_c8 is to the LSTM one):
 // F32_C8 states in and out, bias in the accumulators, every hidden channel of the tile real; state loads issued first, 16-byte
 // stores, the BF16_C8 tensors (r*h, the copy of h') as whole pixel vectors via a half-wave swap between two hidden blocks.
-template <int MB>
-__device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                        const int (&pixi)[NBW], unsigned HW) {
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
+                                                        const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int nbh = a.hid >> 3;
@@ -422,9 +422,9 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-      unsigned vo[NBW][2];  // (indexed [nb] for the code below; one pixel block's vectors in flight at a time: 128 registers)
-      u32x4c hp[NBW][2];
+    for (int nb = 0; nb < NB; ++nb) {
+      unsigned vo[NB][2];  // (indexed [nb] for the code below; one pixel block's vectors in flight at a time: 128 registers)
+      u32x4c hp[NB][2];
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         const int hb = (ct * MB + mb) * 2 + q2;
@@ -456,9 +456,9 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
   }
 }
 
-template <int MB>
-__device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
-                                                         const int (&pixi)[NBW], unsigned HW) {
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
+                                                         const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int nbh = a.hid >> 3;
@@ -470,7 +470,7 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
       unsigned vo[4];
       u32x4c hv[4], uv[4];
 #pragma unroll

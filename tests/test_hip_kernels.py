@@ -836,6 +836,53 @@ def test_conv_wide_tile_lstm_bit_identical(H, case):
     assert relerr(_un8(h1.view(torch.bfloat16), hid), hn) < 1.2e-2
 
 
+@pytest.mark.parametrize('case', [(2, 128, 40, 48), (1, 256, 20, 32), (2, 64, 27, 44), (8, 128, 120, 160)])
+def test_conv_wide_tile_gru_bit_identical(H, case):
+    """The lean ConvGRU kernel pair -- (update, reset): u as F32_C8, r*h as BF16_C8; candidate: h' as F32_C8 + BF16_C8 copy -- on the
+    wide-tile kernel against the ws kernel: bit-identical (conv_epilogue_gru_ur_c8 / conv_epilogue_gru_out_c8 on five pixel blocks per
+    wave).  hid = 64: the candidate kernel's 64 rows do not fill a 128-row tile and stay on the ws kernel (trivially identical)."""
+    N, hid, Hh, Ww = case
+    g = torch.Generator().manual_seed(hid * 3 + Hh)
+    x8 = H.to_bf16_c8(dev(torch.randn(N, hid, Hh, Ww, generator=g)))
+    hprev = torch.randn(N, hid, Hh, Ww, generator=g)
+    h8 = H.to_bf16_c8(dev(hprev))
+    hb = dev(hprev.view(N, hid // 8, 8, Hh, Ww).permute(0, 1, 3, 4, 2).contiguous())
+    wu, wr, wo = [torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5 for _ in range(3)]
+    bu, br, bo = [torch.randn(hid, generator=g) for _ in range(3)]
+    s1 = H.conv_spec(N, Hh, Ww, hid, hid, 2 * hid, 3, 1, 1, epi=H.EPI_GRU_UR, hidden=hid, compute=H.COMPUTE_BF16)
+    s2 = H.conv_spec(N, Hh, Ww, hid, hid, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, hidden=hid, compute=H.COMPUTE_BF16)
+    pw1, pw2 = H.pack_weights(s1, dev(wu), dev(wr)), H.pack_weights(s2, dev(wo))
+    pb1, pb2 = H.pack_rows(s1, dev(bu), dev(br)), H.pack_rows(s2, dev(bo))
+    prev = H.tuning_get('conv_wide')
+    outs = []
+    try:
+        for mode in (0, 2):
+            H.tuning_set('conv_wide', mode)
+            u, hn = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda'), H.f32_c8_empty(N, hid, Hh, Ww, 'cuda')
+            u.fill_(float('nan')), hn.fill_(float('nan'))
+            rh8, hn8 = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda'), H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
+            rh8.view(torch.int16).fill_(0x7fc0), hn8.view(torch.int16).fill_(0x7fc0)
+            H.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8, aux_fmt=H.FMT_F32_C8)
+            H.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8,
+                           aux_fmt=H.FMT_F32_C8)
+            torch.cuda.synchronize()
+            outs.append((u.clone(), rh8.view(torch.int16).clone(), hn.clone(), hn8.view(torch.int16).clone()))
+    finally:
+        H.tuning_set('conv_wide', prev)
+    a, b = outs
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[2]).all() and not (a[1] == 0x7fc0).any() and not (a[3] == 0x7fc0).any()
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # ... and it is the ConvGRU step (fp64 on bf16-rounded operands; r*h rounded to bf16 between the two kernels)
+    xs = torch.cat([_un8(x8, hid), _un8(h8, hid)], 1).double()
+    uu = torch.sigmoid(F.conv2d(xs, wu.bfloat16().double(), bu.double(), padding=1))
+    rr = torch.sigmoid(F.conv2d(xs, wr.bfloat16().double(), br.double(), padding=1))
+    rh = (rr * hprev.double()).float().bfloat16().double()
+    oo = torch.tanh(F.conv2d(torch.cat([_un8(x8, hid).double(), rh], 1), wo.bfloat16().double(), bo.double(), padding=1))
+    ref = hprev.double() * (1 - uu) + oo * uu
+    got = b[2].cpu().permute(0, 1, 4, 2, 3).reshape(N, hid, Hh, Ww)
+    assert relerr(got, ref) < 2e-3
+
+
 @pytest.mark.parametrize('case', WIDE_CASES)
 def test_conv_wide_tile_bit_identical(H, case):
     N, C0, C1, Co, Hh, Ww, m0, form = case
