@@ -10,11 +10,11 @@ python bench.py --trainer ess_supervised --batch 2 --height 200 --width 352 --cl
 python bench.py --trainer ess_supervised --batch 2 --height 200 --width 352 --classes 6 --compute bf16x3 --no-cpu-baseline --no-roofline > gpurun_out/r4_bench_bf16x3_config2_ddd17.json 2>/dev/null
 python tools/bench_stream.py > gpurun_out/r4_bench_stream_b1.json 2>/dev/null
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r4e -o r4e -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-fp32-extra --no-roofline > /dev/null 2>&1)
-python tools/prof_summary.py $(find gpurun_out/prof_r4e -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16_eager_kernel_stats.txt
+python tools/prof_summary.py $(find gpurun_out/prof_r4e -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16_eager_kernel_stats.txt; rm -rf gpurun_out/prof_r4e
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r4g -o r4g -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-extra > /dev/null 2>&1)
-python tools/prof_summary.py $(find gpurun_out/prof_r4g -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16_graph_kernel_stats.txt
+python tools/prof_summary.py $(find gpurun_out/prof_r4g -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16_graph_kernel_stats.txt; rm -rf gpurun_out/prof_r4g
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r4x -o r4x -- python $GRAFT_REPO_ROOT/bench.py --compute bf16x3 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-fp32-extra --no-roofline > /dev/null 2>&1)
-python tools/prof_summary.py $(find gpurun_out/prof_r4x -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16x3_eager_kernel_stats.txt
+python tools/prof_summary.py $(find gpurun_out/prof_r4x -name "*results.db" | head -1) > gpurun_out/r4_uda_bf16x3_eager_kernel_stats.txt; rm -rf gpurun_out/prof_r4x
 for f in gpurun_out/r4_bench_*.json; do python -c "
 import json,sys
 try:

@@ -124,5 +124,8 @@ with open(os.path.join(ROOT, 'gpurun_out', 'r4_traffic.json'), 'w') as f:
 with open(os.path.join(ROOT, 'gpurun_out', 'r4_conv_pmc.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc passes of tools/pmc_r4.py over tools/traffic_probe.py (B = 8, 480x640, bf16 configuration), per call of each plan entry\n')
     f.write('\n'.join(lines) + '\n')
+import shutil
+for pname in PASSES:  # (the rocpd databases are 5 MB each: keep gpurun_out/ small enough to travel back)
+    shutil.rmtree(os.path.join(out, pname), ignore_errors=True)
 print('\n'.join(lines))
 print(json.dumps({k: {a: b for a, b in v.items() if a != 'layers'} for k, v in res.items() if k != '_comment'}, indent=1))

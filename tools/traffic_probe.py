@@ -72,7 +72,7 @@ for lvl, hid in enumerate((64, 128, 256)):
                          aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     n = B * hid * H * W
-    plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS, 'warm': WARM,
+    plan.append({'group': 'gate', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}', 'count': 1, 'reps': REPS, 'warm': WARM,
                  'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 4 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)})
 # ---- ConvGRU pair (lean launches of ConvGRU.forward): (update, reset) kernel, then candidate kernel
@@ -94,14 +94,14 @@ for lvl, hid in enumerate((64, 128, 256)):
         hip.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_F32_C8,
                          aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
-    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} update+reset', 'count': 1,
+    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} update+reset', 'count': 1,
                  'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (2 * hid)})
     for _ in range(WARM + REPS):
         hip.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=hip.FMT_BF16_C8,
                          out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
-    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} candidate', 'count': 1,
+    plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} candidate', 'count': 1,
                  'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + (4 + 4) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * hid})
 print('PLAN ' + json.dumps(plan))
