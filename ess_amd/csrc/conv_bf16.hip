@@ -188,7 +188,7 @@ struct WidePick { int mbw, cw, th, tiles_x, tiles_y, tiles; };
 // ws kernel's 128-row instance) 347 -> 311: + 8 / 5 / 11 % -- the long K loops (8 - 32 chunks) amortise the exposed epilogue, and on real
 // data the wide tile's lower traffic per MFMA is worth more than its coarser rounds (power probe).  The round model
 // decides with a margin of its own (ESS_WIDE_KAPPA_REC, 0.9: the three levels at B = 8 pass, a quarter-filled single round does not).
-bool wide_pick_lstm(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
+bool wide_pick_recurrent(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
   const int mode = wide_mode();
   if (!mode || !c8 || !a.shift || a.scale || a.residual) return false;
   // the conditions under which the ws kernel takes the straight-line recurrent epilogues (conv_epilogue in conv_common.h), for a
@@ -221,7 +221,7 @@ bool wide_pick_lstm(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, 
 }
 
 bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
-  if (d->epilogue != ESS_EPI_LINEAR) return wide_pick_lstm(d, pl, g, a, c8, out);
+  if (d->epilogue != ESS_EPI_LINEAR) return wide_pick_recurrent(d, pl, g, a, c8, out);
   const int mode = wide_mode();
   if (!mode || !c8 || a.fmt_out != ESS_FMT_BF16_C8 || d->epilogue != ESS_EPI_LINEAR || a.out_bf) return false;
   const bool relu = d->act == ESS_ACT_RELU, res = a.residual != nullptr;
