@@ -26,6 +26,10 @@
 // Structure otherwise as conv_bf16_ws.hip: 512 threads, waves 0-3 matrix (LDS fragment reads + MFMA, issue priority), waves 4-7
 // staging (16-byte loads of BF16_C8 pixel vectors / packed weights -> ds_write_b128), two LDS stages, one barrier per 16-channel
 // chunk, persistent tile loop (the staging waves run ahead into the next tile during the epilogue).
+// (Measured and dropped: BF16_C8 outputs with the `nt` cache policy, -DESS_C8_AUX=2 for this file.  Back-to-back launches of one layer
+// gain 3-4 % -- 42.3 -> 40.8, 25.2 -> 24.3, 25.9 -> 24.8, 113.4 -> 111.3 us: the output burst of a single-round launch streams past the
+// L2 --, but inside the train step the next kernel reads that output and the same-box A/B goes the other way: conv time in the step
+// 6.36-6.42 -> 6.45-6.49 ms, step 23.16-23.18 -> 23.19-23.20 ms.  Default policy.)
 #include "conv_bf16_common.h"
 
 namespace {

@@ -11,7 +11,7 @@
 #define ESS_GRU_AUX 2  // same for the F32_C8 ConvGRU states h, u, r*h (T = 20 ConvGRU step 43.18 -> 42.78 ms)
 #endif
 #ifndef ESS_C8_AUX
-#define ESS_C8_AUX 0  // same for the BF16_C8 outputs of the plain epilogue (experiment)
+#define ESS_C8_AUX 0  // same for the BF16_C8 outputs of the straight-line LINEAR epilogues: 0 in the ws / tap-paired kernels (measured +-0 there), 2 (nt) in the wide-tile kernel's translation unit
 #endif
 namespace essconv {
 
@@ -867,8 +867,8 @@ __device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x1
           const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
           const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
           const int o = (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB);
-          if (first) __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, o, 0, 0);
-          else __builtin_amdgcn_raw_buffer_store_b128(vec, r_o2, o, 0, 0);
+          if (first) __builtin_amdgcn_raw_buffer_store_b128(vec, r_o1, o, 0, ESS_C8_AUX);
+          else __builtin_amdgcn_raw_buffer_store_b128(vec, r_o2, o, 0, ESS_C8_AUX);
         }
       }
     }
