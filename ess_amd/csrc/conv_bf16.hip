@@ -170,15 +170,56 @@ int wide_mode() {
   return m;
 }
 void set_wide_mode(int m) { g_wide_mode.store(m < 0 ? 0 : m, std::memory_order_relaxed); }
+// "conv_wide_tail" (ESS_CONV_WIDE_TAIL, default 1): the wide-tile kernel's last chunk runs accumulator-major with per-block epilogues
+// (conv_bf16_wide.hip, TAIL) -- same arithmetic in the same order, bit-identical results; 0 = the burst epilogue behind the K loop;
+// 3 = TAIL + the weight slabs staged by LDS-DMA (WDMA)
+static std::atomic<int> g_wide_tail{-1};
+int wide_tail() {
+  int m = g_wide_tail.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("ESS_CONV_WIDE_TAIL");
+    m = e ? atoi(e) : 1;
+    g_wide_tail.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+void set_wide_tail(int m) { g_wide_tail.store(m == 3 ? 3 : (m != 0 ? 1 : 0), std::memory_order_relaxed); }
+
+// ---- dispatcher constants, in ONE place, each with the shape it was measured at.  Read once (environment overrides at first use,
+// then immutable); the compute-unit count comes from the device the calling thread is on (256 on MI355X), never from a literal.
+//   constant      value  measured on (B = 8, bf16, MI355X)                                         meaning
+//   tail_half     0.56   ws kernel, 256 -> 256 @ 60 x 80: a lone 64 x 256 tile 18.8 us vs a          cost of a ws-kernel tail round that fills at
+//                        co-resident pair 33.8 us (round-3 wall-clock stamps)           most half of the resident slots
+//   narrow_tile   1.35   ws kernel, 64^ -> 32 @ 480 x 640: 6.8 us per round of 32-channel tiles      32-channel ws tiles: a weight slab per 256
+//                        vs 5.0 us for half a 64-channel round                                        pixels, one weight fragment per two MFMAs
+//   kappa         1.12   wide vs ws at model parity on the multi-round decoder layers (120 x 160,     margin the wide kernel must win by (LINEAR):
+//                        240 x 320): the wide kernel measures 4 - 18 % slower (tools/wide_probe.py)     one workgroup per CU exposes its epilogue
+//   kappa_rec     0.9    lean ConvLSTM launches, levels 0 / 1 / 2 @ 480 x 640: + 8 / 5 / 11 % for     same for the recurrent epilogues (8 - 32
+//                        the wide kernel                                                 chunks amortise the epilogue)
+// The DDD17 shape (B = 2, 200 x 352: every launch is sub-round) is covered by an A/B of the switch in bench records
+// (profiles/r5_bench_bf16_config2_ddd17*.json), not by constants of its own.
+struct DispatchTuning { int cus; double tail_half, narrow_tile, kappa, kappa_rec; };
+static const DispatchTuning& tuning() {
+  static const DispatchTuning t = [] {
+    DispatchTuning v{256, 0.56, 1.35, 1.12, 0.9};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      v.cus = cus;
+    if (const char* e = getenv("ESS_WIDE_KAPPA")) v.kappa = atof(e);
+    if (const char* e = getenv("ESS_WIDE_KAPPA_REC")) v.kappa_rec = atof(e);
+    return v;
+  }();
+  return t;
+}
+int device_cus() { return tuning().cus; }
 
 namespace {
-// Relative launch time in units of (output channel x pixel) per CU, from the round-3 wall-clock stamps: two
-// co-resident 64 x 256 tiles of the ws kernel take 33.8 us, a lone one 18.8 (0.56 of a round); the wide kernel runs one tile per CU
-// and round.  kappa scales the wide kernel's per-unit time against the ws kernel's (measured, ESS_WIDE_KAPPA).
+// Relative launch time in units of (output channel x pixel) per CU: rounds of resident workgroups x tile work per CU; the ws
+// kernel's tail round at tail_half when it is at most half full.  kappa scales the wide kernel's per-unit time against the ws kernel's.
 double std_cost(int tiles, int cot, int per_cu) {
-  const int slots = 256 * per_cu;
+  const int slots = tuning().cus * per_cu;
   const int full = tiles / slots, rem = tiles % slots;
-  const double tail = rem == 0 ? 0.0 : (rem * 2 <= slots ? 0.56 : 1.0);
+  const double tail = rem == 0 ? 0.0 : (rem * 2 <= slots ? tuning().tail_half : 1.0);
   return (full + tail) * per_cu * cot * 256.0;
 }
 struct WidePick { int mbw, cw, th, tiles_x, tiles_y, tiles; };
@@ -208,7 +249,7 @@ bool wide_pick_recurrent(const EssConvDesc* d, const EssConvPlan& pl, const Geom
   // 14 + 12 bytes per hidden element and an exposed epilogue costs more than the rounds gain (level 0 / 1: 0.87 - 0.99 x)
   if (d->epilogue != ESS_EPI_LSTM && pl.cout_tile != 128 && mode < 2) return false;
   if (packed_rows(d) % 128) return false;  // every row of a workgroup's tile is a real gate row (hid % 32 / 64 / 128 by epilogue)
-  static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA_REC"); return e ? atof(e) : 0.9; }();
+  const double kappa = tuning().kappa_rec;
   const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
   const double c_std = std_cost(std_tiles, pl.cout_tile, pl.cout_tile == 128 ? 1 : 2);
   int th, tw;
@@ -217,7 +258,7 @@ bool wide_pick_recurrent(const EssConvDesc* d, const EssConvPlan& pl, const Geom
   if (pl.rows_padded % 128) return false;
   const int tiles = tx * ty * (pl.rows_padded / 128) * d->N;
   *out = WidePick{2, 2, th, tx, ty, tiles};
-  return mode >= 2 || kappa * ceil_div(tiles, 256) * 128.0 * th * tw < c_std;
+  return mode >= 2 || kappa * ceil_div(tiles, tuning().cus) * 128.0 * th * tw < c_std;
 }
 
 bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, bool c8, WidePick* out) {
@@ -231,12 +272,12 @@ bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const
   // kappa: margin the wide kernel must win by.  Measured (tools/wide_probe.py, B = 8): per unit of work and round it runs exactly
   // as fast as the ws kernel (256 -> 256 @ 60 x 80: model 52.7 -> 42.2 us, measured 50.7 -> 42.4), but with one workgroup per CU
   // its epilogue is exposed in multi-round launches: at model parity (two rounds against 2.34) it measures 4-18 % slower.
-  static const double kappa = [] { const char* e = getenv("ESS_WIDE_KAPPA"); return e ? atof(e) : 1.12; }();
+  const double kappa = tuning().kappa;
   const int mb = pl.cout_tile / 32;
   const int std_tiles = g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N;
   // (32-channel tiles of the ws kernel stage a weight slab per 256 pixels and read one weight fragment per two MFMAs: measured
   // 6.8 us per round of 64^ -> 32 @ 480 x 640 against 5.0 for half a 64-channel round -- 1.35)
-  const double c_std = std_cost(std_tiles, pl.cout_tile, 2) * (mb == 1 ? 1.35 : 1.0);
+  const double c_std = std_cost(std_tiles, pl.cout_tile, 2) * (mb == 1 ? tuning().narrow_tile : 1.0);
   const int cands[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   double best = 1e300;
   for (const auto& c : cands) {
@@ -248,7 +289,7 @@ bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const
     conv_bf16_wide_tile(mbw, cw, &th, &tw);
     const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
     const int tiles = tx * ty * (d->C_out / cot) * d->N;
-    const double cost = kappa * ceil_div(tiles, 256) * (double)cot * th * tw;
+    const double cost = kappa * ceil_div(tiles, tuning().cus) * (double)cot * th * tw;
     if (cost < best) { best = cost; *out = WidePick{mbw, cw, th, tx, ty, tiles}; }
   }
   if (best >= 1e300) return false;
@@ -282,7 +323,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     {  // persistent launch (see the 3x3 kernel below): one resident set of workgroups when the grid exceeds it
       static const int persist = [] { const char* e = getenv("ESS_WS_PERSIST"); return e ? atoi(e) : 1; }();
       const int by_regs = (d->stride == 2 && mb == 2) ? 1 : 2, by_lds = (int)((160 * 1024) / lds2);
-      const int slots = 256 * (by_regs < by_lds ? by_regs : by_lds);
+      const int slots = tuning().cus * (by_regs < by_lds ? by_regs : by_lds);
       if (persist && (int)grid.x > slots) {
         ConvKArgs t = a;
         t.persist = 1;
@@ -299,9 +340,10 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     if (wide_pick(d, pl, g, a, c8, &wp)) {
       ConvKArgs t = a;
       t.tiles_x = wp.tiles_x; t.n_tiles = wp.tiles_x * wp.tiles_y;
-      t.persist = wp.tiles > 256 ? 1 : 0;
+      const int cus = tuning().cus;  // one workgroup per CU
+      t.persist = wp.tiles > cus ? 1 : 0;
       t.slab = pl.cout_tile;
-      conv_bf16_launch_wide(wp.mbw, wp.cw, d->epilogue, dim3((unsigned)(wp.tiles > 256 ? 256 : wp.tiles)), st, t);
+      conv_bf16_launch_wide(wp.mbw, wp.cw, d->epilogue, dim3((unsigned)(wp.tiles > cus ? cus : wp.tiles)), st, t, wide_tail());
       return ess_launch_status("conv2d_forward(bf16, wide tile)");
     }
     if (lds2 <= 160 * 1024) {
@@ -309,7 +351,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
       // instance -- and by LDS): see the tile schedule in conv_bf16_ws.hip.  ESS_WS_PERSIST=0: one workgroup per tile (tuning).
       static const int persist = [] { const char* e = getenv("ESS_WS_PERSIST"); return e ? atoi(e) : 1; }();
       const int per_cu_lds = (int)((160 * 1024) / lds2), per_cu = (mb == 4 ? 1 : 2) < per_cu_lds ? (mb == 4 ? 1 : 2) : per_cu_lds;
-      const int slots = 256 * per_cu;
+      const int slots = tuning().cus * per_cu;
       if (persist && (int)grid.x > slots) {
         ConvKArgs t = a;
         t.persist = 1;
@@ -321,6 +363,9 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     }
   }
   const int key = d->ksize * 10 + d->stride;
+  // (the generic tile kernel ignores a.split but would read a [tile][chunk][hi | lo] weight pack: refuse instead of computing garbage)
+  ESS_CHECK_ARG(!a.split, "conv(bf16): split operands reached the generic tile kernel (k%d s%d, %zu B of LDS for two stages)", d->ksize,
+                d->stride, 2 * (size_t)pl.lds_bytes);
   if (c8)
     ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && (key == 11 || key == 12 || key == 31 || key == 32),
                   "conv(bf16): the generic tile kernel stages BF16_C8 sources for 1x1 and 3x3 LINEAR convolutions only");

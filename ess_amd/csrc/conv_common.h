@@ -11,7 +11,7 @@
 #define ESS_GRU_AUX 2  // same for the F32_C8 ConvGRU states h, u, r*h (T = 20 ConvGRU step 43.18 -> 42.78 ms)
 #endif
 #ifndef ESS_C8_AUX
-#define ESS_C8_AUX 0  // same for the BF16_C8 outputs of the straight-line LINEAR epilogues: 0 in the ws / tap-paired kernels (measured +-0 there), 2 (nt) in the wide-tile kernel's translation unit
+#define ESS_C8_AUX 0  // same for the BF16_C8 outputs of the straight-line LINEAR epilogues (forward AND data-gradient forms): 0 everywhere -- nt measured +-0 in the ws / tap-paired kernels and a net loss inside the train step for the wide-tile kernel (conv_bf16_wide.hip header); a -DESS_C8_AUX=2 build changes every one of those stores
 #endif
 namespace essconv {
 
@@ -63,7 +63,12 @@ __device__ __forceinline__ ess_rsrc ess_make_rsrc(const void* p, size_t bytes) {
 }
 // fp32 -> IEEE half for the F16_C8 pre-norm tensors, SATURATING: a plain cast turns |v| > 65504 into +-inf, the norm's statistics
 // into NaN and with them the whole channel (BF16_C8 and the reference's fp32 have ~3e38 of range); one v_med3_f32 per element
-__device__ __forceinline__ _Float16 ess_f16_sat(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+// (v_med3_f32 acts as min3 on a NaN operand: a NaN accumulator would be stored as -65504 and a diverged run would yield finite
+// statistics; NaN is kept, so loss-is-NaN detection still fires: test_pre_norm_f16_saturates)
+__device__ __forceinline__ _Float16 ess_f16_sat(float v) {
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  return (_Float16)(v != v ? v : c);
+}
 __device__ __forceinline__ float ess_bload(ess_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
@@ -931,7 +936,7 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
 }
 
 // Epilogue of the wide-tile kernel (conv_bf16_wide.hip; NB = 5 pixel blocks per wave): the straight-line forms only.  The
-// dispatcher routes a launch to that kernel only when one of them applies (conv_bf16.hip, wide_epilogue_ok): one output with
+// dispatcher routes a launch to that kernel only when one of them applies (conv_bf16.hip, wide_pick / wide_pick_recurrent): one output with
 // every channel of the tile real (scale / shift / residual / ReLU / F16 options), or the two outputs of a concat's data-gradient.
 template <int MB, bool SC, bool SH, int NB>
 __device__ __forceinline__ void conv_epilogue_c8_wide_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half, int x,
@@ -1216,13 +1221,18 @@ inline bool ws_enabled();
 // ESS_COMPUTE_BF16X3 resolves, per convolution, to the arithmetic that runs: the bf16 3x3 / stride-1 wave-specialised kernel with
 // split operands (`split`), or the exact-fp32 kernels for every other geometry.  The entry points work on the resolved copy.
 struct ResolvedDesc { EssConvDesc d; bool split; };
+// ESS_CONV_PAIR=0 switches the tap-paired 5x5 kernel off (tuning); ONE reading of the variable for resolve_compute and is_paired
+inline bool pair_enabled() {
+  static const bool on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
+  return on;
+}
 inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
   ResolvedDesc r{*d, false};
   if (d->compute == ESS_COMPUTE_BF16X3) {
     // 3x3 / stride 1 (any epilogue): the wave-specialised kernel; 5x5 LINEAR with at least one 8-channel chunk of input (the
     // frozen E2VID's stride-2 encoder convolutions and upsample-conv decoders): the tap-paired kernel.  The 2-channel 5x5 head
     // stays exact fp32 -- three passes over a chunk that is 6/8 padding would cost twice the fp32 kernel
-    static const bool pair_on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
+    const bool pair_on = pair_enabled();
     const bool ws = d->ksize == 3 && d->stride == 1 && ws_enabled();
     const bool pair = d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR && d->C0 + d->C1 >= 8 && pair_on;
     r.d.compute = (ws || pair) ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
@@ -1233,8 +1243,7 @@ inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
 
 // bf16 5x5 convolutions run on the tap-paired wave-specialised kernel (conv_bf16.hip): 8-channel chunks, two taps per MFMA
 inline bool is_paired(const EssConvDesc* d) {
-  static const bool on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
-  return on && is_bf16(d) && d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR;
+  return pair_enabled() && is_bf16(d) && d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR;
 }
 
 inline int pick_ck(const EssConvDesc* d) {

@@ -9,7 +9,11 @@ RandomBrightnessContrast(p=0.5, limits 0.2), uint8 quantisation, ToTensor, label
 brightness / contrast step, and OneOf([Sharpen, Blur(3), MotionBlur(3)], p=0.5) at the end, in the reference's order
 (datasets/cityscapes_loader.py:39-58; parameter draws restated from albumentations 1.1.0, the version the reference pins).
 albumentations / cv2 are absent here: the interpolation arithmetic is restated (oracle.augment_image_label,
-oracle.augment_perspective_filter), parity against the libraries themselves is unpinned."""
+oracle.augment_perspective_filter), parity against the libraries themselves is unpinned.  Known deviations inside that caveat:
+(i) `perspective_matrix` floors a degenerate quadrilateral's target size to max(2, int(.)) where albumentations 1.1.0 widens the
+quadrilateral in a loop until min_width / min_height >= 2 and recomputes the corner points -- draws that hit the floor differ;
+(ii) the brightness / contrast step quantises with round-half-up where albumentations' uint8 LUT truncates (`astype(uint8)`): values
+may differ by one grey level."""
 import math
 
 import torch

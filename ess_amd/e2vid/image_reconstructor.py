@@ -49,10 +49,15 @@ class ImageReconstructor:
                 events = events.contiguous()
             return self._step(events, need_image, lean_state)
 
-    def _step(self, events, need_image, lean_state, prefix=None):
-        """One model step on a normalised, padded, contiguous slice (under no_grad)."""
+    def _step(self, events, need_image, lean_state, prefix=None, final_lean=False):
+        """One model step on a normalised, padded, contiguous slice (under no_grad).  final_lean: a step whose image / latents ARE
+        consumed, but whose recurrent state needs no fp32 form (the last step of a training sequence: UNetRecurrent.forward,
+        lean_state)."""
+        fl = final_lean and not self.no_recurrent and _LEAN
         if need_image:
-            out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'])
+            out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], lean_state=fl)
+        elif final_lean:
+            out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], encoder_only=True, lean_state=fl)
         elif prefix is not None:
             out, states, latent = self.model(None, self.last_states_for_each_channel['grayscale'], encoder_only=True, lean=True,
                                              prefix=prefix)
@@ -70,13 +75,16 @@ class ImageReconstructor:
             out = flat.view(b, 1, h, w)
         return out, states, latent
 
-    def update_reconstruction_sequence(self, event_tensor, T, need_image=True, time_batched_prefix=None):
+    def update_reconstruction_sequence(self, event_tensor, T, need_image=True, time_batched_prefix=None, final_lean=False):
         """The trainers' hot loop as one call (reference training/ess_trainer.py:277-280, ess_supervised_trainer.py:128-130):
             for i in range(T): out, states, latent = update_reconstruction(event_tensor[:, i*C:(i+1)*C])
         -> (out, states, latent) of the LAST step (out is None unless need_image).  Same per-slice arithmetic; what changes is the
         issue pattern: the non-zero mean / std normalisation of all T slices runs as ONE reduce + ONE map launch straight from the
         [B, T*C, H, W] tensor (no per-slice strided copy, 2 launches instead of 3 T), and the steps t < T-1 are lean.  Falls back
-        to the per-slice path when the preprocessor has hot pixels / flipping or the size needs reflection padding."""
+        to the per-slice path when the preprocessor has hot pixels / flipping or the size needs reflection padding.
+        final_lean (the trainers, which reset the state with every batch): the LAST step's recurrent blocks run their lean form too
+        (hidden states as BF16_C8 copies only, on the wide-tile gate kernel) -- the returned image and latents are bit-identical,
+        the returned states carry no fp32 hidden tensors (round 5: the non-lean last step cost 1.0 ms of the 23.4 ms step)."""
         from .. import hip
         with torch.no_grad():
             events = event_tensor.to(self.device)
@@ -107,5 +115,5 @@ class ImageReconstructor:
                 if prefix is not None and not last:
                     B = events.shape[0]
                     pf = (prefix[0][i * B:(i + 1) * B], prefix[1][i * B:(i + 1) * B])
-                res = self._step(ev, need_image and last, not last, prefix=pf)
+                res = self._step(ev, need_image and last, not last, prefix=pf, final_lean=final_lean and last)
             return res

@@ -46,9 +46,9 @@ class E2VIDRecurrent(BaseE2VID):
         super().__init__(config)
         self.unetrecurrent = UNetRecurrent(recurrent_block_type=self.recurrent_block_type, **self._unet_kwargs())
 
-    def forward(self, event_tensor, prev_states, encoder_only=False, lean=False, prefix=None):
-        """-> (img N x 1 x H x W, states per encoder, latent {1,2,4,8}); encoder_only / lean / prefix: see UNetRecurrent.forward."""
-        return self.unetrecurrent.forward(event_tensor, prev_states, encoder_only=encoder_only, lean=lean, prefix=prefix)
+    def forward(self, event_tensor, prev_states, encoder_only=False, lean=False, prefix=None, lean_state=False):
+        """-> (img N x 1 x H x W, states per encoder, latent {1,2,4,8}); encoder_only / lean / prefix / lean_state: see UNetRecurrent.forward."""
+        return self.unetrecurrent.forward(event_tensor, prev_states, encoder_only=encoder_only, lean=lean, prefix=prefix, lean_state=lean_state)
 
     def forward_prefix(self, event_tensors):
         """head + first encoder conv for many time slices at once (UNetRecurrent.forward_prefix)."""

@@ -602,6 +602,7 @@ class ResidualBlock(nn.Module):
         sc1, sh1 = self._f1.get(s1, self.conv1.bias, 'BN' if bn else None, getattr(self, 'bn1', None))
         sc2, sh2 = self._f2.get(s2, self.conv2.bias, 'BN' if bn else None, getattr(self, 'bn2', None))
         o = torch.empty(N, self.conv1.out_channels, H, W, dtype=torch.float32, device=x.device)
+        x = _fp32(x)  # (an unwritten lean-state placeholder must not be read as fp32)
         hip.conv_forward(s1, x, None, packed_weight(s1, self.conv1.weight), sc1, sh1, out=o)
         if not fused:
             o, _ = hip.instnorm_forward(o, None, 1, EPS)

@@ -54,6 +54,11 @@ class BaseUNet(nn.Module):
             return decoder.forward_sum(x, skip, **kw)
         return decoder.forward_cat(x, skip, **kw)  # (both decoder kinds read the concat through the kernel's two-source loader)
 
+    def _tail_reads_copies(self):
+        """True when resblocks / decoders stage their inputs from BF16_C8 copies (the c8 chain of _tail)"""
+        return hip.get_compute() == 'bf16' and self.use_upsample_conv and self.skip_type in ('sum', 'concat') and \
+            hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 1, 2) and self.norm != 'IN'
+
     def _tail(self, x, blocks, head):
         # bf16 arithmetic with upsample-conv decoders: the resblock outputs and every decoder output but the last are consumed by
         # an upsampling pass only, which reads BF16_C8 copies -- those tensors are produced as copies and nothing else
@@ -139,15 +144,23 @@ class UNetRecurrent(BaseUNet):
         x0 = self.encoders[0].conv(h, want_c8=True, c8_only=True)
         return _c8_of(h), _c8_of(x0)
 
-    def forward(self, x, prev_states, encoder_only=False, lean=False, prefix=None):
+    def forward(self, x, prev_states, encoder_only=False, lean=False, prefix=None, lean_state=False):
         """lean (needs encoder_only; effective in bf16 arithmetic): the step's only purpose is the
         recurrent state for the NEXT step, so the fp32 forms of the head output and of the hidden states are not written
         (their BF16_C8 copies and the fp32 cell states are); `latent` is None.  Result-identical for the steps t < T-1 of
-        a sequence: the next step stages x and h from the copies anyway."""
+        a sequence: the next step stages x and h from the copies anyway.
+        lean_state (any step, the last one of a training sequence in particular): only the RECURRENT BLOCKS run their lean form --
+        hidden states leave as BF16_C8 copies (+ channel-blocked fp32 cells), their fp32 NCHW tensors are unwritten placeholders.
+        Everything downstream in this package stages the copies (residual blocks, decoders, the semantic decoder, the L1 latent
+        losses), so the outputs are bit-identical; a caller that wants fp32 hidden states keeps lean_state off."""
         if lean and not encoder_only:
             raise ValueError('lean needs encoder_only')
         # every consumer of the unwritten fp32 tensors must be able to stage their BF16_C8 copies (diagnostic switches may forbid it)
-        lean = lean and hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2)
+        c8_ok = hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2)
+        lean = lean and c8_ok
+        # (lean_state on a full step: the tail must be the all-BF16_C8 chain -- upsample-conv decoders, fused norms; a module that
+        # would read the fp32 hidden state refuses the unwritten placeholder loudly: submodules._fp32)
+        lean_state = lean or (lean_state and c8_ok and (encoder_only or self._tail_reads_copies()))
         x_conv0 = None
         if prefix is not None:  # (lean steps only: head and first conv were computed for all slices at once, forward_prefix)
             if not lean:
@@ -164,7 +177,7 @@ class UNetRecurrent(BaseUNet):
             prev_states = [None] * self.num_encoders
         blocks, states = [], []
         for i, encoder in enumerate(self.encoders):
-            x, state = encoder(x, prev_states[i], lean=lean, x_conv=x_conv0 if i == 0 else None)
+            x, state = encoder(x, prev_states[i], lean=lean_state, x_conv=x_conv0 if i == 0 else None)
             blocks.append(x)
             states.append(state)
         if lean:

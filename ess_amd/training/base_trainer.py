@@ -82,7 +82,7 @@ class BaseTrainer(object):
     def enable_step_graph(self, example_batch, warmup=2):
         """NOTE: the `warmup` iterations are REAL train steps on `example_batch` (weights, optimiser moments and BatchNorm running
         statistics move), as torch's capture recipe prescribes; pass warmup=0 to capture without them once the step has run."""
-        dp = D.world_size() > 1
+        dp = D.dp_active()
         flat = lambda b: [t for part in b for t in (part if isinstance(part, (list, tuple)) else [part])]  # noqa: E731
         unflat = lambda like, ts: [unflat_part(p, ts) for p in like]  # noqa: E731
 

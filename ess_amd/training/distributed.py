@@ -31,17 +31,43 @@ def init_for_device(device, backend=None):
     HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment for multi-process GPU work on this driver (dmabuf IPC only)."""
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    extra = {}
+    if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:  # no launcher: a one-rank group (ESS_DP_FORCE on a single-GPU box)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        extra = {'rank': 0, 'world_size': 1, 'init_method': f'tcp://127.0.0.1:{port}'}
     if backend is None:
         backend = os.environ.get('ESS_DIST_BACKEND', 'nccl')
     if backend == 'nccl':
-        dist.init_process_group(backend='nccl', device_id=device)
+        dist.init_process_group(backend='nccl', device_id=device, **extra)
     else:
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, **extra)
     return backend
 
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+# ESS_DP_FORCE=1 (or force_dp(True)): take every data-parallel branch -- bucketed / captured all-reduce, broadcast, validation sums --
+# also in a ONE-rank process group.  A single-GPU box can then execute the whole RCCL side (communicator creation bound to the device,
+# ncclAllReduce with ReduceOp.AVG on RCCL's stream, its interplay with hipGraph capture / replay) that a multi-GPU run depends on;
+# averaging over one rank is the identity, so the step's results are those of the plain step (tests/test_hip_graph.py).
+_FORCE = os.environ.get('ESS_DP_FORCE', '0') not in ('', '0')
+
+
+def force_dp(on=True):
+    global _FORCE
+    _FORCE = bool(on)
+
+
+def dp_active():
+    """True when the data-parallel code paths run: more than one rank, or a (one-rank) process group under ESS_DP_FORCE."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE
 
 
 def rank():
@@ -75,12 +101,12 @@ class GradAllReducer:
             self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t))
 
     def launch(self, flat_grad):
-        if world_size() <= 1:
+        if not dp_active():
             return
         self._reduce(flat_grad)
 
     def arm(self, opt, n_buckets=2):
-        if world_size() <= 1:
+        if not dp_active():
             return
         from .. import functional as Fn
         params = list(opt.param_groups[0]['params'])
@@ -147,7 +173,7 @@ class GradAllReducer:
 
 def all_reduce_sum_(tensors):
     """In-place SUM over ranks of a list of tensors (validation confusion matrices / loss sums); no-op on one rank."""
-    if world_size() <= 1:
+    if not dp_active():
         return
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -157,7 +183,7 @@ def reduce_validation_sums(cumulative_losses, n, device=None):
     """Loss sums and batch count of a validation epoch, summed over the ranks (each validates its own shard).  EVERY rank must
     call this, also one whose shard was empty (n == 0, no keys): it contributes zeros for the keys the others report -- a rank
     that skipped the collectives would leave the others blocked in them."""
-    if world_size() <= 1:
+    if not dp_active():
         return cumulative_losses, n
     gathered = [None] * world_size()
     dist.all_gather_object(gathered, sorted(cumulative_losses))
@@ -173,7 +199,7 @@ def reduce_validation_sums(cumulative_losses, n, device=None):
 
 def broadcast_module(module, src=0):
     """Make every rank start from rank `src`'s weights/buffers."""
-    if world_size() <= 1:
+    if not dp_active():
         return
     from .. import functional as Fn
     with torch.no_grad():

@@ -90,7 +90,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         self.reconstructor.last_states_for_each_channel = {'grayscale': None}
         T, C = s.nr_events_data_b, s.input_channels_b
         # (only the encoder half feeds the recurrent state and the latents: no reconstruction is needed by this trainer)
-        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=False)
+        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=False, final_lean=True)
         losses, outputs = {}, {}
         loss, pred_b = self.trainTaskStep('sensor_b', latent_real, labels_b, losses)
         return loss, losses, outputs
@@ -138,7 +138,7 @@ class ESSSupervisedModel(base_trainer.BaseTrainer):
         with torch.no_grad():
             self.reconstructor.last_states_for_each_channel = {'grayscale': None}
             T, C = s.nr_events_data_b, s.input_channels_b
-            _, _, latent = self.reconstructor.update_reconstruction_sequence(data, T, need_image=False)
+            _, _, latent = self.reconstructor.update_reconstruction_sequence(data, T, need_image=False, final_lean=True)
             self.valTaskStep(latent, labels, losses, sensor)
         return losses, None
 

@@ -261,7 +261,7 @@ class ESSModel(base_trainer.BaseTrainer):
         T, C = s.nr_events_data_b, s.input_channels_b
         # (the loop `for i in range(T): update_reconstruction(data_b[:, i*C:(i+1)*C])` of the reference as one call: all T slices
         # normalised by one reduce + one map launch, lean steps for t < T-1)
-        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=True)
+        img_fake, states_real, latent_real = self.reconstructor.update_reconstruction_sequence(data_b, T, need_image=True, final_lean=True)
         return img_fake, latent_real
 
     def event_train_step(self, batch, enc=None):
@@ -389,7 +389,7 @@ class ESSModel(base_trainer.BaseTrainer):
             rec = self.reconstructor_valid
             rec.last_states_for_each_channel = {'grayscale': None}
             T, C = s.nr_events_data_b, s.input_channels_b
-            img_fake, _, content = rec.update_reconstruction_sequence(data, T, need_image=True)  # (only the last slice's image and latents are consumed)
+            img_fake, _, content = rec.update_reconstruction_sequence(data, T, need_image=True, final_lean=True)  # (only the last slice's image and latents are consumed)
             preds = self.valTaskStep(content, labels, losses, sensor)
             self.valCycleStep(content, img_fake, labels, losses, sensor, 'sensor_a', preds)
         return losses, None

@@ -279,6 +279,15 @@ def test_pre_norm_f16_saturates(H):
         assert d < 5e-2, d
         dy = H.to_bf16_c8(torch.randn(N, C, Hh, Ww, device=dev, generator=g))
         assert torch.isfinite(H.from_bf16_c8(H.instnorm_backward_c8(o16, C, dy, st16, True, x_f16=True), C)).all()
+        # saturating must not swallow NaN (v_med3_f32 alone stores -65504 for a NaN accumulator): a NaN in the bias reaches the
+        # F16_C8 tensor as NaN, as it does the BF16_C8 one, so a diverged run still shows up in the statistics and the loss
+        bn = b.clone()
+        bn[3] = float('nan')
+        pbn = H.pack_rows(spec, bn)
+        H.conv_forward(spec, x8, None, pw, None, pbn, out=o16, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F16_C8)
+        H.conv_forward(spec, x8, None, pw, None, pbn, out=o8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_BF16_C8)
+        n16, n8 = torch.isnan(H.f16_c8_to_float(o16, C)), torch.isnan(H.from_bf16_c8(o8, C))
+        assert n16[:, 3].all() and torch.equal(n16, n8) and not n16[:, :3].any() and not n16[:, 4:].any()
     finally:
         H.set_compute('fp32')
 

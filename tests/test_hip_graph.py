@@ -188,3 +188,33 @@ def test_data_parallel_captured_step_full_size():
     assert r.returncode == 0, '\n'.join(lines) + r.stderr[-2000:]
     assert r.stdout.count('eager~graph True') == 2 and r.stdout.count('ranks_agree True') == 2, lines
     assert r.stdout.count('losses_finite True') == 2 and r.stdout.count('peak_memory_GiB') == 2, lines
+
+
+def _run_rccl_worker(args, timeout):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'ESS_DIST_BACKEND')}
+    env.update(MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', ESS_DP_FORCE='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dp_rccl_worker.py')] + list(args), cwd=root, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if 'RCCL1' in ln]
+    print('\n'.join(lines))
+    assert r.returncode == 0, '\n'.join(lines) + r.stderr[-3000:]
+    assert any('backend nccl world 1' in ln and 'ok True' in ln for ln in lines), lines
+    return lines
+
+
+@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16')])
+def test_rccl_one_rank_dp_step_matches_plain(kind, mode):
+    """The RCCL side of the data-parallel step on THIS box: a one-rank 'nccl' process group under ESS_DP_FORCE=1 (tests/dp_rccl_worker.py).
+    (a) the eager step with bucketed all_reduce(AVG, async_op) calls issued from inside the backward, (b) the captured step as
+    [graph | all-reduce | graph | all-reduce | graph] with real collectives between the replays: losses of three steps and every weight
+    of the trainable networks bit-equal to the plain (no process group traffic) step of the same issue form."""
+    _run_rccl_worker([kind, mode], 900)
+
+
+def test_rccl_one_rank_dp_step_full_size():
+    """The same at the config-3 shape (B = 4, T = 5, 2 x 480 x 640, K = 11, bf16): 9.5 M gradient floats through ncclAllReduce per step."""
+    _run_rccl_worker(['ess', 'bf16', 'full'], 1500)

@@ -787,6 +787,11 @@ WIDE_CASES = [
 ]
 
 
+# (conv_wide, conv_wide_tail): the ws kernel, then the wide-tile kernel with the burst epilogue, the accumulator-major tail chunk, and
+# the tail chunk + LDS-DMA weight staging -- four instruction streams, one arithmetic
+WIDE_SETTINGS = ((0, 0), (2, 0), (2, 1), (2, 3))
+
+
 @pytest.mark.parametrize('case', [(2, 64, 64, 40, 48, True), (1, 256, 256, 20, 32, True), (2, 64, 0, 40, 32, False), (1, 32, 32, 27, 44, True),
                                   (8, 64, 64, 120, 160, True)])
 def test_conv_wide_tile_lstm_bit_identical(H, case):
@@ -804,11 +809,12 @@ def test_conv_wide_tile_lstm_bit_identical(H, case):
     c = dev(torch.randn(N, hid // 8, Hh, Ww, 8, generator=g)) if has_prev else None
     spec = H.conv_spec(N, Hh, Ww, Cx, C1, 4 * hid, 3, 1, 1, epi=H.EPI_LSTM, hidden=hid, compute=H.COMPUTE_BF16)
     pw, pb = H.pack_weights(spec, dev(w)), H.pack_rows(spec, dev(b))
-    prev = H.tuning_get('conv_wide')
+    prev, prev_t = H.tuning_get('conv_wide'), H.tuning_get('conv_wide_tail')
     outs = []
     try:
-        for mode in (0, 2):
+        for mode, tail in WIDE_SETTINGS:
             H.tuning_set('conv_wide', mode)
+            H.tuning_set('conv_wide_tail', tail)
             co = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda')
             co.fill_(float('nan'))
             hb = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
@@ -819,9 +825,11 @@ def test_conv_wide_tile_lstm_bit_identical(H, case):
             outs.append((co.clone(), hb.view(torch.int16).clone()))
     finally:
         H.tuning_set('conv_wide', prev)
-    (c0, h0), (c1, h1) = outs
+        H.tuning_set('conv_wide_tail', prev_t)
+    (c0, h0), (c1, h1) = outs[0], outs[-1]
     assert torch.isfinite(c0).all() and not (h0 == 0x7fc0).any()
-    assert torch.equal(c0, c1) and torch.equal(h0, h1)
+    for k, (ck, hk) in enumerate(outs[1:]):  # every form of the wide-tile kernel against the ws kernel
+        assert torch.equal(c0, ck) and torch.equal(h0, hk), WIDE_SETTINGS[k + 1]
     # ... and it is the ConvLSTM step (fp64 math on bf16-rounded operands)
     xin = _un8(x, Cx).double()
     if C1:
@@ -853,11 +861,12 @@ def test_conv_wide_tile_gru_bit_identical(H, case):
     s2 = H.conv_spec(N, Hh, Ww, hid, hid, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, hidden=hid, compute=H.COMPUTE_BF16)
     pw1, pw2 = H.pack_weights(s1, dev(wu), dev(wr)), H.pack_weights(s2, dev(wo))
     pb1, pb2 = H.pack_rows(s1, dev(bu), dev(br)), H.pack_rows(s2, dev(bo))
-    prev = H.tuning_get('conv_wide')
+    prev, prev_t = H.tuning_get('conv_wide'), H.tuning_get('conv_wide_tail')
     outs = []
     try:
-        for mode in (0, 2):
+        for mode, tail in WIDE_SETTINGS:
             H.tuning_set('conv_wide', mode)
+            H.tuning_set('conv_wide_tail', tail)
             u, hn = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda'), H.f32_c8_empty(N, hid, Hh, Ww, 'cuda')
             u.fill_(float('nan')), hn.fill_(float('nan'))
             rh8, hn8 = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda'), H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
@@ -869,9 +878,11 @@ def test_conv_wide_tile_gru_bit_identical(H, case):
             outs.append((u.clone(), rh8.view(torch.int16).clone(), hn.clone(), hn8.view(torch.int16).clone()))
     finally:
         H.tuning_set('conv_wide', prev)
-    a, b = outs
+        H.tuning_set('conv_wide_tail', prev_t)
+    a, b = outs[0], outs[-1]
     assert torch.isfinite(a[0]).all() and torch.isfinite(a[2]).all() and not (a[1] == 0x7fc0).any() and not (a[3] == 0x7fc0).any()
-    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    for k, o in enumerate(outs[1:]):
+        assert all(torch.equal(p, q) for p, q in zip(a, o)), WIDE_SETTINGS[k + 1]
     # ... and it is the ConvGRU step (fp64 on bf16-rounded operands; r*h rounded to bf16 between the two kernels)
     xs = torch.cat([_un8(x8, hid), _un8(h8, hid)], 1).double()
     uu = torch.sigmoid(F.conv2d(xs, wu.bfloat16().double(), bu.double(), padding=1))
@@ -903,11 +914,12 @@ def test_conv_wide_tile_bit_identical(H, case):
     psh = H.pack_rows(spec, dev(b)) if has_shift else None
     xs0, xs1 = H.to_bf16_c8(dev(x0)), (H.to_bf16_c8(dev(x1)) if C1 else None)
     res = H.to_bf16_c8(dev(torch.randn(N, Co, Hh, Ww, generator=g))) if has_res else None
-    prev = H.tuning_get('conv_wide')
+    prev, prev_t = H.tuning_get('conv_wide'), H.tuning_get('conv_wide_tail')
     outs = []
     try:
-        for mode in (0, 2):
+        for mode, tail in WIDE_SETTINGS:
             H.tuning_set('conv_wide', mode)
+            H.tuning_set('conv_wide_tail', tail)
             mk = H.f16_c8_empty if f16 else H.bf16_c8_empty
             c1 = split if split else Co
             o1 = mk(N, c1, Hh, Ww, 'cuda')
@@ -921,11 +933,15 @@ def test_conv_wide_tile_bit_identical(H, case):
             outs.append((o1.view(torch.int16).clone(), None if o2 is None else o2.view(torch.int16).clone()))
     finally:
         H.tuning_set('conv_wide', prev)
-    (a1, a2), (b1, b2) = outs
-    assert not (a1 == (0x7e00 if f16 else 0x7fc0)).all()
-    assert torch.equal(a1, b1), (a1 != b1).float().mean().item()
-    if split:
-        assert torch.equal(a2, b2)
+        H.tuning_set('conv_wide_tail', prev_t)
+    a1, a2 = outs[0]
+    for k, (b1, b2) in enumerate(outs[1:]):  # every form of the wide-tile kernel against the ws kernel
+        # (zero-padded channel lanes cannot trip this: the NaN patterns differ from 0)
+        assert not (a1 == (0x7e00 if f16 else 0x7fc0)).any() and not (b1 == (0x7e00 if f16 else 0x7fc0)).any()
+        assert torch.equal(a1, b1), (WIDE_SETTINGS[k + 1], (a1 != b1).float().mean().item())
+        if split:
+            assert not (a2 == 0x7fc0).any() and not (b2 == 0x7fc0).any()
+            assert torch.equal(a2, b2), WIDE_SETTINGS[k + 1]
     # ... and both are the convolution (fp32 math on bf16-rounded operands, rounded to the stored type)
     xin = x0.bfloat16().float()
     if m0 == 1:

@@ -793,5 +793,22 @@ def test_sequence_call_matches_per_slice_loop(shape):
             img2, st2, lat2 = rec.update_reconstruction_sequence(ev, T, time_batched_prefix=True)
             assert torch.equal(img2, img1) and all(torch.equal(lat2[k], lat1[k]) for k in (1, 2, 4, 8))
             assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(st2, st1))
+            # final_lean (the trainers): the last step's recurrent blocks in their lean form too -- image and latents bit-identical
+            # (hidden states as BF16_C8 copies: the values every consumer stages anyway), with and without the image tail
+            from ess_amd.e2vid.model.submodules import _c8_of
+            for need_image in (True, False):
+                rec.last_states_for_each_channel = {'grayscale': None}
+                img1n, _, lat1n = rec.update_reconstruction_sequence(ev, T, need_image=need_image)
+                rec.last_states_for_each_channel = {'grayscale': None}
+                img3, st3, lat3 = rec.update_reconstruction_sequence(ev, T, need_image=need_image, final_lean=True)
+                if need_image:
+                    assert torch.equal(img3, img1n)
+                assert torch.equal(lat3[1], lat1n[1])
+                for k in (2, 4, 8):
+                    if mode == 'bf16' and H % 8 == 0:
+                        assert getattr(lat3[k], 'ess_fp32_unwritten', False), k  # the lean form did run
+                        assert torch.equal(_c8_of(lat3[k]).view(torch.int16), _c8_of(lat1n[k]).view(torch.int16)), k
+                    else:
+                        assert torch.equal(lat3[k], lat1n[k]), k
         finally:
             hip.set_compute('fp32')

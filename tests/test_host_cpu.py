@@ -474,6 +474,15 @@ def test_rccl_process_group_construction_mocked(monkeypatch):
     monkeypatch.delenv('MASTER_ADDR', raising=False)
     monkeypatch.setattr(dist, 'init_process_group', lambda **kw: calls.update(init=kw))
     dev = torch.device('cuda', 3)
+    # without a launcher (no RANK / WORLD_SIZE): a one-rank group on a private tcp:// rendezvous (ESS_DP_FORCE on a single-GPU box)
+    monkeypatch.delenv('RANK', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    assert D.init_for_device(dev) == 'nccl'
+    one = calls['init']
+    assert one['backend'] == 'nccl' and one['device_id'] == dev and one['rank'] == 0 and one['world_size'] == 1
+    assert one['init_method'].startswith('tcp://127.0.0.1:')
+    monkeypatch.setenv('RANK', '3')
+    monkeypatch.setenv('WORLD_SIZE', '8')
     assert D.init_for_device(dev) == 'nccl'
     assert calls['init'] == {'backend': 'nccl', 'device_id': dev}
     assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
@@ -494,3 +503,36 @@ def test_rccl_process_group_construction_mocked(monkeypatch):
     assert calls['ops'] == [(1000, dist.ReduceOp.AVG, True)] and calls['waited'] == 1
     assert torch.equal(g, torch.ones(1000))  # AVG on the wire: nothing divided on the host side
     assert D.stream_ordered_collectives()
+
+
+def test_forced_dp_one_rank_gloo(monkeypatch):
+    """ESS_DP_FORCE / force_dp: in a ONE-rank process group the data-parallel branches are taken (bench.py and the -m gpu tests run
+    the RCCL side of the step that way on a single-GPU box); without the switch a one-rank group is a no-op as before."""
+    import socket
+    import torch.distributed as dist
+    from ess_amd.training import distributed as D
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group('gloo', rank=0, world_size=1, init_method=f'tcp://127.0.0.1:{port}')
+    try:
+        seen = []
+        orig = dist.all_reduce
+        monkeypatch.setattr(dist, 'all_reduce', lambda t, *a, **k: (seen.append(t.numel()), orig(t, *a, **k))[1])
+        red = D.GradAllReducer()
+        g = torch.arange(6, dtype=torch.float32)
+        D.force_dp(False)
+        assert not D.dp_active()
+        red.launch(g)
+        red.wait()
+        assert seen == []
+        D.force_dp(True)
+        assert D.dp_active() and D.world_size() == 1
+        red.launch(g)
+        red.wait()
+        assert seen == [6] and torch.equal(g, torch.arange(6, dtype=torch.float32))  # mean over one rank
+        sums, n = D.reduce_validation_sums({'x': torch.tensor(1.5)}, 3)
+        assert n == 3.0 and float(sums['x']) == 1.5
+    finally:
+        D.force_dp(False)
+        dist.destroy_process_group()
