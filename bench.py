@@ -150,10 +150,10 @@ def decoder_conv3x3_layers(args):
 
 def _traffic_from_profiles(tag):
     """HBM bytes per launch set and the SQ-counter readings of the same launches (mfma_busy, sclk, LDS) from the PMC passes of
-    tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r4_traffic.json
+    tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r5_traffic.json (r4 / r3 as fall-backs)
     (builder-side PMC passes over tools/traffic_probe.py, not re-measured in this run -- rocprofv3 cannot wrap a process from the
     inside); falls back to round 3's file; None when this shape / kernel was not profiled."""
-    for name in ('r4_traffic.json', 'r3_traffic.json'):
+    for name in ('r5_traffic.json', 'r4_traffic.json', 'r3_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 t = json.load(f).get(tag)
@@ -177,7 +177,7 @@ def _pmc_summary(t):
         if 'mfma_busy' in out:
             out['mfma_busy_at_sclk'] = round(out['mfma_busy'] * 2.4 / out['sclk_GHz'], 4)
     if out:
-        out['pmc_note'] = ('rocprofv3 --pmc passes (profiles/r4_conv_pmc.txt): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) -- matrix-pipe '
+        out['pmc_note'] = ('rocprofv3 --pmc passes (profiles/r5_conv_pmc.txt): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) -- matrix-pipe '
                            'issue slots used at the NOMINAL clock; sclk_GHz = SQ_BUSY_CYCLES / 32 shader engines / kernel time, the clock the launches ran at; '
                            'mfma_busy_at_sclk = the same slots against that clock; hbm_GBps = (2 FETCH_SIZE + WRITE_SIZE) / kernel time against the 8 TB/s HBM3E peak')
     return out

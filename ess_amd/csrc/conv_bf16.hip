@@ -170,20 +170,6 @@ int wide_mode() {
   return m;
 }
 void set_wide_mode(int m) { g_wide_mode.store(m < 0 ? 0 : m, std::memory_order_relaxed); }
-// "conv_wide_tail" (ESS_CONV_WIDE_TAIL, default 1): the wide-tile kernel's last chunk runs accumulator-major with per-block epilogues
-// (conv_bf16_wide.hip, TAIL) -- same arithmetic in the same order, bit-identical results; 0 = the burst epilogue behind the K loop;
-// 3 = TAIL + the weight slabs staged by LDS-DMA (WDMA)
-static std::atomic<int> g_wide_tail{-1};
-int wide_tail() {
-  int m = g_wide_tail.load(std::memory_order_relaxed);
-  if (m < 0) {
-    const char* e = getenv("ESS_CONV_WIDE_TAIL");
-    m = e ? atoi(e) : 1;
-    g_wide_tail.store(m, std::memory_order_relaxed);
-  }
-  return m;
-}
-void set_wide_tail(int m) { g_wide_tail.store(m == 3 ? 3 : (m != 0 ? 1 : 0), std::memory_order_relaxed); }
 
 // ---- dispatcher constants, in ONE place, each with the shape it was measured at.  Read once (environment overrides at first use,
 // then immutable); the compute-unit count comes from the device the calling thread is on (256 on MI355X), never from a literal.
@@ -343,7 +329,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
       const int cus = tuning().cus;  // one workgroup per CU
       t.persist = wp.tiles > cus ? 1 : 0;
       t.slab = pl.cout_tile;
-      conv_bf16_launch_wide(wp.mbw, wp.cw, d->epilogue, dim3((unsigned)(wp.tiles > cus ? cus : wp.tiles)), st, t, wide_tail());
+      conv_bf16_launch_wide(wp.mbw, wp.cw, d->epilogue, dim3((unsigned)(wp.tiles > cus ? cus : wp.tiles)), st, t);
       return ess_launch_status("conv2d_forward(bf16, wide tile)");
     }
     if (lds2 <= 160 * 1024) {

@@ -180,12 +180,14 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
         const bool first = c0 < a.C0 || a.C1 == 0;
         const unsigned pls = first ? pl0 : pl1;
         const unsigned cbase = (unsigned)(first ? c0 : c0 - a.C0) * pls;
+        if (!a.split || vc == 3 * ch) {  // (split: one load per chunk serves its three virtual chunks, see conv_bf16_ws.hip)
 #pragma unroll
         for (int k = 0; k < KPC; ++k) {
           const unsigned off = (first ? v_o0[k] : v_o1[k]) + cbase;
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             pre[k].v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
+        }
         }
         const u32x4* wsrc = wbase_s + (size_t)(a.split ? 2 * ch + w_lo : ch) * WSZ;
 #pragma unroll

@@ -42,15 +42,7 @@ constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
 
 // EPI: ESS_EPI_LINEAR (BF16_C8 outputs), ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h', bias in
 // the accumulators -- conv_epilogue_lstm_c8) or ESS_EPI_GRU_UR / ESS_EPI_GRU_OUT (the lean ConvGRU kernel pair: conv_epilogue_gru_*_c8)
-// TAIL: the last chunk of a tile runs accumulator-major -- pixel block by pixel block, all nine taps of one block, then that block's
-// epilogue -- so that the stores of block nb leave the CU under the MFMAs of block nb + 1 instead of as one burst behind the K loop
-// (round 5; per accumulator the order chunk by chunk, tap by tap is unchanged: results stay bit-identical).  The stage parity then
-// runs on across the tiles of a persistent workgroup (a tile's chunk ch lives in stage (sb + ch) & 1), and the matrix waves pass the
-// last chunk's barrier on ENTERING it: the staging waves start the next tile in the stage the tail does not read.
-// WDMA: the weight slab of a chunk goes L2 -> LDS by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction, issued by the staging
-// waves into the stage the matrix waves left at the previous barrier) instead of through VGPRs and ds_write_b128: 74 % of the staged
-// bytes of a 128 x 320 tile bypass the register file and the VGPR -> LDS store path.
-template <int MBW, int CW, int EPI = ESS_EPI_LINEAR, bool TAIL = false, bool WDMA = false>
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16, NB = WIDE_NB, RP = WIDE_RP;
@@ -127,24 +119,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const int c = ic % COT, tc = ic / COT;
       w_src[it] = (unsigned)((c / SLAB) * a.n_chunks * (KS * KS * CB8 * SLAB) + tc * SLAB + (c % SLAB));  // (SLAB is wave-uniform)
     }
-    struct Set { u32x4 pre[CB8][KPC]; u32x4 wpre[WDMA ? 1 : WV]; };
+    struct Set { u32x4 pre[CB8][KPC]; u32x4 wpre[WV]; };
     Set sa;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)(ct * NSLAB) * a.n_chunks * (KS * KS * CB8 * SLAB);
-    // (WDMA) this tile's slabs as a buffer resource; voffset = this lane's vector inside a chunk block, soffset = the chunk
-    const ess_rsrc r_w = ess_make_rsrc(wbase, (size_t)NSLAB * a.n_chunks * (KS * KS * CB8 * SLAB) * 16);
-    const unsigned lds_w0 = (unsigned)(size_t)smem16 + (unsigned)((CB8 * PLANE + (tid & ~63)) * 16);  // wave-uniform part of the LDS address
-    auto dma_weights = [&](int ch, int buf) {
-      if constexpr (WDMA) {
-        const unsigned soff = (unsigned)ch * (unsigned)(KS * KS * CB8 * SLAB * 16);
-#pragma unroll
-        for (int it = 0; it < WV; ++it) {
-          const int i = tid + it * 256;
-          if (i < WSZ)  // (lanes switched off by EXEC write nothing)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(size_t)(lds_w0 + (unsigned)((buf * BUFSZ + it * 256) * 16)),
-                                                     16, (int)(w_src[it] * 16u), (int)soff, 0, 0);
-        }
-      }
-    };
     auto load_chunk = [&](int ch, Set& r) {
 #ifdef ESS_ABLATE
       if (a.deep & 4) return;  // (ablation build only, switch ESS_WS_ABL: no global loads)
@@ -158,11 +135,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #pragma unroll
         for (int k = 0; k < KPC; ++k) r.pre[cb][k] = sp[first ? v_pos0[k] : v_pos1[k]];
       }
-      if constexpr (!WDMA) {
-        const u32x4* wsrc = wbase + (size_t)ch * (KS * KS * CB8 * SLAB);
+      const u32x4* wsrc = wbase + (size_t)ch * (KS * KS * CB8 * SLAB);
 #pragma unroll
-        for (int it = 0; it < WV; ++it) r.wpre[it] = wsrc[w_src[it]];
-      }
+      for (int it = 0; it < WV; ++it) r.wpre[it] = wsrc[w_src[it]];
     };
     auto commit = [&](int ch, int buf, const Set& r) {
 #ifdef ESS_ABLATE
@@ -183,32 +158,21 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
           if (v_lds[k] >= 0) in_t[cb * PLANE + v_lds[k]] = v;
         }
       }
-      if constexpr (!WDMA) {
 #pragma unroll
-        for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
-      }
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
     };
-    // (WDMA) before a barrier that publishes a stage its weight DMA must have landed; the CB8 * KPC input loads of the chunk after it,
-    // issued behind the DMA, may stay in flight (VMEM loads return in order)
-#define ESS_DMA_LANDED(PENDING_) { if constexpr (WDMA) { if (PENDING_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CB8 * KPC) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } }
     const int nch = a.n_chunks;
-    const int sb = TAIL ? (((ti - t_first) / t_step) * nch) & 1 : 0;  // stage of this tile's chunk 0
-    dma_weights(0, sb);
     load_chunk(0, sa);
-    commit(0, sb, sa);
+    commit(0, 0, sa);
     if (nch > 1) load_chunk(1, sa);
-    ESS_DMA_LANDED(nch > 1)
-    __syncthreads();  // the first stage is ready
+    __syncthreads();  // stage 0 is ready
     for (int ch = 0; ch < nch; ++ch) {
       if (ch + 1 < nch) {
-        dma_weights(ch + 1, (sb + ch + 1) & 1);
-        commit(ch + 1, (sb + ch + 1) & 1, sa);
+        commit(ch + 1, (ch + 1) & 1, sa);
         if (ch + 2 < nch) load_chunk(ch + 2, sa);
-        ESS_DMA_LANDED(ch + 2 < nch)
       }
       __syncthreads();
     }
-#undef ESS_DMA_LANDED
     }  // tile loop
     return;
   }
@@ -309,91 +273,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
     for (int ch = 0; ch < nch; ++ch) __syncthreads();
   } else
 #endif
-  if constexpr (!TAIL) {
+  {
     ESS_READ_TAP(f0, 0, lds0)
     for (int ch = 0; ch < nch; ch += 2) {
       ESS_CHUNK(f0, f1, ch)
       if (ch + 1 < nch) ESS_CHUNK(f1, f0, ch + 1)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the read issued behind the last chunk's barrier)
-  } else {
-    const int sb = (((ti - t_first) / t_step) * nch) & 1;
-    ESS_READ_TAP(f0, 0, lds0 + (unsigned)(sb * BUFSZ * 16))
-    // chunks 0 .. nch - 2 as above; the trailing read of the last one fetches tap 0 of the tail chunk for all blocks (discarded)
-    for (int ch = 0; ch + 1 < nch; ch += 2) {
-      ESS_CHUNK(f0, f1, ch + sb)
-      if (ch + 2 < nch) ESS_CHUNK(f1, f0, ch + 1 + sb)
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    ESS_TIE(f0) ESS_TIE(f1)
-    // the tail chunk's stage is complete (the barrier that ended chunk nch - 2, or "first stage ready" when nch == 1); the barrier
-    // the staging waves close the tile with is passed at once: nothing of this tile is left to stage
-    __syncthreads();
-    const unsigned stg_t = lds0 + (unsigned)(((sb + nch - 1) & 1) * BUFSZ * 16);
-    struct TFrags { u32x4 a[MBW]; u32x4 b; };
-    TFrags g0, g1;
-#define ESS_TREAD(G_, TAP_, NB_)                                                                                                  \
-    {                                                                                                                            \
-      constexpr int ky_ = (TAP_) / KS, kx_ = (TAP_) % KS;                                                                        \
-      const unsigned wa_ = stg_t + a_base, ba_ = stg_t + b_base;                                                                 \
-      _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                         \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(G_.a[mb]) : "v"(wa_ + (unsigned)(mb * 32 * 16)), "n"((TAP_) * CB8 * COT * 16)); \
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(G_.b) : "v"(ba_), "n"(((NB_) * 2 * RP + ky_ * RP + kx_) * 16));        \
-    }
-#define ESS_TWAIT(G_, N_)                                                                                                        \
-    {                                                                                                                            \
-      if constexpr (MBW == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(G_.a[0]), "+v"(G_.b) : "n"(N_));                       \
-      else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(G_.a[0]), "+v"(G_.a[MBW - 1]), "+v"(G_.b) : "n"(N_));                     \
-    }
-#define ESS_TMMA(G_, NB_)                                                                                                        \
-    _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                           \
-      acc[mb][NB_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, G_.a[mb]), __builtin_bit_cast(bf16x8, G_.b), acc[mb][NB_], 0, 0, 0);
-#define ESS_TBLOCK(NB_)                                                                                                          \
-    {                                                                                                                            \
-      ESS_TREAD(g1, 1, NB_) ESS_TWAIT(g0, NRT) ESS_TMMA(g0, NB_)                                                                 \
-      ESS_TREAD(g0, 2, NB_) ESS_TWAIT(g1, NRT) ESS_TMMA(g1, NB_)                                                                 \
-      ESS_TREAD(g1, 3, NB_) ESS_TWAIT(g0, NRT) ESS_TMMA(g0, NB_)                                                                 \
-      ESS_TREAD(g0, 4, NB_) ESS_TWAIT(g1, NRT) ESS_TMMA(g1, NB_)                                                                 \
-      ESS_TREAD(g1, 5, NB_) ESS_TWAIT(g0, NRT) ESS_TMMA(g0, NB_)                                                                 \
-      ESS_TREAD(g0, 6, NB_) ESS_TWAIT(g1, NRT) ESS_TMMA(g1, NB_)                                                                 \
-      ESS_TREAD(g1, 7, NB_) ESS_TWAIT(g0, NRT) ESS_TMMA(g0, NB_)                                                                 \
-      ESS_TREAD(g0, 8, NB_) ESS_TWAIT(g1, NRT) ESS_TMMA(g1, NB_)                                                                 \
-      if constexpr ((NB_) + 1 < NB) { ESS_TREAD(g1, 0, ((NB_) + 1 < NB ? (NB_) + 1 : 0)) ESS_TWAIT(g0, NRT) } else { ESS_TWAIT(g0, 0) } \
-      ESS_TMMA(g0, NB_)                                                                                                          \
-      tail_epilogue(std::integral_constant<int, (NB_)>{});                                                                       \
-    }
-    constexpr int NRT = MBW + 1;
-    auto tail_epilogue = [&](auto NBC) {
-      constexpr int nb = decltype(NBC)::value;
-      f32x16 acc1[MBW][1];
-#pragma unroll
-      for (int mb = 0; mb < MBW; ++mb) acc1[mb][0] = acc[mb][nb];
-      const int ly1[1] = {ly[nb]};
-      if constexpr (EPI == ESS_EPI_LINEAR) {
-        conv_epilogue_c8_wide<MBW>(a, acc1, ct_w, n, half, x0 + ox, y0, ly1, biased);
-      } else {
-        const int y = y0 + ly[nb], x = x0 + ox;
-        const int pixi1[1] = {(y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1};
-        if constexpr (EPI == ESS_EPI_LSTM) conv_epilogue_lstm_c8<MBW>(a, acc1, ct_w, n, half, pixi1, (unsigned)(a.Hout * a.Wout));
-        else if constexpr (EPI == ESS_EPI_GRU_UR) conv_epilogue_gru_ur_c8<MBW>(a, acc1, ct_w, n, half, pixi1, (unsigned)(a.Hout * a.Wout));
-        else conv_epilogue_gru_out_c8<MBW>(a, acc1, ct_w, n, half, pixi1, (unsigned)(a.Hout * a.Wout));
-      }
-    };
-    // block 0's first tap, then the five blocks; the two fragment sets swap roles from block to block (nine taps: odd)
-    ESS_TREAD(g0, 0, 0)
-    ESS_TBLOCK(0)
-    { TFrags t_ = g0; g0 = g1; g1 = t_; }
-    ESS_TBLOCK(1)
-    { TFrags t_ = g0; g0 = g1; g1 = t_; }
-    ESS_TBLOCK(2)
-    { TFrags t_ = g0; g0 = g1; g1 = t_; }
-    ESS_TBLOCK(3)
-    { TFrags t_ = g0; g0 = g1; g1 = t_; }
-    ESS_TBLOCK(4)
-#undef ESS_TBLOCK
-#undef ESS_TMMA
-#undef ESS_TWAIT
-#undef ESS_TREAD
   }
 #undef ESS_CHUNK
 #undef ESS_TIE
@@ -404,9 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #ifdef ESS_ABLATE
   if (a.deep & 8) continue;  // (ablation build only: no epilogue)
 #endif
-  if constexpr (TAIL) {
-    // (every block's epilogue ran inside the tail chunk)
-  } else if constexpr (EPI == ESS_EPI_LSTM) {
+  if constexpr (EPI == ESS_EPI_LSTM) {
     int pixi[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -431,17 +315,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #undef ESS_TILE_DECODE
 }
 
-// var: bit 0 = TAIL, bit 1 = WDMA (instantiated: 0, 1, 3)
 template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
-void launch_wide_t(dim3 grid, hipStream_t st, const ConvKArgs& a, int var) {
+void launch_wide_t(dim3 grid, hipStream_t st, const ConvKArgs& a) {
   constexpr int PW = 4 / CW, TH = PW * WIDE_NB * 2, PLANE = (TH + 2) * WIDE_RP, COT = MBW * CW * 32;
   constexpr size_t lds = 2 * (size_t)(2 * PLANE + 9 * 2 * COT) * 16;
   static_assert(lds <= 160 * 1024, "two stages must fit the 160 KiB LDS");
-#define ESS_WIDE_GO(T_, D_) { ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI, T_, D_>, lds); hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI, T_, D_>), grid, dim3(512), lds, st, a); }
-  if (var == 3) ESS_WIDE_GO(true, true)
-  else if (var & 1) ESS_WIDE_GO(true, false)
-  else ESS_WIDE_GO(false, false)
-#undef ESS_WIDE_GO
+  ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI>, lds);
+  hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI>), grid, dim3(512), lds, st, a);
 }
 
 }  // namespace
@@ -454,16 +334,14 @@ void conv_bf16_wide_tile(int mbw, int cw, int* th, int* tw) {
   (void)mbw;
 }
 
-// var: bit 0 = the accumulator-major last chunk with per-block epilogues (TAIL), bit 1 = weight slabs by LDS-DMA (WDMA; with TAIL only):
-// the dispatcher's switch "conv_wide_tail" (0 | 1 | 3)
-void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a, int var) {
-  if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a, var); return; }  // (recurrent epilogues: the dispatcher offers <2, 2> only)
-  if (epi == ESS_EPI_GRU_UR) { launch_wide_t<2, 2, ESS_EPI_GRU_UR>(grid, st, a, var); return; }
-  if (epi == ESS_EPI_GRU_OUT) { launch_wide_t<2, 2, ESS_EPI_GRU_OUT>(grid, st, a, var); return; }
-  if (mbw == 2 && cw == 2) launch_wide_t<2, 2>(grid, st, a, var);
-  else if (mbw == 2 && cw == 1) launch_wide_t<2, 1>(grid, st, a, var);
-  else if (mbw == 1 && cw == 2) launch_wide_t<1, 2>(grid, st, a, var);
-  else launch_wide_t<1, 1>(grid, st, a, var);
+void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a) {
+  if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a); return; }  // (recurrent epilogues: the dispatcher offers <2, 2> only)
+  if (epi == ESS_EPI_GRU_UR) { launch_wide_t<2, 2, ESS_EPI_GRU_UR>(grid, st, a); return; }
+  if (epi == ESS_EPI_GRU_OUT) { launch_wide_t<2, 2, ESS_EPI_GRU_OUT>(grid, st, a); return; }
+  if (mbw == 2 && cw == 2) launch_wide_t<2, 2>(grid, st, a);
+  else if (mbw == 2 && cw == 1) launch_wide_t<2, 1>(grid, st, a);
+  else if (mbw == 1 && cw == 2) launch_wide_t<1, 2>(grid, st, a);
+  else launch_wide_t<1, 1>(grid, st, a);
 }
 
 }  // namespace essconv

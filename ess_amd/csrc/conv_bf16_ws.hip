@@ -221,9 +221,13 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
     // fragments, same accumulators, three times the chunks.  The weight pack holds a hi and a lo slab per (tile, chunk).
     const int nvc = a.split ? 3 * a.n_chunks : a.n_chunks;
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ * (a.split ? 2 : 1);
+    // (round 5: the fp32 values of a chunk are loaded ONCE and stay in `pre` for its three virtual chunks -- hi, lo and hi again are
+    // three conversions of the same registers; the first version re-read them from L2 per virtual chunk, 12 bytes per element
+    // through the dword-per-plane path that already bounded the fp32-source kernel)
     auto load_chunk = [&](int vc) {
       const int ch = a.split ? vc / 3 : vc;
       const int w_lo = a.split && (vc - 3 * ch) == 2 ? 1 : 0;
+      if (!a.split || vc == 3 * ch) {
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
             pre[cb][k].v[j] =
                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(first ? r0 : r1, (int)(off + j * pls), 0, 0));
         }
+      }
       }
       const u32x4* wsrc = wbase + (size_t)(a.split ? 2 * ch + w_lo : ch) * WSZ;
 #pragma unroll

@@ -1014,6 +1014,11 @@ static SplitCopies split_copies(const EssConvDesc* d) {
   return s;
 }
 
+// the lo copies of a fused split-operand call, handed to the BF16_C8 3x3 launch of the SAME thread's nested entry (no public
+// signature changes; null outside that nested call)
+struct X3Lo { const void* x0; const void* x1; const void* dy; };
+static thread_local const X3Lo* g_x3 = nullptr;
+
 extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   if (wvalidate(d)) return 0;
   if (split_via_c8(d)) {
@@ -1051,6 +1056,16 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     if ((rc = ess_split_bf16_c8_internal(src0, x0h, x0l, d->N, d->C0, d->H_in >> s0, d->W_in >> s0, st))) return rc;
     if (d->C1 && (rc = ess_split_bf16_c8_internal(src1, x1h, x1l, d->N, d->C1, d->H_in >> s1, d->W_in >> s1, st))) return rc;
     if ((rc = ess_split_bf16_c8_internal(dy, dyh, dyl, d->N, d->C_out, d->H_out, d->W_out, st))) return rc;
+    // ONE launch of the LDS-DMA kernel walking the tile list three times (WgradBArgs::x3): one slab set, one reduce (round 5; the
+    // three accumulating launches of round 4 wrote and reduced the slabs three times: ESS_X3_WGRAD_FUSED=0 brings them back)
+    static const bool fused = [] { const char* e = getenv("ESS_X3_WGRAD_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused) {
+      const X3Lo lo{x0l, d->C1 ? x1l : nullptr, dyl};
+      g_x3 = &lo;
+      rc = ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyh, dw, db, accumulate, workspace, slabs, stream);
+      g_x3 = nullptr;
+      return rc;
+    }
     if ((rc = ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyh, dw, db, accumulate, workspace, slabs, stream))) return rc;
     if ((rc = ess_conv2d_wgrad(&dc, x0l, d->C1 ? x1l : nullptr, dyh, dw, nullptr, 1, workspace, slabs, stream))) return rc;
     return ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyl, dw, db, 1, workspace, slabs, stream);
@@ -1127,6 +1142,10 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     if (w.bf16_1x1) bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile
+    if (g_x3) {
+      ESS_CHECK_ARG(!w.bf16_1x1 && d->stride == 1, "wgrad: the fused split-operand form exists for the 3x3 / stride-1 LDS-DMA kernel only");
+      bb.x3 = 1; bb.x0_lo = g_x3->x0; bb.x1_lo = g_x3->x1; bb.dy_lo = g_x3->dy;
+    }
     if ((rc = wgrad_c8_launch(bb, w.bf16_1x1 ? 1 : 9, d->stride, 2 * w.lds_bytes, grid, st))) return rc;
   } else if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {
     const int per_img = d->H_out * d->W_out / 64;

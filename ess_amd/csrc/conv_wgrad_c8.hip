@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
-  const bool want_b = a.ws_b && cit == 0 && ib == 0;
+  const bool want_b0 = a.ws_b && cit == 0 && ib == 0;
+  bool want_b = want_b0;  // (x3: dY_hi is contracted twice -- passes 0 and 1 --, the bias gradient takes it once: off during pass 1)
 
   // K loop over this workgroup's pixel tiles: 8 k-steps of 16 pixels x TAPS taps per tile, two LDS stages; the quads of tile
   // t+1 (loads issued behind the first k-step) are transposed and written into the other stage on k-steps 4-7
@@ -330,8 +331,9 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
   const int Cin = a.C0 + a.C1;
   const unsigned lds0 = (unsigned)(size_t)smem_dma;
+  const int ntt = b.x3 ? 3 * a.ntiles : a.ntiles;  // (split operands: three passes over the tile list, see WgradBArgs)
   int ntl = 0;  // this workgroup's tiles: split, split + nsplit, ...
-  if (split < a.ntiles) ntl = (a.ntiles - 1 - split) / nsplit + 1;
+  if (split < ntt) ntl = (ntt - 1 - split) / nsplit + 1;
 
   ESS_TR(0);
   if (loader) {
@@ -361,16 +363,21 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     }
     const int tpi = a.tiles_x * a.tiles_y;
     auto issue = [&](int tile, int st) {
+      int pass = 0;
+      if (b.x3) { pass = tile / a.ntiles; tile -= pass * a.ntiles; }  // (wave-uniform)
+      const char* p_dy = (const char*)(pass == 2 ? b.dy_lo : (const void*)a.dy);
+      const char* p_x0 = (const char*)(pass == 1 ? b.x0_lo : (const void*)a.src0);
+      const char* p_x1 = (const char*)(a.C1 ? (pass == 1 ? b.x1_lo : (const void*)a.src1) : (const void*)p_x0);
       const int n = tile / tpi;
       const int tr = tile - n * tpi;
       const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
       const int y0 = ty * G::TH, x0 = tx * G::TW;
       const __amdgpu_buffer_rsrc_t r_dy =
-          __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + (size_t)n * nbo * HWo16), 0, (int)(nbo * HWo16), 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void*)(p_dy + (size_t)n * nbo * HWo16), 0, (int)(nbo * HWo16), 0x00020000);
       const __amdgpu_buffer_rsrc_t r_x0 =
-          __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.src0 + (size_t)n * nb0 * HW0_16), 0, (int)(nb0 * HW0_16), 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc((void*)(p_x0 + (size_t)n * nb0 * HW0_16), 0, (int)(nb0 * HW0_16), 0x00020000);
       const __amdgpu_buffer_rsrc_t r_x1 = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)((const char*)(a.C1 ? a.src1 : a.src0) + (size_t)n * (a.C1 ? nb1 * HW1_16 : 0u)), 0, (int)(a.C1 ? nb1 * HW1_16 : 0u), 0x00020000);
+          (void*)(p_x1 + (size_t)n * (a.C1 ? nb1 * HW1_16 : 0u)), 0, (int)(a.C1 ? nb1 * HW1_16 : 0u), 0x00020000);
       const unsigned sbase = lds0 + (unsigned)st * G::STAGE;
       unsigned vd[2], vx0[G::XP], vx1[G::XP];
 #pragma unroll
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
-  const bool want_b = a.ws_b && cit == 0 && ib == 0;
+  const bool want_b0 = a.ws_b && cit == 0 && ib == 0;
+  bool want_b = want_b0;  // (x3: dY_hi is contracted twice -- passes 0 and 1 --, the bias gradient takes it once: off during pass 1)
   const int g = lane >> 4, i16 = lane & 15;
   const unsigned pix_off = (unsigned)((8 * (g >> 1) + (i16 >> 2)) * 16 + (i16 & 1) * 8);
   const unsigned pl_sel = (unsigned)(2 * (g & 1) + ((i16 & 3) >> 1));
@@ -502,6 +510,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   }
   for (int k = 0; k + 1 < ntl; ++k) {  // every tile but the last
     if (k < 30) ESS_TR(3 + k);
+    if (b.x3) want_b = want_b0 && (split + k * nsplit) / a.ntiles != 1;
     const unsigned nst = (unsigned)((k + 1) % NST) * G::STAGE;
     a_next = lds0 + nst + a_lane;
     x_next = lds0 + nst + x_lane;
@@ -514,6 +523,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   }
   if (ntl > 0) {
     if (ntl - 1 < 30) ESS_TR(3 + ntl - 1);
+    if (b.x3) want_b = want_b0 && (split + (ntl - 1) * nsplit) / a.ntiles != 1;
     static_for<0, 24>([&](auto uc) { unit(uc, No{}); });
   }
   ESS_TR(34);

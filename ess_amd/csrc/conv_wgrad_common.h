@@ -62,6 +62,12 @@ struct WgradBArgs {
   int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
   int split;         // split-operand bf16 (ESS_COMPUTE_BF16X3, fp32-staged kernels): every pixel tile is contracted three times --
                      // (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) -- into the same accumulators
+  // split operands on the BF16_C8 LDS-DMA kernel (round 5): x3 != 0 -> the tile list is walked three times, pass p = tile / ntiles
+  // reading (dY, X) = (w.dy, w.src*), (w.dy, x*_lo), (dy_lo, w.src*) -- one launch, one slab set and one reduce instead of three
+  int x3;
+  const void* x0_lo;
+  const void* x1_lo;
+  const void* dy_lo;
 };
 
 // conv_wgrad_c8.hip: launchers (the caller has validated the geometry and sized the workspace)

@@ -10,6 +10,7 @@
 //     registers between the reduction and the map (2 B read + 2 B written per element);
 //   * larger planes and BatchNorm (few channel blocks, reduction over N x H x W): pass 1 writes one fp64 partial per
 //     (group, slice, channel) -- no atomics, fixed summation order --, pass 2 totals them and applies the map.
+#include <atomic>
 #include "common.h"
 #include <stdlib.h>
 
@@ -80,7 +81,9 @@ __device__ __forceinline__ u32x4n opaque(u32x4n v) {
 }
 
 // ---- InstanceNorm forward, fused: one workgroup per (n, channel block)
-template <int THREADS>
+// MV_: vectors per thread (0: the default of the thread count).  Small planes (60 x 80: 4800 vectors) run 256 x 20 by default; the
+// 512 x 10 / 1024 x 5 forms put 8 / 16 waves on the CU that owns the plane (tuning switch "in_small_threads")
+template <int THREADS, int MV_ = 0>
 __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                             u32x4n* __restrict__ y, float* __restrict__ stats, int CB, int C,
                                                             int hw, float eps, int relu) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
   __shared__ float red[16 * 8];
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   const size_t base = (size_t)g * hw;
-  constexpr int MV = THREADS == 1024 ? 19 : MAXV;  // (16 waves per CU: 128 registers per thread)
+  constexpr int MV = MV_ ? MV_ : (THREADS == 1024 ? 19 : MAXV);  // (16 waves per CU: 128 registers per thread)
   u32x4n xv[MV];
   float s[8];
 #pragma unroll
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
     stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x)] = m;
     stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x) + 1] = r;
   }
-  constexpr int RB = THREADS == 1024 ? 1 : 5;  // residual vectors in flight per batch (register budget)
+  constexpr int RB = (THREADS == 1024 && MV > 5) ? 1 : 5;  // residual vectors in flight per batch (register budget)
 #pragma unroll
   for (int k0 = 0; k0 < MV; k0 += RB) {
     u32x4n rv[RB];
@@ -168,9 +171,10 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
 }
 
 // ---- InstanceNorm backward, fused (256 threads: x and dy of a 60x80 block stay in registers)
-__global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
-                                                        const float* __restrict__ stats, u32x4n* __restrict__ dx, int CB, int C,
-                                                        int hw, int relu) {
+template <int THREADS = 256, int MV = MAXV>
+__global__ __launch_bounds__(THREADS) void in_bwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
+                                                            const float* __restrict__ stats, u32x4n* __restrict__ dx, int CB, int C,
+                                                            int hw, int relu) {
   const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
   relu &= 0xff;
   __shared__ float red[16 * 8];
@@ -183,19 +187,19 @@ __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict
     mean[j] = stats[2 * ((size_t)n * C + c)];
     rstd[j] = stats[2 * ((size_t)n * C + c) + 1];
   }
-  u32x4n xv[MAXV], gv[MAXV];
+  u32x4n xv[MV], gv[MV];
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {  // (unconditional loads from clamped addresses: see in_fwd_c8_kernel)
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < MV; ++k) {  // (unconditional loads from clamped addresses: see in_fwd_c8_kernel)
+    const int i = threadIdx.x + k * THREADS;
     xv[k] = x[base + (i < hw ? i : hw - 1)];
     gv[k] = dy[base + (i < hw ? i : hw - 1)];
   }
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
     if (i < hw) {
       float f[8], gg[8];
       unpack8x(xv[k], f, xf16);
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(256) void in_bwd_c8_kernel(const u32x4n* __restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] /= hw; s2[j] /= hw; }
 #pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int i = threadIdx.x + k * 256;
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
     if (i < hw) {
       float f[8], gg[8];
       unpack8x(opaque(xv[k]), f, xf16);
@@ -610,6 +614,20 @@ inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr
 // (sum, sum) pairs of doubles per group, slice and channel of the block; split_for8() keeps groups * slices <= 1024 + groups
 extern "C" size_t ess_norm_workspace_c8(int32_t groups) { return (size_t)(groups > 0 ? groups + 1024 : 0) * 8 * 16; }
 
+// "in_small_threads" (ESS_IN_SMALL_THREADS: 256 | 512 | 1024): threads of the fused single-plane InstanceNorm kernels on planes of
+// at most 5120 vectors (the decoder's 60 x 80 level).  Every setting computes the same statistics up to the summation order.
+static std::atomic<int> g_in_small{-1};
+int in_small_threads() {
+  int v = g_in_small.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("ESS_IN_SMALL_THREADS");
+    v = e ? atoi(e) : 512;  // (B = 8, 256 channels @ 60 x 80, MI355X: forward 17.8 / 16.7 / 17.4 us, backward 22.4 / 17.5 / 19.8 us at 256 / 512 / 1024)
+    g_in_small.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+extern "C" void ess_set_in_small_threads(int v) { g_in_small.store(v == 256 || v == 1024 ? v : 512, std::memory_order_relaxed); }
+
 extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C,
                                        int32_t hw, float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes,
                                        ess_stream_t stream) {
@@ -621,7 +639,10 @@ extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* rs = (const u32x4n*)residual; u32x4n* ys = (u32x4n*)y;
   if (hw <= 256 * MAXV) {
-    hipLaunchKernelGGL(in_fwd_c8_kernel<256>, dim3(groups), dim3(256), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
+    const int th = in_small_threads();
+    if (th == 1024 && hw <= 1024 * 5) hipLaunchKernelGGL((in_fwd_c8_kernel<1024, 5>), dim3(groups), dim3(1024), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
+    else if (th == 512 && hw <= 512 * 10) hipLaunchKernelGGL((in_fwd_c8_kernel<512, 10>), dim3(groups), dim3(512), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
+    else hipLaunchKernelGGL(in_fwd_c8_kernel<256>, dim3(groups), dim3(256), 0, st, xs, rs, ys, stats, CB, C, hw, eps, relu);
     return ess_launch_status("instnorm_forward_c8");
   }
   if (hw <= 1024 * 19 && groups >= in1024_min_groups()) {
@@ -648,7 +669,10 @@ extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const flo
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* gs = (const u32x4n*)dy; u32x4n* ds = (u32x4n*)dx;
   if (hw <= 256 * MAXV) {
-    hipLaunchKernelGGL(in_bwd_c8_kernel, dim3(groups), dim3(256), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
+    const int th = in_small_threads();
+    if (th == 1024 && hw <= 1024 * 5) hipLaunchKernelGGL((in_bwd_c8_kernel<1024, 5>), dim3(groups), dim3(1024), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
+    else if (th == 512 && hw <= 512 * 10) hipLaunchKernelGGL((in_bwd_c8_kernel<512, 10>), dim3(groups), dim3(512), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
+    else hipLaunchKernelGGL((in_bwd_c8_kernel<256, MAXV>), dim3(groups), dim3(256), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
     return ess_launch_status("instnorm_backward_c8");
   }
   int rc = need_ws(workspace, ess_norm_workspace_c8(groups), workspace_bytes, "instnorm_backward_c8");

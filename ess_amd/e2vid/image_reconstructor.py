@@ -15,6 +15,7 @@ from .utils.inference_utils import CropParameters, EventPreprocessor
 
 
 _LEAN = os.environ.get('ESS_LEAN', '1') != '0'  # diagnostic switch: materialise every fp32 state
+_FINAL_LEAN = os.environ.get('ESS_FINAL_LEAN', '1')[:1] != '0'  # (A/B switch of update_reconstruction_sequence(final_lean=True))
 _T_PREFIX = os.environ.get('ESS_T_PREFIX', '0') == '1'  # time-batched head + first conv (measured: see DESIGN.md section 7c)
 
 class ImageReconstructor:
@@ -53,7 +54,7 @@ class ImageReconstructor:
         """One model step on a normalised, padded, contiguous slice (under no_grad).  final_lean: a step whose image / latents ARE
         consumed, but whose recurrent state needs no fp32 form (the last step of a training sequence: UNetRecurrent.forward,
         lean_state)."""
-        fl = final_lean and not self.no_recurrent and _LEAN
+        fl = final_lean and not self.no_recurrent and _LEAN and _FINAL_LEAN
         if need_image:
             out, states, latent = self.model(events, self.last_states_for_each_channel['grayscale'], lean_state=fl)
         elif final_lean:

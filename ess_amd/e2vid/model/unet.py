@@ -160,7 +160,11 @@ class UNetRecurrent(BaseUNet):
         lean = lean and c8_ok
         # (lean_state on a full step: the tail must be the all-BF16_C8 chain -- upsample-conv decoders, fused norms; a module that
         # would read the fp32 hidden state refuses the unwritten placeholder loudly: submodules._fp32)
-        lean_state = lean or (lean_state and c8_ok and (encoder_only or self._tail_reads_copies()))
+        # ... and the upsampling passes take their BF16_C8 form for even plane widths only (an odd-width plane is upsampled from
+        # fp32 values: those of a lean state would be the bf16-rounded copy's -- close, not bit-identical)
+        wid = None if x is None else x.shape[3]
+        even = wid is not None and all(((wid >> i) & 1) == 0 for i in range(1, self.num_encoders + 1))
+        lean_state = lean or (lean_state and c8_ok and (encoder_only or (self._tail_reads_copies() and even)))
         x_conv0 = None
         if prefix is not None:  # (lean steps only: head and first conv were computed for all slices at once, forward_prefix)
             if not lean:

@@ -805,8 +805,10 @@ def test_sequence_call_matches_per_slice_loop(shape):
                     assert torch.equal(img3, img1n)
                 assert torch.equal(lat3[1], lat1n[1])
                 for k in (2, 4, 8):
-                    if mode == 'bf16' and H % 8 == 0:
-                        assert getattr(lat3[k], 'ess_fp32_unwritten', False), k  # the lean form did run
+                    ran_lean = getattr(lat3[k], 'ess_fp32_unwritten', False)
+                    if mode == 'bf16' and H % 8 == 0 and ((W >> 3) % 2 == 0 or not need_image):
+                        assert ran_lean, k  # the lean form did run (padded / odd-width planes may or may not take it)
+                    if ran_lean:
                         assert torch.equal(_c8_of(lat3[k]).view(torch.int16), _c8_of(lat1n[k]).view(torch.int16)), k
                     else:
                         assert torch.equal(lat3[k], lat1n[k]), k

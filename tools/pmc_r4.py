@@ -119,9 +119,10 @@ for gname, gd in groups.items():
                                       'hbm_GBps': round(gd['bytes'] / gd['us'] / 1e3, 1), 'tflops': round(gd['flops'] / gd['us'] / 1e6, 1),
                                       'mfma_busy': round(gd['busy'] / (1024 * gd['us'] * 1e3 * 2.4), 4), 'layers': gd['layers'],
                                       'source': 'tools/pmc_r4.py (rocprofv3 --pmc, separate passes over tools/traffic_probe.py)'}
-with open(os.path.join(ROOT, 'gpurun_out', 'r4_traffic.json'), 'w') as f:
+TAG = os.environ.get('ESS_PMC_TAG', 'r4')  # (round tag of the output files: ESS_PMC_TAG=r5 python tools/pmc_r4.py)
+with open(os.path.join(ROOT, 'gpurun_out', TAG + '_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
-with open(os.path.join(ROOT, 'gpurun_out', 'r4_conv_pmc.txt'), 'w') as f:
+with open(os.path.join(ROOT, 'gpurun_out', TAG + '_conv_pmc.txt'), 'w') as f:
     f.write('# rocprofv3 --pmc passes of tools/pmc_r4.py over tools/traffic_probe.py (B = 8, 480x640, bf16 configuration), per call of each plan entry\n')
     f.write('\n'.join(lines) + '\n')
 import shutil
