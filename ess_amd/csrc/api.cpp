@@ -32,11 +32,11 @@ void ess_allow_lds_impl(const void* kernel, size_t bytes) {
 // ---- tuning switches (process-wide; every setting gives identical results -- they choose between kernels of equal arithmetic)
 #include <string.h>
 namespace essconv { void set_wide_mode(int m); int wide_mode(); int device_cus(); }
-extern "C" void ess_set_in_small_threads(int v);
+void set_in_small_threads(int v);
 int in_small_threads();
 extern "C" int ess_tuning_set(const char* key, int32_t value) {
   if (key && !strcmp(key, "conv_wide")) { essconv::set_wide_mode(value); return ESS_OK; }
-  if (key && !strcmp(key, "in_small_threads")) { ess_set_in_small_threads(value); return ESS_OK; }
+  if (key && !strcmp(key, "in_small_threads")) { set_in_small_threads(value); return ESS_OK; }
   ess_set_error("tuning_set: unknown key '%s'", key ? key : "(null)");
   return ESS_EINVAL;
 }

@@ -626,7 +626,7 @@ int in_small_threads() {
   }
   return v;
 }
-extern "C" void ess_set_in_small_threads(int v) { g_in_small.store(v == 256 || v == 1024 ? v : 512, std::memory_order_relaxed); }
+void set_in_small_threads(int v) { g_in_small.store(v == 256 || v == 1024 ? v : 512, std::memory_order_relaxed); }
 
 extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C,
                                        int32_t hw, float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes,

@@ -13,8 +13,8 @@
  *   - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream); the library
  *     never synchronises, never calls hipSetDevice and keeps no mutable global state that can change a result (re-entrant).
  *     What it does keep: read-once constants (environment tuning variables, the device's compute-unit count, per-kernel LDS
- *     opt-ins) and ONE documented process-wide switch, ess_tuning_set("conv_wide", ..), which selects between kernels that
- *     produce bit-identical results;
+ *     opt-ins) and the documented process-wide switches of ess_tuning_set, which select between kernels of equal arithmetic
+ *     ("conv_wide": bit-identical results; "in_small_threads": equal up to the summation order of the norm statistics);
  *   - return value: 0 on success, negative ESS_E* otherwise; ess_last_error() gives a thread-local
  *     message.  Nothing throws across the ABI.
  */
@@ -360,7 +360,9 @@ int ess_label_confusion(const int64_t* pred_lbl, const int64_t* labels, int64_t*
 /* ---- tuning switches: process-wide kernel choices that never change a result (every setting runs the same arithmetic in the
  * same order).  "conv_wide": 0 = the 64 x 256-pixel-tile 3x3 kernel always, 1 = the wide-tile kernel where its round count wins
  * (default; environment ESS_CONV_WIDE), 2 = the wide-tile kernel wherever it applies.  ess_tuning_get also answers the read-only
- * key "device_cus" (the compute-unit count the dispatcher's round model uses: queried from the device, 256 on MI355X).  */
+ * key "device_cus" (the compute-unit count the dispatcher's round model uses: queried from the device, 256 on MI355X).
+ * "in_small_threads": 256 | 512 (default; environment ESS_IN_SMALL_THREADS) | 1024 -- threads of the fused single-plane InstanceNorm
+ * kernels on planes of at most 5120 pixels; the settings differ in the summation order of the statistics only (fp32 rounding).  */
 int ess_tuning_set(const char* key, int32_t value);
 int ess_tuning_get(const char* key, int32_t* value);
 

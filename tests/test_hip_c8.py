@@ -182,6 +182,38 @@ def test_instance_norm_c8(H, case):
     assert (dx - xr.grad).abs().max().item() < 2.0 ** -7 * xr.grad.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize('threads', [256, 512, 1024])
+@pytest.mark.parametrize('case', [(2, 64, 60, 80, 1, False), (1, 40, 24, 40, 0, True), (2, 16, 64, 80, 1, True)])
+def test_instance_norm_c8_small_plane_thread_counts(H, case, threads):
+    """The fused single-plane kernels in each of their thread counts (tuning switch in_small_threads: 256 x 20, 512 x 10 -- the default --
+    and 1024 x 5 vectors per thread; planes of <= 5120 pixels): each against the fp32 reference to the storage rounding; (64, 80) =
+    5120 vectors is the last plane the 512- and 1024-thread forms take, (24, 40) leaves most threads without a vector."""
+    N, C, Hh, W, relu, has_res = case
+    g = torch.Generator().manual_seed(sum(case) + threads)
+    x = bfr(torch.randn(N, C, Hh, W, generator=g) * 1.7 + 0.4)
+    res = bfr(torch.randn(N, C, Hh, W, generator=g)) if has_res else None
+    dy = bfr(torch.randn(N, C, Hh, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    ref = _in_ref(xr, res, relu)
+    ref.backward(dy)
+    prev = H.tuning_get('in_small_threads')
+    try:
+        H.tuning_set('in_small_threads', threads)
+        assert H.tuning_get('in_small_threads') == threads
+        y8, stats = H.instnorm_forward_c8(c8(H, x), C, None if res is None else c8(H, res), relu)
+        dx8 = H.instnorm_backward_c8(c8(H, x), C, c8(H, dy), stats, relu)
+        torch.cuda.synchronize()
+    finally:
+        H.tuning_set('in_small_threads', prev)
+    y, dx = un8(H, y8, C), un8(H, dx8, C)
+    assert (y - ref.detach()).abs().max().item() < 2.0 ** -7 * ref.detach().abs().max().item() + 1e-6
+    mean = x.mean(dim=(2, 3)).reshape(-1)
+    rstd = 1.0 / torch.sqrt(x.var(dim=(2, 3), unbiased=False) + 1e-5).reshape(-1)
+    assert (stats[:, 0].cpu() - mean).abs().max().item() < 1e-5
+    assert ((stats[:, 1].cpu() - rstd) / rstd).abs().max().item() < 1e-5
+    assert (dx - xr.grad).abs().max().item() < 2.0 ** -7 * xr.grad.abs().max().item() + 1e-6
+
+
 BN_CASES = [
     # N, C, H, W, relu, residual
     (2, 64, 12, 20, 1, False),

@@ -20,7 +20,7 @@ python tools/prof_summary.py $(find gpurun_out/prof_r5e -name "*results.db" | he
 python tools/prof_summary.py $(find gpurun_out/prof_r5g -name "*results.db" | head -1) > gpurun_out/r5_uda_bf16_graph_kernel_stats.txt; rm -rf gpurun_out/prof_r5g
 (cd /tmp && $T 420 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r5x -o r5x -- python $GRAFT_REPO_ROOT/bench.py --compute bf16x3 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-fp32-extra --no-roofline > /dev/null 2>&1)
 python tools/prof_summary.py $(find gpurun_out/prof_r5x -name "*results.db" | head -1) > gpurun_out/r5_uda_bf16x3_eager_kernel_stats.txt; rm -rf gpurun_out/prof_r5x
-ESS_PMC_TAG=r5 $T 900 python tools/pmc_r4.py gpurun_out/pmc_r5 > gpurun_out/r5_pmc.log 2>&1; rm -rf gpurun_out/pmc_r5
+ESS_PMC_TAG=r5 $T 900 python tools/pmc_r4.py $GRAFT_REPO_ROOT/gpurun_out/pmc_r5 > gpurun_out/r5_pmc.log 2>&1; rm -rf gpurun_out/pmc_r5
 for f in gpurun_out/r5_bench_*.json; do python -c "
 import json,sys
 try:
