@@ -292,8 +292,9 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   const dim3 grid((unsigned)(g.tiles_x * g.tiles_y * pl.n_cout_tiles * d->N));
   const int mb = pl.cout_tile / 32;
   const bool c8 = a.fmt0 == ESS_FMT_BF16_C8;
-  ESS_CHECK_ARG(!a.split || (((ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) || is_paired(d)) && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
-                "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised and the 5x5 tap-paired kernels with fp32 tensors");
+  const bool split_generic = d->ksize == 3 && d->stride == 2 && d->epilogue == ESS_EPI_LINEAR;  // (resolve_compute's third class)
+  ESS_CHECK_ARG(!a.split || (((ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) || is_paired(d) || split_generic) && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
+                "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised, the 5x5 tap-paired and the 3x3 / stride-2 generic kernels with fp32 tensors");
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
   if (!c8 && !a.residual && conv_bf16_stem_applies(d, pl)) {  // 1-channel 7x7 / stride 2 stem: K = the filter rows
     conv_bf16_launch_stem(d, pl, st, a);
@@ -350,8 +351,8 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   }
   const int key = d->ksize * 10 + d->stride;
   // (the generic tile kernel ignores a.split but would read a [tile][chunk][hi | lo] weight pack: refuse instead of computing garbage)
-  ESS_CHECK_ARG(!a.split, "conv(bf16): split operands reached the generic tile kernel (k%d s%d, %zu B of LDS for two stages)", d->ksize,
-                d->stride, 2 * (size_t)pl.lds_bytes);
+  ESS_CHECK_ARG(!a.split || split_generic, "conv(bf16): split operands reached the generic tile kernel (k%d s%d, %zu B of LDS for two stages)",
+                d->ksize, d->stride, 2 * (size_t)pl.lds_bytes);
   if (c8)
     ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && (key == 11 || key == 12 || key == 31 || key == 32),
                   "conv(bf16): the generic tile kernel stages BF16_C8 sources for 1x1 and 3x3 LINEAR convolutions only");

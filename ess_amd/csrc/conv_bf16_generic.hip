@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
     }
     return r;
   };
-  auto to_lds = [&](int ch, int cb, int k, const Pre& r) -> u32x4 {
+  // split operands (a.split, ESS_COMPUTE_BF16X3; fp32 sources only): the K loop runs over 3 * n_chunks VIRTUAL chunks -- chunk vc / 3
+  // staged as (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi) from ONE load of its fp32 values (conv_bf16_ws.hip has the same scheme)
+  auto to_lds = [&](int ch, int cb, int k, const Pre& r, bool x_lo = false) -> u32x4 {
     if constexpr (SRCBF) {
       const int c0 = ch * CK + cb * 8;
       const bool first = c0 < a.C0 || a.C1 == 0;
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
       v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
       return v;
     } else {
+      if (x_lo) {
+        float lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lo[j] = r.d.v[j] - (float)(__bf16)r.d.v[j];
+        return pack8(lo);
+      }
       return pack8(r.d.v);
     }
   };
@@ -137,7 +145,11 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
   // nothing waits on these loads before the matrix work has been issued
   Pre pre[CB8][KPC];
   u32x4 wpre[WPRE ? WV : 1];
-  const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ;
+  const bool split = !SRCBF && a.split;
+  const int nvc = split ? 3 * a.n_chunks : a.n_chunks;
+  const u32x4* wbase = (const u32x4*)a.wpk + (size_t)ct * a.n_chunks * WSZ * (split ? 2 : 1);
+  // weight slab of virtual chunk vc: [chunk][hi | lo] with split operands (lo for the third pass)
+  auto wslab = [&](int vc) { return split ? 2 * (vc / 3) + ((vc % 3) == 2 ? 1 : 0) : vc; };
 #pragma unroll
   for (int cb = 0; cb < CB8; ++cb)
 #pragma unroll
@@ -147,18 +159,20 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
     for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wbase[i < WSZ ? i : 0]; }
   }
 
-  for (int ch = 0; ch < a.n_chunks; ++ch) {
+  for (int vc = 0; vc < nvc; ++vc) {
+    const int ch = split ? vc / 3 : vc;
+    const bool x_lo = split && (vc - 3 * ch) == 1;
     __syncthreads();  // previous chunk's fragments have been read
 #pragma unroll
     for (int cb = 0; cb < CB8; ++cb)
 #pragma unroll
       for (int k = 0; k < KPC; ++k)
-        if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = to_lds(ch, cb, k, pre[cb][k]);
+        if (v_lds[k] >= 0) in_t[cb * a.plane + v_lds[k]] = to_lds(ch, cb, k, pre[cb][k], x_lo);
     if constexpr (WPRE) {
 #pragma unroll
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = wpre[it]; }
     } else {
-      const u32x4* wsrc = wbase + (size_t)ch * WSZ;
+      const u32x4* wsrc = wbase + (size_t)wslab(vc) * WSZ;
       u32x4 wv[WV];
 #pragma unroll
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wv[it] = wsrc[i < WSZ ? i : 0]; }
@@ -167,13 +181,15 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
     }
     __syncthreads();
     // prefetch the next chunk; the loads land while the matrix cores work on this one
-    if (ch + 1 < a.n_chunks) {
+    if (vc + 1 < nvc) {
+      if (!split || (vc + 1) % 3 == 0) {  // (split: the fp32 values in `pre` serve the three virtual chunks of their chunk)
 #pragma unroll
-      for (int cb = 0; cb < CB8; ++cb)
+        for (int cb = 0; cb < CB8; ++cb)
 #pragma unroll
-        for (int k = 0; k < KPC; ++k) pre[cb][k] = load_vec(ch + 1, cb, k);
+          for (int k = 0; k < KPC; ++k) pre[cb][k] = load_vec(split ? (vc + 1) / 3 : vc + 1, cb, k);
+      }
       if constexpr (WPRE) {
-        const u32x4* wsrc = wbase + (size_t)(ch + 1) * WSZ;
+        const u32x4* wsrc = wbase + (size_t)wslab(vc + 1) * WSZ;
 #pragma unroll
         for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; wpre[it] = wsrc[i < WSZ ? i : 0]; }
       }

@@ -1235,8 +1235,12 @@ inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
     const bool pair_on = pair_enabled();
     const bool ws = d->ksize == 3 && d->stride == 1 && ws_enabled();
     const bool pair = d->ksize == 5 && d->epilogue == ESS_EPI_LINEAR && d->C0 + d->C1 >= 8 && pair_on;
-    r.d.compute = (ws || pair) ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
-    r.split = ws || pair;
+    // 3x3 / stride 2 (the ResNet prefix's downsampling convolutions; LINEAR): the generic tile kernel with the same three virtual
+    // chunks (round 5).  1x1 convolutions stay exact fp32: they are bound by their fp32 tensors' bytes, three passes buy nothing
+    static const bool gen_on = [] { const char* e = getenv("ESS_X3_GENERIC"); return !(e && e[0] == '0'); }();
+    const bool gen = gen_on && d->ksize == 3 && d->stride == 2 && d->epilogue == ESS_EPI_LINEAR && d->C0 + d->C1 >= 16;
+    r.d.compute = (ws || pair || gen) ? ESS_COMPUTE_BF16 : ESS_COMPUTE_FP32;
+    r.split = ws || pair || gen;
   }
   return r;
 }

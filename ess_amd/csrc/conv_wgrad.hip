@@ -1095,7 +1095,7 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
       a.IH = w.IH; a.IW = w.IW; a.plx = w.plx; a.ci_tiles = w.ci_tiles; a.npairs = w.co_tiles * w.ci_tiles; a.nsplit = w.nsplit;
       a.dy_c8 = 1; a.ps = 1; a.pp = p; a.pq = q;
       bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
-      if ((rc = wgrad_c8_launch(bb, 9, 1, 2 * w.lds_bytes, grid, st))) return rc;
+        if ((rc = wgrad_c8_launch(bb, 9, 1, 2 * w.lds_bytes, grid, st))) return rc;
       TapMap tm{};
       tm.mapped = 1;
       for (int t = 0; t < 9; ++t) {

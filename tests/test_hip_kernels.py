@@ -711,6 +711,30 @@ def test_conv_split_operand_bf16x3(H, case):
     assert e3 < 2e-5 and e3 < e1 / 50, (e3, e1, e0)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 128, 24, 40, True), (1, 128, 256, 20, 32, False), (2, 24, 40, 18, 26, True)])
+def test_conv3x3_stride2_split_operand_bf16x3(H, case):
+    """3x3 / stride 2 / pad 1 (the ResNet prefix's downsampling convolutions) in the bf16x3 mode: the generic tile kernel over three
+    virtual chunks per chunk (round 5; exact fp32 before) -- fp64 math on the unrounded operands to the 2^-16 level, far under plain
+    bf16; the last case has ragged channel counts and odd output extents."""
+    N, Ci, Co, Hh, Ww, relu = case
+    g = torch.Generator().manual_seed(Ci + Co + Hh)
+    x = torch.randn(N, Ci, Hh, Ww, generator=g) + 6.0
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    errs = {}
+    for comp in (H.COMPUTE_BF16X3, H.COMPUTE_BF16, H.COMPUTE_FP32):
+        spec = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 3, 2, 1, act=H.ACT_RELU if relu else H.ACT_NONE, compute=comp)
+        out = torch.full((N, Co, spec.H_out, spec.W_out), float('nan'), device='cuda')
+        H.conv_forward(spec, dev(x), None, H.pack_weights(spec, dev(w)), None, H.pack_rows(spec, dev(b)), out=out)
+        errs[comp] = relerr(out.cpu().double(), ref)
+    e3, e1, e0 = errs[H.COMPUTE_BF16X3], errs[H.COMPUTE_BF16], errs[H.COMPUTE_FP32]
+    print(f'3x3 / stride 2: max rel err vs fp64 -- bf16x3 {e3:.2e}, bf16 {e1:.2e}, fp32 {e0:.2e}')
+    assert e3 < 2e-5 and e3 < e1 / 50, (e3, e1, e0)
+
+
 @pytest.mark.parametrize('case', [(2, 32, 64, 24, 40, 2), (1, 64, 32, 20, 36, 1), (2, 2, 32, 16, 24, 1)])
 def test_conv5x5_split_operand_bf16x3(H, case):
     """5x5 convolutions under ESS_COMPUTE_BF16X3: with at least one 8-channel chunk of input the tap-paired kernel runs them with
