@@ -106,6 +106,10 @@ __global__ void pack_weights_bf16_multi_kernel(const PackJobs jobs) {
   const int blk0 = k ? jobs.j[k - 1].blk_end : 0;
   const long long i = (long long)(blockIdx.x - blk0) * blockDim.x + threadIdx.x;
   if (i >= jb.total) return;
+  if (jb.w_kind == ESS_W_ROWS) {  // a bias vector, tile-padded with zeros (LINEAR: packed row = output channel)
+    ((float*)jb.out)[i] = i < jb.cout ? jb.w[i] : 0.f;
+    return;
+  }
   long long t = i;
   const int kp = t & 7; t >>= 3;
   const int col = t % jb.cot; t /= jb.cot;
@@ -131,8 +135,8 @@ int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds,
   for (int i = 0; i < count; ++i) {
     int rc = validate(&descs[i]);
     if (rc) return rc;
-    ESS_CHECK_ARG(is_bf16(&descs[i]) && descs[i].epilogue == ESS_EPI_LINEAR && !is_paired(&descs[i]) && w[i] && packed[i] &&
-                      (kinds[i] == ESS_W_CONV || kinds[i] == ESS_W_TRANSPOSED),
+    ESS_CHECK_ARG(is_bf16(&descs[i]) && descs[i].epilogue == ESS_EPI_LINEAR && w[i] && packed[i] &&
+                      ((!is_paired(&descs[i]) && (kinds[i] == ESS_W_CONV || kinds[i] == ESS_W_TRANSPOSED)) || kinds[i] == ESS_W_ROWS),
                   "pack_weights_multi: job %d is not a plain bf16 LINEAR layout", i);
   }
   for (int i0 = 0; i0 < count; i0 += PACK_JOBS) {
@@ -144,10 +148,11 @@ int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds,
       EssConvPlan pl;
       make_plan(d, &pl);
       PackJob& jb = jobs.j[k];
-      jb.w = w[i0 + k]; jb.out = (__bf16*)packed[i0 + k]; jb.total = pl.packed_elems;
+      jb.w = w[i0 + k]; jb.out = (__bf16*)packed[i0 + k];
+      jb.total = kinds[i0 + k] == ESS_W_ROWS ? pl.rows_padded : pl.packed_elems;
       jb.cot = pl.cout_tile; jb.ck = pl.ck; jb.n_chunks = pl.n_chunks; jb.ks = d->ksize; jb.cin = d->C0 + d->C1; jb.cout = d->C_out;
       jb.w_kind = kinds[i0 + k];
-      blocks += (int)ceil_div64(pl.packed_elems, 256);
+      blocks += (int)ceil_div64(jb.total, 256);
       jb.blk_end = blocks;
     }
     hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);

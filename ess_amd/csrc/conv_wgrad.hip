@@ -1016,8 +1016,8 @@ static SplitCopies split_copies(const EssConvDesc* d) {
 
 // the lo copies of a fused split-operand call, handed to the BF16_C8 3x3 launch of the SAME thread's nested entry (no public
 // signature changes; null outside that nested call)
-struct X3Lo { const void* x0; const void* x1; const void* dy; };
-static thread_local const X3Lo* g_x3 = nullptr;
+struct WgradPasses { int npass, bias_mask; const void* dy[3]; const void* x0[3]; const void* x1[3]; mutable bool used; };  // used: the nested launch took the passes
+static thread_local const WgradPasses* g_passes = nullptr;
 
 extern "C" size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d) {
   if (wvalidate(d)) return 0;
@@ -1060,11 +1060,15 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     // three accumulating launches of round 4 wrote and reduced the slabs three times: ESS_X3_WGRAD_FUSED=0 brings them back)
     static const bool fused = [] { const char* e = getenv("ESS_X3_WGRAD_FUSED"); return !(e && e[0] == '0'); }();
     if (fused) {
-      const X3Lo lo{x0l, d->C1 ? x1l : nullptr, dyl};
-      g_x3 = &lo;
-      rc = ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyh, dw, db, accumulate, workspace, slabs, stream);
-      g_x3 = nullptr;
-      return rc;
+      const void* x1h_ = d->C1 ? x1h : nullptr; const void* x1l_ = d->C1 ? x1l : nullptr;
+      const WgradPasses ps{3, 0b101, {dyh, dyh, dyl}, {x0h, x0l, x0h}, {x1h_, x1l_, x1h_}, false};
+      g_passes = &ps;
+      rc = ess_conv2d_wgrad(&dc, x0h, x1h_, dyh, dw, db, accumulate, workspace, slabs, stream);
+      g_passes = nullptr;
+      if (rc || ps.used) return rc;
+      // (the plan did not take the LDS-DMA kernel: the first set is done, the other two follow as accumulating launches)
+      if ((rc = ess_conv2d_wgrad(&dc, x0l, x1l_, dyh, dw, nullptr, 1, workspace, slabs, stream))) return rc;
+      return ess_conv2d_wgrad(&dc, x0h, x1h_, dyl, dw, db, 1, workspace, slabs, stream);
     }
     if ((rc = ess_conv2d_wgrad(&dc, x0h, d->C1 ? x1h : nullptr, dyh, dw, db, accumulate, workspace, slabs, stream))) return rc;
     if ((rc = ess_conv2d_wgrad(&dc, x0l, d->C1 ? x1l : nullptr, dyh, dw, nullptr, 1, workspace, slabs, stream))) return rc;
@@ -1142,9 +1146,11 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     WgradBArgs bb{};
     bb.w = a; bb.pyv = w.pyv; bb.pxv = w.pxv; bb.rv = w.rv;
     if (w.bf16_1x1) bb.w.pad = 1;  // tile geometry of the 3x3 kernel: the X tile starts one row / column before the output tile
-    if (g_x3) {
-      ESS_CHECK_ARG(!w.bf16_1x1 && d->stride == 1, "wgrad: the fused split-operand form exists for the 3x3 / stride-1 LDS-DMA kernel only");
-      bb.x3 = 1; bb.x0_lo = g_x3->x0; bb.x1_lo = g_x3->x1; bb.dy_lo = g_x3->dy;
+    if (g_passes) {
+      ESS_CHECK_ARG(!w.bf16_1x1 && d->stride == 1, "wgrad: several (dY, X) sets in one launch exist for the 3x3 / stride-1 LDS-DMA kernel only");
+      bb.npass = g_passes->npass; bb.bias_mask = g_passes->bias_mask;
+      g_passes->used = true;
+      for (int q = 0; q < 3; ++q) { bb.p_dy[q] = g_passes->dy[q]; bb.p_x0[q] = g_passes->x0[q]; bb.p_x1[q] = g_passes->x1[q]; }
     }
     if ((rc = wgrad_c8_launch(bb, w.bf16_1x1 ? 1 : 9, d->stride, 2 * w.lds_bytes, grid, st))) return rc;
   } else if (w.small1x1 && w.small1x1_mfma && ((((uintptr_t)a.src0) | ((uintptr_t)a.dy)) & 15) == 0) {
@@ -1194,4 +1200,34 @@ extern "C" int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0_, const v
     hipLaunchKernelGGL((wgrad_reduce_kernel<64, 1, 1024>), dim3((unsigned)(nblk_w + nblk_b), (unsigned)T), dim3(1024), 0, st, a.ws, a.ws_b, dw, db,
                        w.nsplit, T, CC, d->C_out, nblk_w, accumulate, TapMap{});
   return ess_launch_status("conv2d_wgrad_reduce");
+}
+
+
+// Two (or three) (dY, X) sets of the SAME convolution into one weight gradient: dw (+)= sum_s wgrad(X_s, dY_s).  BF16_C8 3x3 / stride 1
+// / pad 1 (the LDS-DMA kernel): ONE launch walks the tile list once per set -- one prologue, one slab set, one reduce --; any other
+// geometry: one accumulating call per set.  The decoder's two weight-gradient passes of a UDA step use it (functional.py, deferred
+// weight gradients).
+extern "C" int ess_conv2d_wgrad_sets(const EssConvDesc* d, int32_t n_sets, const void* const* src0, const void* const* src1,
+                                     const void* const* dy, float* dw, float* db, int32_t accumulate, void* workspace,
+                                     size_t workspace_bytes, ess_stream_t stream) {
+  ESS_CHECK_ARG(d && src0 && dy && n_sets >= 1 && n_sets <= 3, "wgrad_sets: 1 to 3 sets");
+  for (int q = 0; q < n_sets; ++q) ESS_CHECK_ARG(src0[q] && dy[q] && (d->C1 == 0 || (src1 && src1[q])), "wgrad_sets: null tensor in set %d", q);
+  const bool one_launch = n_sets > 1 && d->compute == ESS_COMPUTE_BF16 && d->fmt0 == ESS_FMT_BF16_C8 && d->fmt_out == ESS_FMT_BF16_C8 &&
+                          d->ksize == 3 && d->stride == 1 && d->pad == 1 && !g_passes;
+  if (one_launch) {
+    WgradPasses ps{n_sets, (1 << n_sets) - 1, {}, {}, {}, false};
+    for (int q = 0; q < n_sets; ++q) { ps.dy[q] = dy[q]; ps.x0[q] = src0[q]; ps.x1[q] = d->C1 ? src1[q] : nullptr; }
+    g_passes = &ps;
+    int rc = ess_conv2d_wgrad(d, src0[0], d->C1 ? src1[0] : nullptr, dy[0], dw, db, accumulate, workspace, workspace_bytes, stream);
+    g_passes = nullptr;
+    if (rc || ps.used) return rc;
+    for (int q = 1; q < n_sets; ++q)  // (the plan did not take the LDS-DMA kernel: set 0 is done, the others accumulate)
+      if ((rc = ess_conv2d_wgrad(d, src0[q], d->C1 ? src1[q] : nullptr, dy[q], dw, db, 1, workspace, workspace_bytes, stream))) return rc;
+    return ESS_OK;
+  }
+  for (int q = 0; q < n_sets; ++q) {
+    const int rc = ess_conv2d_wgrad(d, src0[q], d->C1 ? src1[q] : nullptr, dy[q], dw, db, q ? 1 : accumulate, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return ESS_OK;
 }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void wgrad_c8_kernel(const WgradBArgs b, int s
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
   const bool want_b0 = a.ws_b && cit == 0 && ib == 0;
-  bool want_b = want_b0;  // (x3: dY_hi is contracted twice -- passes 0 and 1 --, the bias gradient takes it once: off during pass 1)
+  bool want_b = want_b0;  // (several passes: the bias gradient takes the passes of bias_mask -- split operands contract dY_hi twice)
 
   // K loop over this workgroup's pixel tiles: 8 k-steps of 16 pixels x TAPS taps per tile, two LDS stages; the quads of tile
   // t+1 (loads issued behind the first k-step) are transposed and written into the other stage on k-steps 4-7
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   const int cot = pair / a.ci_tiles, cit = pair - cot * a.ci_tiles;
   const int Cin = a.C0 + a.C1;
   const unsigned lds0 = (unsigned)(size_t)smem_dma;
-  const int ntt = b.x3 ? 3 * a.ntiles : a.ntiles;  // (split operands: three passes over the tile list, see WgradBArgs)
+  const int ntt = b.npass > 1 ? b.npass * a.ntiles : a.ntiles;  // (several (dY, X) sets: npass passes over the tile list, see WgradBArgs)
   int ntl = 0;  // this workgroup's tiles: split, split + nsplit, ...
   if (split < ntt) ntl = (ntt - 1 - split) / nsplit + 1;
 
@@ -363,11 +363,17 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     }
     const int tpi = a.tiles_x * a.tiles_y;
     auto issue = [&](int tile, int st) {
-      int pass = 0;
-      if (b.x3) { pass = tile / a.ntiles; tile -= pass * a.ntiles; }  // (wave-uniform)
-      const char* p_dy = (const char*)(pass == 2 ? b.dy_lo : (const void*)a.dy);
-      const char* p_x0 = (const char*)(pass == 1 ? b.x0_lo : (const void*)a.src0);
-      const char* p_x1 = (const char*)(a.C1 ? (pass == 1 ? b.x1_lo : (const void*)a.src1) : (const void*)p_x0);
+      const char* p_dy = (const char*)a.dy;
+      const char* p_x0 = (const char*)a.src0;
+      const char* p_x1 = (const char*)a.src1;
+      if (b.npass > 1) {  // (wave-uniform: the pass of this tile picks its tensors)
+        const int pass = tile / a.ntiles;
+        tile -= pass * a.ntiles;
+        p_dy = (const char*)(pass == 0 ? b.p_dy[0] : pass == 1 ? b.p_dy[1] : b.p_dy[2]);
+        p_x0 = (const char*)(pass == 0 ? b.p_x0[0] : pass == 1 ? b.p_x0[1] : b.p_x0[2]);
+        p_x1 = (const char*)(pass == 0 ? b.p_x1[0] : pass == 1 ? b.p_x1[1] : b.p_x1[2]);
+      }
+      if (!a.C1) p_x1 = p_x0;
       const int n = tile / tpi;
       const int tr = tile - n * tpi;
       const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
   const bool want_b0 = a.ws_b && cit == 0 && ib == 0;
-  bool want_b = want_b0;  // (x3: dY_hi is contracted twice -- passes 0 and 1 --, the bias gradient takes it once: off during pass 1)
+  bool want_b = want_b0;  // (several passes: the bias gradient takes the passes of bias_mask -- split operands contract dY_hi twice)
   const int g = lane >> 4, i16 = lane & 15;
   const unsigned pix_off = (unsigned)((8 * (g >> 1) + (i16 >> 2)) * 16 + (i16 & 1) * 8);
   const unsigned pl_sel = (unsigned)(2 * (g & 1) + ((i16 & 3) >> 1));
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   }
   for (int k = 0; k + 1 < ntl; ++k) {  // every tile but the last
     if (k < 30) ESS_TR(3 + k);
-    if (b.x3) want_b = want_b0 && (split + k * nsplit) / a.ntiles != 1;
+    if (b.npass > 1) want_b = want_b0 && ((b.bias_mask >> ((split + k * nsplit) / a.ntiles)) & 1);
     const unsigned nst = (unsigned)((k + 1) % NST) * G::STAGE;
     a_next = lds0 + nst + a_lane;
     x_next = lds0 + nst + x_lane;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(512) void wgrad_c8_ws_kernel(const WgradBArgs b) {
   }
   if (ntl > 0) {
     if (ntl - 1 < 30) ESS_TR(3 + ntl - 1);
-    if (b.x3) want_b = want_b0 && (split + (ntl - 1) * nsplit) / a.ntiles != 1;
+    if (b.npass > 1) want_b = want_b0 && ((b.bias_mask >> ((split + (ntl - 1) * nsplit) / a.ntiles)) & 1);
     static_for<0, 24>([&](auto uc) { unit(uc, No{}); });
   }
   ESS_TR(34);

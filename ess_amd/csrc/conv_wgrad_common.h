@@ -62,12 +62,16 @@ struct WgradBArgs {
   int pyv, pxv, rv;  // per-channel pitches (16-B vectors) of the dY / X tiles, vectors per X row
   int split;         // split-operand bf16 (ESS_COMPUTE_BF16X3, fp32-staged kernels): every pixel tile is contracted three times --
                      // (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) -- into the same accumulators
-  // split operands on the BF16_C8 LDS-DMA kernel (round 5): x3 != 0 -> the tile list is walked three times, pass p = tile / ntiles
-  // reading (dY, X) = (w.dy, w.src*), (w.dy, x*_lo), (dy_lo, w.src*) -- one launch, one slab set and one reduce instead of three
-  int x3;
-  const void* x0_lo;
-  const void* x1_lo;
-  const void* dy_lo;
+  // several (dY, X) sets through ONE launch of the BF16_C8 LDS-DMA kernel (round 5): npass > 1 -> the tile list is walked npass
+  // times, pass p = tile / ntiles reading (p_dy[p], p_x0[p], p_x1[p]) into the same accumulators -- one prologue, one slab set and
+  // one reduce instead of npass.  Users: split operands (three passes: (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi); bias_mask 0b101:
+  // dY_hi is contracted twice, the bias gradient takes it once) and the two weight-gradient passes a decoder layer sees per UDA
+  // step (ess_conv2d_wgrad_sets; bias_mask 0b11).  npass <= 1: w.dy / w.src0 / w.src1.
+  int npass;
+  int bias_mask;
+  const void* p_dy[3];
+  const void* p_x0[3];
+  const void* p_x1[3];
 };
 
 // conv_wgrad_c8.hip: launchers (the caller has validated the geometry and sized the workspace)

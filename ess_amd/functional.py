@@ -36,6 +36,43 @@ def _direct(p):
     return DIRECT_GRAD_ACCUM and getattr(p, '_ess_direct_grad', False) and p.is_leaf and p.grad is not None and p.grad.is_contiguous()
 
 
+# Deferred weight gradients (round 5).  A weight that receives TWO weight-gradient passes per step (the decoder in the UDA step: the
+# task loss on the image latents, then the cycle / task terms on the event latents) pays the split-K prologue, slab write and reduce
+# twice.  While WGRAD_DEFER is a dict, Conv2dFn.backward stashes the (x0, x1, dy) of a direct BF16_C8 3x3 / stride-1 weight gradient
+# there instead of launching it; the next backward pass through the same weight launches BOTH sets as one call
+# (hip.conv_wgrad_sets: one launch, one slab set, one reduce); flush_deferred_wgrads() launches whatever found no partner.  The
+# trainer opens the window before the first backward pass and closes it behind the last one (ESSModel._train_step_eager).
+WGRAD_DEFER = None
+WGRAD_STASHING = False  # stash only while the FIRST pass runs; later passes match against the dict (or launch on their own)
+
+
+def begin_deferred_wgrads():
+    global WGRAD_DEFER, WGRAD_STASHING
+    if os.environ.get('ESS_WGRAD_DEFER', '1')[:1] != '0':
+        WGRAD_DEFER, WGRAD_STASHING = {}, True
+
+
+def stop_stashing_wgrads():
+    """behind the first pass: from here on a weight gradient either finds its stashed partner or is launched at once"""
+    global WGRAD_STASHING
+    WGRAD_STASHING = False
+
+
+def flush_deferred_wgrads(close=True):
+    """launch the stashed weight gradients that found no second pass; close=True also ends the window"""
+    global WGRAD_DEFER, WGRAD_STASHING
+    pend = WGRAD_DEFER
+    if close:
+        WGRAD_DEFER, WGRAD_STASHING = None, False
+    if not pend:
+        return
+    for (spec, x0, x1, dy, weight, db_t) in list(pend.values()):
+        hip.conv_wgrad(spec, x0, x1, dy, weight.grad, db_t, accumulate=True)
+        if GRAD_READY_HOOK is not None:
+            GRAD_READY_HOOK(weight)
+    pend.clear()
+
+
 # Set by training.distributed.GradAllReducer.arm(): called with a parameter as soon as the launch that completes its gradient
 # in the running backward pass has been issued (bucketed gradient all-reduce overlapped with the rest of the backward).
 GRAD_READY_HOOK = None
@@ -67,6 +104,7 @@ def packed_rows(spec, v):
     pr = ent[2].get(key)
     if pr is None:
         pr = ent[2][key] = hip.pack_rows(spec, v.detach())
+        pr.ess_spec = spec  # (repack() refreshes LINEAR bias rows in place through the multi-tensor launch)
     return pr
 
 
@@ -108,8 +146,15 @@ def repack(params):
             _pack_cache.pop(id(p), None)
             continue
         for key in list(ent[2]):
-            if key[-1] == 'rows':  # bias rows: cheap, re-packed lazily
-                del ent[2][key]
+            if key[-1] == 'rows':
+                # bias rows of a plain bf16 convolution ride in the same launch (round 5: 21 pack_rows launches per step otherwise);
+                # any other row layout is dropped and re-packed lazily
+                sp = getattr(ent[2][key], 'ess_spec', None)
+                if sp is not None and p.dim() == 1 and sp.key[11] == hip.EPI_LINEAR and sp.key[15] == hip.COMPUTE_BF16 and \
+                        os.environ.get('ESS_REPACK_ROWS', '1')[:1] != '0':
+                    jobs.append((sp, hip.W_ROWS, p.detach(), ent[2][key]))
+                else:
+                    del ent[2][key]
                 continue
             skey, kind = key
             k, epi, compute = skey[8], skey[11], skey[15]
@@ -348,10 +393,23 @@ class Conv2dFn(torch.autograd.Function):
             if s2_1x1 and not c8in:
                 sp1 = hip.conv_spec(N, Hv // 2, Wv // 2, C0, 0, Cout, 1, 1, 0)
                 hip.conv_wgrad(sp1, x0[:, :, ::2, ::2].contiguous(), None, dy, weight.grad, db_t, accumulate=True)
+                done = True
             else:  # (BF16_C8: the 1x1 kernel samples the stride-2 grid itself)
-                hip.conv_wgrad(spec, x0, x1, dy, weight.grad, db_t, accumulate=True)
+                done = True
+                defer = WGRAD_DEFER is not None and c8in and hip.is_c8(dy) and k == 3 and s == 1 and p == 1
+                held = WGRAD_DEFER.pop(id(weight), None) if defer else None
+                if held is not None and held[0].key == spec.key and held[4] is weight:
+                    # the second pass through this weight: both sets in one launch
+                    hip.conv_wgrad_sets(spec, [(held[1], held[2], held[3]), (x0, x1, dy)], weight.grad, db_t, accumulate=True)
+                elif defer and held is None and WGRAD_STASHING:
+                    WGRAD_DEFER[id(weight)] = (spec, x0, x1, dy, weight, db_t)  # (launched with the next pass, or by the flush)
+                    done = False
+                else:
+                    if held is not None:  # (another shape went through this weight first: no common launch)
+                        hip.conv_wgrad(held[0], held[1], held[2], held[3], weight.grad, held[5], accumulate=True)
+                    hip.conv_wgrad(spec, x0, x1, dy, weight.grad, db_t, accumulate=True)
             dw = db = None
-            if GRAD_READY_HOOK is not None:
+            if done and GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK(weight)
         elif needw or needb:
             dw = torch.empty_like(weight)

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libess_hip.so')
 SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
-W_CONV, W_TRANSPOSED = 0, 1
+W_CONV, W_TRANSPOSED, W_ROWS = 0, 1, 2
 COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
 
@@ -41,7 +41,7 @@ def get_compute():
 
 EXPORTS = [
     'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',
-    'ess_conv2d_forward', 'ess_to_bf16_c8', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_norm_workspace', 'ess_instnorm_forward',
+    'ess_conv2d_forward', 'ess_to_bf16_c8', 'ess_conv2d_wgrad_workspace', 'ess_conv2d_wgrad', 'ess_conv2d_wgrad_sets', 'ess_norm_workspace', 'ess_instnorm_forward',
     'ess_instnorm_backward', 'ess_batchnorm_train_forward', 'ess_batchnorm_train_backward',
     'ess_upsample_bilinear2x_add', 'ess_sumpool2x2', 'ess_add', 'ess_event_normalize', 'ess_task_loss_workspace',
     'ess_task_loss', 'ess_sym_js_loss', 'ess_l1_loss', 'ess_radam_step', 'ess_argmax_confusion', 'ess_resize_nearest', 'ess_conv2d_pack_weights_multi',
@@ -101,6 +101,7 @@ def lib():
             'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P, P],
             'ess_to_bf16_c8': [P, P, I, I, I, I, P],
             'ess_conv2d_wgrad': [D, P, P, P, P, P, c_int, P, c_size_t, P],
+            'ess_conv2d_wgrad_sets': [D, I, P, P, P, P, P, c_int, P, c_size_t, P],
             'ess_instnorm_forward': [P, P, P, P, I, I, F, I, P, c_size_t, P],
             'ess_instnorm_backward': [P, P, P, P, I, I, I, P, c_size_t, P],
             'ess_batchnorm_train_forward': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, P, c_size_t, P],
@@ -229,8 +230,9 @@ def pack_weights(spec, w, w2=None, kind=W_CONV):
 
 
 def pack_weights_multi(jobs):
-    """Re-pack many weights in one launch.  jobs: list of (spec, kind, weight, packed buffer).  Raises EssHipError when a
-    job is not a plain bf16 LINEAR layout (nothing is launched then)."""
+    """Re-pack many weights in one launch.  jobs: list of (spec, kind, weight, packed buffer); kind W_ROWS: `weight` is a bias vector
+    and the buffer the fp32 one pack_rows() returned.  Raises EssHipError when a job is not a plain bf16 LINEAR layout (nothing is
+    launched then)."""
     n = len(jobs)
     descs = (EssConvDesc * n)(*[j[0].desc for j in jobs])
     kinds = (c_int32 * n)(*[int(j[1]) for j in jobs])
@@ -360,6 +362,30 @@ def conv_wgrad(spec, src0, src1, dy, dw, db=None, accumulate=False):
     ws = workspace(nbytes, dy.device, 'wgrad')
     _check(lib().ess_conv2d_wgrad(byref(desc), ptr(src0, sdt), ptr(src1, sdt), ptr(dy, ddt), ptr(dw), ptr(db), int(accumulate),
                                   c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_conv2d_wgrad')
+
+
+def conv_wgrad_sets(spec, sets, dw, db=None, accumulate=False):
+    """dw (+)= sum over `sets` = [(src0, src1, dy), ...] (1..3 sets of the same convolution, same formats): BF16_C8 3x3 / stride-1 layers
+    take ONE launch for all sets (ess_conv2d_wgrad_sets), anything else one accumulating launch per set."""
+    src0, _, dy = sets[0]
+    sfmt = FMT_BF16_C8 if is_c8(src0) else FMT_F32_NCHW
+    dfmt = FMT_BF16_C8 if is_c8(dy) else FMT_F32_NCHW
+    desc = spec.desc if (sfmt, dfmt) == (FMT_F32_NCHW, FMT_F32_NCHW) else spec.desc_fmt(sfmt, dfmt)
+    sdt = torch.bfloat16 if sfmt == FMT_BF16_C8 else torch.float32
+    ddt = torch.bfloat16 if dfmt == FMT_BF16_C8 else torch.float32
+    for (a0, a1, g) in sets:
+        if is_c8(a0) != is_c8(src0) or is_c8(g) != is_c8(dy) or a0.shape != src0.shape or g.shape != dy.shape:
+            raise EssHipError('conv_wgrad_sets: the sets must agree in shapes and storage formats')
+    nbytes = lib().ess_conv2d_wgrad_workspace(byref(desc))
+    if nbytes == 0:
+        raise EssHipError('ess_conv2d_wgrad_workspace: ' + lib().ess_last_error().decode())
+    ws = workspace(nbytes, dy.device, 'wgrad')
+    n = len(sets)
+    a0s = (c_void_p * n)(*[ptr(t[0], sdt).value for t in sets])
+    a1s = (c_void_p * n)(*[(ptr(t[1], sdt).value if t[1] is not None else None) for t in sets])
+    gs = (c_void_p * n)(*[ptr(t[2], ddt).value for t in sets])
+    _check(lib().ess_conv2d_wgrad_sets(byref(desc), n, a0s, a1s, gs, ptr(dw), ptr(db), int(accumulate), c_void_p(ws.data_ptr()),
+                                       c_size_t(ws.numel()), stream()), 'ess_conv2d_wgrad_sets')
 
 
 # ------------------------------------------------------------------------------------------ norms

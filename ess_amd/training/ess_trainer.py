@@ -144,7 +144,15 @@ class ESSModel(base_trainer.BaseTrainer):
         t_final_loss, t_losses, t_outputs = self.img_train_step(input_batch)
         # DSEC: the image latents were detached, so this reaches the decoder only; DDD17: decoder + image encoder
         # (unit_backward == .backward() of the sum of the weighted terms, minus one gradient-times-scalar pass per term)
+        # DSEC: the decoder's weights see a second weight-gradient pass further down (the task cycle terms on the event latents): this
+        # pass only stashes its (x, dy) pairs, the second one launches both sets together (functional.WGRAD_DEFER: one split-K
+        # prologue, slab set and reduce per layer and step instead of two)
+        defer_w = self.settings.dataset_name_b == 'DSEC_events'
+        if defer_w:
+            Fn.begin_deferred_wgrads()
         Fn.unit_backward([t_final_loss])
+        if defer_w:
+            Fn.stop_stashing_wgrads()
         final_loss = t_final_loss.detach()
         losses.update(t_losses)
         outputs.update(t_outputs)
@@ -159,10 +167,12 @@ class ESSModel(base_trainer.BaseTrainer):
             if fork:  # (the weight-gradient kernels add into .grad themselves: no AccumulateGrad leaf tells the engine to join B)
                 torch.cuda.current_stream().wait_stream(self._side_stream)
             self._deferred_fork = fork
+            # (the stashed decoder weight gradients of the image pass wait for _finish_deferred_backward)
         elif fork:
             # one backward over both sets of terms: the engine enqueues the image-encoder chain (recorded on B) and the decoder
             # chain (recorded on A) on their own streams and joins them at the end; they write disjoint gradient buffers
             Fn.unit_backward(self._e_terms + self._t_terms)
+            Fn.flush_deferred_wgrads()
             # (the weight-gradient kernels add into .grad themselves: no AccumulateGrad leaf tells the engine to join B)
             torch.cuda.current_stream().wait_stream(self._side_stream)
         else:
@@ -172,6 +182,7 @@ class ESSModel(base_trainer.BaseTrainer):
                 self.grad_reducer.launch(opt_front.flat_grad)  # overlaps with the task backward below
                 self.grad_reducer.arm(opt_back, n_buckets=3)  # decoder gradients: bucketed, reduced from inside the backward below
             Fn.unit_backward(self._t_terms)  # decoder only
+            Fn.flush_deferred_wgrads()  # (stashed weight gradients that found no second pass; reports them to the bucket hook)
             if overlap:
                 self.grad_reducer.flush()
         final_loss = hip.sum_scalars([final_loss, e_loss, t_loss])  # (one library launch: the reference adds with one torch op per term)
@@ -188,6 +199,7 @@ class ESSModel(base_trainer.BaseTrainer):
     def _finish_deferred_backward(self):
         """Second half of a step recorded with defer_task_backward: the decoder's task backward (decoder gradients only)."""
         Fn.unit_backward(self._t_terms)
+        Fn.flush_deferred_wgrads()
         if getattr(self, '_deferred_fork', False):
             torch.cuda.current_stream().wait_stream(self._side_stream)
 

@@ -65,8 +65,11 @@ enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3,
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
-  ESS_W_TRANSPOSED = 1   /* weight [C_in][C_out][k][k] used spatially flipped: nn.ConvTranspose2d
+  ESS_W_TRANSPOSED = 1,  /* weight [C_in][C_out][k][k] used spatially flipped: nn.ConvTranspose2d
                             forward, or the data-gradient of a Conv2d (pass its weight)              */
+  ESS_W_ROWS = 2         /* ess_conv2d_pack_weights_multi only: the job's `w` is a per-output-channel vector (a bias,
+                            C_out floats) and `packed` the float buffer of ess_conv2d_pack_rows (fill 0) -- the
+                            biases of the trainable convolutions ride in the weights' re-pack launch       */
 };
 
 /* One 2-D convolution over the channel-concatenation of up to two sources.
@@ -126,7 +129,7 @@ int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
 int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const float* w, const float* w2,
                             void* packed, ess_stream_t stream);
 /* ess_conv2d_pack_weights for `count` tensors in one launch (the re-pack of every trainable convolution after an optimiser
- * step).  bf16 compute, LINEAR epilogue, 1x1 / 3x3 / 7x7 layouts only; anything else is refused and nothing is launched.
+ * step).  bf16 compute, LINEAR epilogue, 1x1 / 3x3 / 7x7 layouts (and ESS_W_ROWS jobs) only; anything else is refused and nothing is launched.
  * descs / w_kinds / w / packed: host arrays of `count` entries.                                                      */
 int ess_conv2d_pack_weights_multi(const EssConvDesc* descs, const int32_t* w_kinds, const float* const* w,
                                   void* const* packed, int32_t count, ess_stream_t stream);
@@ -169,6 +172,12 @@ size_t ess_conv2d_wgrad_workspace(const EssConvDesc* d);
 int ess_conv2d_wgrad(const EssConvDesc* d, const void* src0, const void* src1, const void* dy,
                      float* dw, float* db, int accumulate, void* workspace, size_t workspace_bytes,
                      ess_stream_t stream);
+/* The weight gradient over n_sets (1..3) tensor sets of the same convolution: dw (+)= sum_s wgrad(src0[s], src1[s], dy[s]).  BF16_C8
+ * 3x3 / stride 1 / pad 1: one launch for all sets (one split-K slab set, one reduce); otherwise one accumulating call per set.
+ * No reference counterpart (autograd accumulates per backward pass): the decoder's two weight-gradient passes of a UDA step.       */
+int ess_conv2d_wgrad_sets(const EssConvDesc* d, int32_t n_sets, const void* const* src0, const void* const* src1,
+                          const void* const* dy, float* dw, float* db, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, ess_stream_t stream);
 
 /* InstanceNorm2d(affine=False, eps) (+residual)(+ReLU): models/style_networks.py:163-164,180-182,192.
  * relu = 0: y = IN(x) + residual; 1: y = relu(IN(x)) + residual; 2 (forward only): y = relu(IN(x) +

@@ -372,6 +372,48 @@ def test_conv_wgrad_c8(H, case):
         H.set_compute('fp32')
 
 
+@pytest.mark.parametrize('case', [(2, 64, 0, 64, 24, 40, 3, 1, 1, 0, 0, True, 2), (2, 128, 128, 128, 12, 20, 3, 1, 1, 1, 0, True, 2),
+                                  (1, 24, 0, 40, 17, 30, 3, 1, 1, 0, 0, True, 3), (2, 128, 0, 128, 12, 20, 1, 1, 0, 0, 0, False, 2)])
+def test_conv_wgrad_sets_c8(H, case):
+    """ess_conv2d_wgrad_sets: dW (+)= sum over 2 / 3 (x, dy) sets of the same convolution -- ONE launch of the LDS-DMA kernel for
+    BF16_C8 3x3 / stride-1 layers (the decoder's two weight-gradient passes per UDA step), one accumulating launch per set otherwise
+    (the 1x1 case) -- against the sum of the per-set torch gradients; bias gradient from every set; accumulate form."""
+    N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, bias, nsets = case
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(abs(hash(case)) % 1000)
+        d0, d1 = (2 if m0 else 1), (2 if m1 else 1)
+        spec = H.conv_spec(N, Hv, Wv, C0, C1, Cout, k, s, p, m0, m1)
+        sets, wsum, bsum = [], 0, 0
+        for _ in range(nsets):
+            x0 = bfr(torch.randn(N, C0, Hv // d0, Wv // d0, generator=g))
+            x1 = bfr(torch.randn(N, C1, Hv // d1, Wv // d1, generator=g)) if C1 else None
+            dy = bfr(torch.randn(N, Cout, spec.H_out, spec.W_out, generator=g))
+            xin = (_up(x0, m0) if x1 is None else torch.cat([_up(x0, m0), _up(x1, m1)], 1)).requires_grad_(True)
+            w = torch.zeros(Cout, C0 + C1, k, k, requires_grad=True)
+            b = torch.zeros(Cout, requires_grad=True)
+            F.conv2d(xin, w, b, s, p).backward(dy)
+            wsum, bsum = wsum + w.grad, bsum + b.grad
+            sets.append((c8(H, x0), None if x1 is None else c8(H, x1), c8(H, dy)))
+        dw = torch.full((Cout, C0 + C1, k, k), float('nan'), device='cuda')
+        db = torch.full((Cout,), float('nan'), device='cuda') if bias else None
+        H.conv_wgrad_sets(spec, sets, dw, db)
+        torch.cuda.synchronize()
+        assert ((dw.cpu() - wsum).abs().max() / wsum.abs().max()).item() < 2e-5
+        if bias:
+            assert ((db.cpu() - bsum).abs().max() / bsum.abs().max()).item() < 2e-5
+        dw2 = dw.clone()
+        H.conv_wgrad_sets(spec, sets, dw2, None, accumulate=True)
+        assert ((dw2.cpu() - 2 * wsum).abs().max() / wsum.abs().max()).item() < 4e-5
+        # one set through the same entry == the plain call, bit for bit
+        dwa, dwb = torch.empty_like(dw), torch.empty_like(dw)
+        H.conv_wgrad_sets(spec, sets[:1], dwa, None)
+        H.conv_wgrad(spec, sets[0][0], sets[0][1], sets[0][2], dwb, None)
+        assert torch.equal(dwa, dwb)
+    finally:
+        H.set_compute('fp32')
+
+
 def test_conv_wgrad_head_and_stem_c8(H):
     H.set_compute('bf16')
     try:
