@@ -203,7 +203,7 @@ def roofline_blocks(args, device):
         return hip.to_bf16_c8(t) if bf16 else t
 
     # ---- plain 3x3 convolutions (forward) and their weight gradients
-    conv_ms = conv_fl = wg_ms = wg_fl = 0.0
+    conv_ms = conv_fl = wg_ms = wg_fl = wg2_ms = 0.0
     per_layer = []
     for (C0, C1, Cout, Hv, Wv, m0, cnt) in decoder_conv3x3_layers(args):
         spec = hip.conv_spec(B, Hv, Wv, C0, C1, Cout, 3, 1, 1, hip.SRC_NEAREST_UP2 if m0 else hip.SRC_DIRECT, hip.SRC_DIRECT)
@@ -219,9 +219,13 @@ def roofline_blocks(args, device):
         dy = act(Cout, Hv, Wv)
         dw, db = torch.empty_like(w), torch.empty_like(bias)
         wms = _timed(ev, stream, lambda: hip.conv_wgrad(spec, x0, x1, dy, dw, db), reps=10, warm=2)
+        # the form the UDA step launches for the decoder since round 5: both weight-gradient passes of a layer in ONE launch
+        # (ess_conv2d_wgrad_sets: two (x, dy) sets, one slab set, one reduce) -- twice the FLOPs per launch
+        w2ms = _timed(ev, stream, lambda: hip.conv_wgrad_sets(spec, [(x0, x1, dy), (x0, x1, dy)], dw, db), reps=10, warm=2) if bf16 else 2 * wms
         per_layer.append({'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''), 'count': cnt, 'conv_ms': round(ms, 4),
-                          'conv_tflops': round(fl / ms / 1e9, 1), 'wgrad_ms': round(wms, 4), 'wgrad_tflops': round(fl / wms / 1e9, 1)})
-        conv_ms += cnt * ms; conv_fl += cnt * fl; wg_ms += cnt * wms; wg_fl += cnt * fl
+                          'conv_tflops': round(fl / ms / 1e9, 1), 'wgrad_ms': round(wms, 4), 'wgrad_tflops': round(fl / wms / 1e9, 1),
+                          'wgrad_two_sets_ms': round(w2ms, 4), 'wgrad_two_sets_tflops': round(2 * fl / w2ms / 1e9, 1)})
+        conv_ms += cnt * ms; conv_fl += cnt * fl; wg_ms += cnt * wms; wg_fl += cnt * fl; wg2_ms += cnt * w2ms
         del x0, x1, out, dy
     # ---- fused ConvLSTM step (gate conv + epilogue), three encoder levels of one time step
     gate_ms = gate_fl = 0.0
@@ -295,7 +299,11 @@ def roofline_blocks(args, device):
                                  **_pmc_summary(t_gru), 'per_level': gru_levels, 'traffic': t_gru},
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
-                          **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg}},
+                          **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg,
+                          'two_sets_per_launch': {'ms_per_launch_set': round(wg2_ms, 4), 'achieved': round(2 * wg_fl / wg2_ms / 1e9, 1),
+                                                  'frac': round(2 * wg_fl / wg2_ms / 1e9 / peak, 4),
+                                                  'note': 'the decoder layers as the UDA step launches them: both weight-gradient passes of a step '
+                                                          'in one launch (functional.WGRAD_DEFER); `achieved` / `frac` above stay the one-set launch of the earlier rounds'}}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
                     '; HIP events on the launch stream, inside this process after the timed steps; launch sets repeated back to back, i.e. '
                     'at the sustained-matrix-load clock (the same kernels inside the step, between HBM-bound launches, run 5-20 % faster: '
