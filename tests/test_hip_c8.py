@@ -598,3 +598,50 @@ def test_f16_c8_pre_norm_forms(H, case):
             assert all(torch.equal(a, b2) for a, b2 in zip(*outs))
     finally:
         H.set_compute('fp32')
+
+
+def test_deferred_weight_gradients_two_passes(H):
+    """functional.WGRAD_DEFER: a conv layer that sees two backward passes inside the window gets ONE weight-gradient launch for both
+    (x, dy) sets; a layer with a single pass is launched by the flush; outside the window nothing is stashed.  The gradients equal the
+    plain two-launch accumulation to fp32 summation order; data-gradients are untouched (bit-identical)."""
+    from ess_amd import functional as Fn
+    from ess_amd.utils import radam
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(11)
+        w1 = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda())
+        b1 = torch.nn.Parameter(torch.randn(64, generator=g).cuda())
+        w2 = torch.nn.Parameter((torch.randn(32, 64, 3, 3, generator=g) * 0.05).cuda())
+        opt = radam.RAdam([w1, b1, w2], lr=1e-3)  # (direct accumulation into the optimiser's flat gradient buffer)
+        xs = [c8(H, bfr(torch.randn(2, 64, 24, 40, generator=g))).requires_grad_(True) for _ in range(2)]
+        gys = [c8(H, bfr(torch.randn(2, 32, 24, 40, generator=g))) for _ in range(2)]
+
+        def run(defer):
+            opt.zero_grad()
+            dxs = []
+            if defer:
+                Fn.begin_deferred_wgrads()
+            for i in range(2):
+                x = xs[i].detach().requires_grad_(True)
+                y = Fn.conv2d(Fn.conv2d(x, w1, b1, 1, 1), w2, None, 1, 1) if i == 0 else Fn.conv2d(x, w1, b1, 1, 1)
+                gy = gys[i] if i == 0 else c8(H, bfr(torch.randn(2, 64, 24, 40, generator=torch.Generator().manual_seed(3))))
+                y.backward(gy)
+                if defer and i == 0:
+                    assert len(Fn.WGRAD_DEFER) == 2  # both layers stashed by the first pass
+                    Fn.stop_stashing_wgrads()
+                dxs.append(x.grad.view(torch.int16).clone())
+            if defer:
+                assert len(Fn.WGRAD_DEFER) == 1 and id(w2) in Fn.WGRAD_DEFER  # w1 found its partner, w2 waits for the flush
+                Fn.flush_deferred_wgrads()
+                assert Fn.WGRAD_DEFER is None
+            torch.cuda.synchronize()
+            return opt.flat_grad.clone(), dxs
+
+        g_plain, dx_plain = run(False)
+        g_defer, dx_defer = run(True)
+        assert all(torch.equal(a, b) for a, b in zip(dx_plain, dx_defer))
+        scale = g_plain.abs().max().item()
+        assert (g_plain - g_defer).abs().max().item() < 2e-5 * scale
+        assert g_plain.abs().sum().item() > 0
+    finally:
+        H.set_compute('fp32')
