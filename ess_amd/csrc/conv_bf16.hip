@@ -326,6 +326,33 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     conv_bf16_launch_pair(d->stride, mb, c8, grid, lds2, st, a);
     return ess_launch_status("conv2d_forward(bf16, tap-paired)");
   }
+  // one nearest-x2-upsampled BF16_C8 source, 3x3 / stride 1 / pad 1, BF16_C8 / F16_C8 output: the polyphase kernel (conv_bf16_poly.hip;
+  // 16 instead of 36 tap products per source pixel).  ESS_CONV_POLY=0: the general kernels with the upsampling in the tile loader
+  // (the rounding differs: four effective weights are rounded once each instead of nine weights)
+  static const bool poly_on = [] { const char* e = getenv("ESS_CONV_POLY"); return !(e && e[0] == '0'); }();
+  if (poly_on && ws_enabled() && c8 && a.fmt_out == ESS_FMT_BF16_C8 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && pl.ck == 16 &&
+      d->mode0 == ESS_SRC_NEAREST_UP2 && d->C1 == 0 && d->epilogue == ESS_EPI_LINEAR && d->out_split == 0 && !a.out_bf &&
+      (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU) && (d->C_out % 32) == 0 && (d->C0 % 16) == 0 && !(d->H_in & 1) && !(d->W_in & 1) &&
+      (pl.cout_tile == 32 || pl.cout_tile == 64)) {
+    int th, tw, max_cin;
+    conv_bf16_poly_tile(&th, &tw, &max_cin);
+    if (d->C0 <= max_cin) {  // (the kernel keeps the effective weights of every chunk in LDS)
+    ConvKArgs t = a;
+    t.Hin = d->H_in >> 1; t.Win = d->W_in >> 1;      // the stored (low-resolution) source
+    // (t.Hout / t.Wout stay the full-resolution output extent; a workgroup's tile is th x tw LOW-resolution pixels = 2 th x 2 tw outputs)
+    t.tiles_x = ceil_div(t.Win, tw);
+    t.n_tiles = t.tiles_x * ceil_div(t.Hin, th);
+    t.n_cout_tiles = d->C_out / 32;
+    t.slab = pl.cout_tile;
+    // one resident set of workgroups, each bound to ONE 32-channel output tile (its weights stay in LDS) and walking pixel tiles
+    const int cus = tuning().cus, nct = t.n_cout_tiles, ptiles = t.n_tiles * d->N;
+    int per_ct = cus / nct > 0 ? cus / nct : 1;
+    if (per_ct > ptiles) per_ct = ptiles;
+    t.persist = 1;
+    conv_bf16_launch_poly(dim3((unsigned)(per_ct * nct)), st, t);
+    return ess_launch_status("conv2d_forward(bf16, polyphase nearest-up2)");
+    }
+  }
   if (ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) {
     const size_t lds2 = 2 * (size_t)pl.lds_bytes;  // double-buffered stages
     WidePick wp;

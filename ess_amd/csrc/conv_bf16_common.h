@@ -36,6 +36,9 @@ void conv_bf16_launch_stem(const EssConvDesc* d, const EssConvPlan& pl, hipStrea
 // conv_bf16_wide.hip: 3x3 / stride 1, BF16_C8 sources and outputs, five pixel blocks per matrix wave (tile rows *th x 16 columns)
 void conv_bf16_wide_tile(int mbw, int cw, int* th, int* tw);
 void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a);
+// conv_bf16_poly.hip: 3x3 / stride 1 / pad 1 of ONE nearest-x2-upsampled BF16_C8 source, polyphase (2 x 2 effective filters per output parity)
+void conv_bf16_poly_tile(int* th, int* tw, int* max_cin);
+void conv_bf16_launch_poly(dim3 grid, hipStream_t st, const ConvKArgs& a);
 // conv_bf16_pair.hip
 void conv_bf16_launch_pair(int stride, int mb, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
 

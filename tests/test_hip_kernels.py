@@ -1461,3 +1461,48 @@ def test_conv_stem7x7_bf16(H, case):
         assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
         if form == 'both':
             assert torch.equal(got, out.cpu().bfloat16().float())
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 48, 64, 'bias_f16'), (1, 64, 64, 50, 38, 'bias'), (2, 32, 96, 34, 66, 'scale_shift_relu'),
+                                  (1, 128, 32, 32, 32, 'residual_relu'), (8, 64, 32, 480, 640, 'bias_f16'), (2, 16, 32, 2, 2, 'bias')])
+def test_conv_poly_up2_c8(H, case):
+    """3x3 / stride 1 / pad 1 of ONE nearest-x2-upsampled BF16_C8 source on the polyphase kernel (conv_bf16_poly.hip: 2 x 2 effective
+    filters per output parity, 16 instead of 36 tap products per source pixel) against F.conv2d(F.interpolate(x, 2, 'nearest')) in fp32
+    on the bf16-rounded operands: borders (the zero padding of the upsampled image), ragged tiles (50 x 38 outputs = 25 x 19 source
+    pixels), 32 / 64 / 96 output channels (one, two, three 32-channel class tiles; 64-row weight slabs), every epilogue form, the
+    persistent launch at the decoder's own size (64^ -> 32 @ 480 x 640, B = 8) and a 1 x 1 source."""
+    N, Ci, Co, Hh, Ww, form = case
+    g = torch.Generator().manual_seed(Ci + Co + Hh)
+    x = torch.randn(N, Ci, Hh // 2, Ww // 2, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    sc = torch.rand(Co, generator=g) + 0.5
+    f16, relu, has_res, has_scale = 'f16' in form, 'relu' in form, 'residual' in form, 'scale' in form
+    spec = H.conv_spec(N, Hh, Ww, Ci, 0, Co, 3, 1, 1, mode0=H.SRC_NEAREST_UP2, act=H.ACT_RELU if relu else H.ACT_NONE, compute=H.COMPUTE_BF16)
+    pw = H.pack_weights(spec, dev(w))
+    psc = H.pack_rows(spec, dev(sc), fill=1.0) if has_scale else None
+    psh = H.pack_rows(spec, dev(b))
+    x8 = H.to_bf16_c8(dev(x))
+    rs = torch.randn(N, Co, Hh, Ww, generator=g) if has_res else None
+    r8 = H.to_bf16_c8(dev(rs)) if has_res else None
+    out = (H.f16_c8_empty if f16 else H.bf16_c8_empty)(N, Co, Hh, Ww, 'cuda')
+    out.view(torch.int16).fill_(0x7e00 if f16 else 0x7fc0)  # NaN patterns: every element must be written
+    H.conv_forward(spec, x8, None, pw, psc, psh, residual=r8, out=out, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F16_C8 if f16 else H.FMT_BF16_C8)
+    torch.cuda.synchronize()
+    assert not (out.view(torch.int16) == (0x7e00 if f16 else 0x7fc0)).any()
+    ref = F.conv2d(F.interpolate(x.bfloat16().float(), scale_factor=2, mode='nearest'), w.bfloat16().float(), None, padding=1)
+    if has_scale:
+        ref = ref * sc.view(1, -1, 1, 1)
+    ref = ref + b.view(1, -1, 1, 1)
+    if has_res:
+        ref = ref + rs.bfloat16().float()
+    if relu:
+        ref = F.relu(ref)
+    got = H.f16_c8_to_float(out, Co).cpu() if f16 else _un8(out, Co)
+    # (the four effective weights of a class are sums of 1 / 2 / 4 bf16 weights rounded once more: a second bf16 rounding of the weights)
+    assert relerr(got, ref) < (6e-3 if f16 else 1.4e-2), relerr(got, ref)
+    # borders exactly as the interior: the error does not concentrate in the outer ring
+    ring = torch.ones_like(ref, dtype=torch.bool)
+    if Hh > 4 and Ww > 4:
+        ring[:, :, 2:-2, 2:-2] = False
+        assert (got - ref)[ring].abs().max() <= 2.0 * (got - ref)[~ring].abs().max() + 1e-3
