@@ -183,6 +183,33 @@ def _pmc_summary(t):
     return out
 
 
+def part_mfma_ceiling():
+    """What THIS box's matrix cores sustain on random bf16 operands when nothing else runs: tools/mfma_ceiling.hip (a register-only
+    v_mfma_f32_32x32x16_bf16 loop, one wave per SIMD; and the same loop with 0.7 ds_read_b128 per MFMA, the wide-tile kernel's rate),
+    compiled with the box's own hipcc and run for ~1 s.  Context for `roofline.frac` (which stays against the NOMINAL 2.5 PFLOP/s):
+    the part is power-limited under matrix load and boxes of the pool differ.  None when hipcc is absent / the probe fails."""
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'mfma_ceiling.hip')
+    if not (os.path.exists(hipcc) and os.path.exists(src)):
+        return None
+    try:
+        exe = os.path.join(tempfile.mkdtemp(prefix='ess_ceiling_'), 'mfma_ceiling')
+        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-Wno-implicit-const-int-float-conversion', src, '-o', exe],
+                       check=True, capture_output=True, timeout=180)
+        out = subprocess.run([exe, '--json'], check=True, capture_output=True, timeout=60).stdout.decode().strip().splitlines()[-1]
+        d = json.loads(out)
+        d['note'] = ('tools/mfma_ceiling.hip on this box, random N(0,1) bf16 operands, 4000 back-to-back launches of ~65 us after a 0.13 s '
+                     'warm-up; tflops_per_launch includes the launch / prologue time of a 65 us kernel, tflops_in_loop is the K loop alone '
+                     '(s_memrealtime), clock_GHz = s_memtime ticks / s_memrealtime')
+        return d
+    except Exception as e:  # noqa: BLE001 -- context only: never fails the bench
+        return {'error': repr(e)[:200]}
+
+
 def roofline_blocks(args, device):
     """`roofline` of the bench line: the time-dominant kernel of the step -- the plain 3x3 convolution of the trainable networks
     (conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> in the bf16 configuration) -- timed LIVE with HIP events on the launch
@@ -633,6 +660,11 @@ def main():
             result['extra'] = extra
         if not args.no_roofline:
             result['roofline'] = roofline_blocks(args, device)
+            if args.compute == 'bf16':
+                pc = part_mfma_ceiling()
+                result['roofline']['part_ceiling'] = pc
+                if pc and 'registers_only' in pc:
+                    result['roofline']['frac_of_part_ceiling'] = round(result['roofline']['achieved'] / pc['registers_only']['tflops_per_launch'], 4)
             if in_step is not None:
                 result['roofline']['in_step'] = in_step
                 if in_step.get('achieved'):
