@@ -141,10 +141,38 @@ __global__ void task_loss_value_kernel(const double* ws, float* loss, float scal
   *loss = (float)(L * scale);
 }
 
+// ------------------------------------------------------------------ mean-type losses finish inside their ONE launch
+// ws (doubles): [0] = arrival counter (low 32 bits), [1 + b] = partial sum of block b.  Every block stores its partial (plain store, no
+// atomic on the sum), releases it and takes a ticket; the block that draws the last ticket adds the partials IN BLOCK ORDER -- the
+// value does not depend on which block arrives last or in what order the others did -- writes the loss and puts the counter back
+// to zero for the next call.  Contract (include/ess_hip.h): ESS_LOSS_WORKSPACE_BYTES, counter zero before the FIRST use.  Replaces
+// memset + kernel (atomicAdd on one double) + finalize kernel: three graph nodes per loss term became one (a node boundary of the
+// replayed step costs 1.55 us, profiles/r5_graph_gap_probe.txt; memset and finalize ran 4.7 + 5.1 us).
+constexpr int LOSS_MAX_BLOCKS = 2048;
+__device__ __forceinline__ void mean_finish(double block_acc, double* ws, float* loss, double denom, float scale, double* red) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    ws[1 + blockIdx.x] = block_acc;
+    __threadfence();  // the partial is visible device-wide before the ticket is
+    s_last = atomicAdd((unsigned*)ws, 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // (acquire side: nothing of the partials may come from a stale line)
+  double a = 0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
+    a += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = block_sum_d(a, red);
+  if (threadIdx.x == 0) {
+    *loss = (float)(a / denom * scale);
+    __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ------------------------------------------------------------------ symmetric JS (as two mean-KL terms)
 template <int KM>
 __global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ za, const float* __restrict__ zb, double* ws,
-                                                     float* __restrict__ da, float scale, int N, int K, int hw) {
+                                                     float* __restrict__ da, float scale, int N, int K, int hw, float* loss) {
   __shared__ double red[16];
   const size_t total = (size_t)N * hw;
   const float invM = 1.f / ((float)total * K);
@@ -192,11 +220,11 @@ __global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ z
     }
   }
   acc = block_sum_d(acc, red);
-  if (threadIdx.x == 0) atomicAdd(ws, acc);
+  mean_finish(acc, ws, loss, (double)total * K, scale, red);
 }
 
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, double* ws,
-                                                 float* __restrict__ da, float scale, int64_t n) {
+                                                 float* __restrict__ da, float scale, int64_t n, float* loss) {
   __shared__ double red[16];
   const float gs = scale / (float)n;
   double acc = 0;
@@ -206,12 +234,12 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
     if (da) da[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
   }
   acc = block_sum_d(acc, red);
-  if (threadIdx.x == 0) atomicAdd(ws, acc);
+  mean_finish(acc, ws, loss, (double)n, scale, red);
 }
 
 // 16-byte variant (n % 4 == 0, aligned pointers): same per-element arithmetic, a quarter of the memory instructions
 __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, double* ws,
-                                                    f32x4* __restrict__ da, float scale, int64_t n4, int64_t n) {
+                                                    f32x4* __restrict__ da, float scale, int64_t n4, int64_t n, float* loss) {
   __shared__ double red[16];
   const float gs = scale / (float)n;
   double acc = 0;
@@ -229,14 +257,14 @@ __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a,
     if (da) da[i] = g;
   }
   acc = block_sum_d(acc, red);
-  if (threadIdx.x == 0) atomicAdd(ws, acc);
+  mean_finish(acc, ws, loss, (double)n, scale, red);
 }
 
 // L1 over BF16_C8 tensors (the latent / intermediate-prediction cycle losses of the bf16 configuration): 8 elements per 16-byte
 // vector, fp32 differences, the gradient sign(a - b) * scale / n written as BF16_C8.  Padded tail channels are zero in both
 // operands: they add nothing to the sum and get a zero gradient; `n` is the number of REAL elements.
 __global__ __launch_bounds__(256) void l1_c8_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, double* ws,
-                                                    uint4* __restrict__ da, float scale, int64_t nvec, int64_t n) {
+                                                    uint4* __restrict__ da, float scale, int64_t nvec, int64_t n, float* loss) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   __shared__ double red[16];
   const float gs = scale / (float)n;
@@ -258,11 +286,7 @@ __global__ __launch_bounds__(256) void l1_c8_kernel(const uint4* __restrict__ a,
     if (da) da[i] = __builtin_bit_cast(uint4, g);
   }
   acc = block_sum_d(acc, red);
-  if (threadIdx.x == 0) atomicAdd(ws, acc);
-}
-
-__global__ void mean_finalize_kernel(const double* ws, float* loss, double denom, float scale) {
-  *loss = (float)(ws[0] / denom * scale);
+  mean_finish(acc, ws, loss, (double)n, scale, red);
 }
 
 // ------------------------------------------------------------------ RAdam over a flat buffer
@@ -364,16 +388,13 @@ extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, floa
   ESS_CHECK_ARG(a && b && loss && workspace && N > 0 && hw > 0, "sym_js_loss: bad arguments");
   ESS_CHECK_ARG(K > 0 && K <= KMAX, "sym_js_loss: K=%d unsupported (max %d)", K, KMAX);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("sym_js_loss: memset failed"); return ESS_ELAUNCH; }
   const size_t total = (size_t)N * hw;
   if (K <= 16)
     hipLaunchKernelGGL((sym_js_kernel<16>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, N, K, hw);
+                       loss_scale, N, K, hw, loss);
   else
     hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, N, K, hw);
-  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)total * K,
-                     loss_scale);
+                       loss_scale, N, K, hw, loss);
   return ess_launch_status("sym_js_loss");
 }
 
@@ -381,14 +402,12 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
                            ess_stream_t stream) {
   ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("l1_loss: memset failed"); return ESS_ELAUNCH; }
   if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0)
     hipLaunchKernelGGL(l1_x4_kernel, dim3(wave_uniform_grid((size_t)n / 4, 2048)), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b,
-                       (double*)workspace, (f32x4*)da, loss_scale, n / 4, n);
+                       (double*)workspace, (f32x4*)da, loss_scale, n / 4, n, loss);
   else
     hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, n);
-  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
+                       loss_scale, n, loss);
   return ess_launch_status("l1_loss");
 }
 
@@ -397,10 +416,8 @@ extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* d
   ESS_CHECK_ARG(a && b && loss && workspace && n_vectors > 0 && n > 0 && n <= 8 * n_vectors, "l1_loss_c8: bad arguments");
   ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0, "l1_loss_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) { ess_set_error("l1_loss_c8: memset failed"); return ESS_ELAUNCH; }
   hipLaunchKernelGGL(l1_c8_kernel, dim3(wave_uniform_grid((size_t)n_vectors, 2048)), dim3(256), 0, st, (const uint4*)a, (const uint4*)b,
-                     (double*)workspace, (uint4*)da, loss_scale, n_vectors, n);
-  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(1), 0, st, (const double*)workspace, loss, (double)n, loss_scale);
+                     (double*)workspace, (uint4*)da, loss_scale, n_vectors, n, loss);
   return ess_launch_status("l1_loss_c8");
 }
 

@@ -339,14 +339,24 @@ def f16_c8_to_float(t, C):
 _ws_cache = {}
 
 
-def workspace(nbytes, device, tag='ws'):
-    """Grow-only scratch buffer per (device, stream, tag): kernels on one stream are ordered, so reuse is safe."""
+def workspace(nbytes, device, tag='ws', zero=False):
+    """Grow-only scratch buffer per (device, stream, tag): kernels on one stream are ordered, so reuse is safe.
+    zero: zero-filled when (re)allocated -- for kernels that keep an arrival counter in it and leave it zero themselves."""
     key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1024), dtype=torch.uint8, device=device)
+        buf = (torch.zeros if zero else torch.empty)(max(int(nbytes), 1024), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+LOSS_WORKSPACE_BYTES = 8 * (1 + 2048)  # ESS_LOSS_WORKSPACE_BYTES of include/ess_hip.h: arrival counter + one partial per block
+
+
+def _mean_loss_ws(device):
+    """Workspace of the single-launch mean losses (ess_sym_js_loss / ess_l1_loss / ess_l1_loss_c8): zero before its first use, left
+    zero by every call (the last block resets the counter) -- its own tag, the task loss leaves sums in its workspace."""
+    return workspace(LOSS_WORKSPACE_BYTES, device, 'mean_loss', zero=True)
 
 
 def conv_wgrad(spec, src0, src1, dy, dw, db=None, accumulate=False):
@@ -646,7 +656,7 @@ def sym_js_loss(a, b, want_grad, scale=1.0):
     N, K, H, W = a.shape
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     da = torch.empty_like(a) if want_grad else None
-    ws = workspace(64, a.device, 'loss')
+    ws = _mean_loss_ws(a.device)
     _check(lib().ess_sym_js_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), N, K, H * W, c_void_p(ws.data_ptr()),
                                  stream()), 'ess_sym_js_loss')
     return loss, da
@@ -655,7 +665,7 @@ def sym_js_loss(a, b, want_grad, scale=1.0):
 def l1_loss(a, b, want_grad, scale=1.0):
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     da = torch.empty_like(a) if want_grad else None
-    ws = workspace(64, a.device, 'loss')
+    ws = _mean_loss_ws(a.device)
     _check(lib().ess_l1_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), a.numel(), c_void_p(ws.data_ptr()),
                              stream()), 'ess_l1_loss')
     return loss, da
@@ -667,7 +677,7 @@ def l1_loss_c8(a, b, n_real, want_grad, scale=1.0):
         raise EssHipError('l1_loss_c8: shape mismatch')
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     da = torch.empty_like(a) if want_grad else None
-    ws = workspace(64, a.device, 'loss')
+    ws = _mean_loss_ws(a.device)
     _check(lib().ess_l1_loss_c8(ptr(a, torch.bfloat16), ptr(b, torch.bfloat16), ptr(loss), ptr(da, torch.bfloat16), c_float(scale),
                                 a.numel() // 8, int(n_real), c_void_p(ws.data_ptr()), stream()), 'ess_l1_loss_c8')
     return loss, da

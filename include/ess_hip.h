@@ -326,17 +326,22 @@ size_t ess_task_loss_workspace(int32_t K);
 int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
                   int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
                   void* workspace, ess_stream_t stream);
+/* Workspace of the mean-type losses below (ess_sym_js_loss, ess_l1_loss, ess_l1_loss_c8): an arrival counter + one partial sum per
+ * workgroup.  Each of them is ONE launch: the workgroup that arrives last adds the partials in workgroup order (the value does not
+ * depend on arrival order), writes the loss and resets the counter.  The buffer must be ZERO-FILLED BEFORE ITS FIRST USE; every call
+ * leaves it ready for the next one.  Do not share it with ess_task_loss (which leaves its sums behind) or between streams. */
+#define ESS_LOSS_WORKSPACE_BYTES (8 * (1 + 2048))
 /* symJSDivLoss (utils/loss_functions.py:27-37): loss (1 float) and gradient w.r.t. `a` only
- * (the other argument is always computed under no_grad by the trainers).                            */
+ * (the other argument is always computed under no_grad by the trainers).  workspace: ESS_LOSS_WORKSPACE_BYTES (see above). */
 int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int32_t N,
                     int32_t K, int32_t hw, void* workspace, ess_stream_t stream);
-/* L1Loss mean (training/ess_trainer.py:217-229): loss and gradient w.r.t. a.                        */
+/* L1Loss mean (training/ess_trainer.py:217-229): loss and gradient w.r.t. a.  workspace: ESS_LOSS_WORKSPACE_BYTES.  */
 int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n,
                 void* workspace, ess_stream_t stream);
 
 /* L1Loss mean over BF16_C8 operands (bf16 configuration: the latents / intermediate predictions the cycle losses compare are
  * stored as BF16_C8); da (nullable): BF16_C8 gradient.  n_vectors 16-byte pixel vectors, n REAL elements (the mean's
- * denominator; padded tail channels are zero in both operands).                                                   */
+ * denominator; padded tail channels are zero in both operands).  workspace: ESS_LOSS_WORKSPACE_BYTES.               */
 int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* da, float loss_scale, int64_t n_vectors, int64_t n,
                    void* workspace, ess_stream_t stream);
 

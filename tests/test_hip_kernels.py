@@ -397,6 +397,61 @@ def test_losses_against_golden_and_oracle(H, golden):
     assert abs(l.item() - gd['dice'].item()) < 5e-6
 
 
+def test_mean_losses_single_launch(H):
+    """ess_l1_loss / ess_l1_loss_c8 / ess_sym_js_loss finish inside their one launch (partials in workgroup order, arrival counter in
+    the workspace, reset by the last workgroup): full 2048-workgroup grids, odd sizes that take the scalar kernel, many calls in a
+    row on one workspace (the counter must come back to zero every time), bit-identical values call to call, a side stream with
+    its own workspace, and replays of a captured graph."""
+    g = torch.Generator().manual_seed(11)
+    cases = [(8 * 256 * 60 * 80,), (2048 * 256 * 4 + 4,), (1237,), (3,)]
+    for (n,) in cases:
+        a, b = torch.randn(n, generator=g), torch.randn(n, generator=g)
+        ref = (a.double() - b.double()).abs().mean().item()
+        ad, bd = a.cuda(), b.cuda()
+        vals = []
+        for it in range(4):
+            loss, da = H.l1_loss(ad, bd, it == 0, scale=1.5)
+            vals.append(loss.item())
+            if da is not None:
+                assert torch.equal(da.cpu(), torch.sign(a - b) * (1.5 / n))
+        assert abs(vals[0] - 1.5 * ref) < 2e-6 * ref + 1e-9, (n, vals[0], 1.5 * ref)
+        assert len(set(vals)) == 1, vals
+    # BF16_C8 form at the DSEC latent size, then a small one on the same workspace
+    for shp in ((8, 256, 60, 80), (1, 8, 3, 5)):
+        a, b = [torch.randn(*shp, generator=g).bfloat16().float() for _ in range(2)]
+        a8, b8 = H.to_bf16_c8(a.cuda()), H.to_bf16_c8(b.cuda())
+        ref = (a.double() - b.double()).abs().mean().item()
+        vals = [H.l1_loss_c8(a8, b8, a.numel(), False)[0].item() for _ in range(3)]
+        assert abs(vals[0] - ref) < 2e-6 * ref and len(set(vals)) == 1
+    # symmetric JS at the DSEC prediction size, on a side stream too, and through graph replays
+    za, zb = torch.randn(8, 11, 120, 160, generator=g).cuda(), torch.randn(8, 11, 120, 160, generator=g).cuda()
+    v0 = H.sym_js_loss(za, zb, False)[0].item()
+    ref = O.sym_js_div(za.double().cpu(), zb.double().cpu()).item()
+    assert abs(v0 - ref) < 1e-5 * abs(ref) + 1e-8
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        v1 = [H.sym_js_loss(za, zb, False)[0] for _ in range(3)]
+    side.synchronize()
+    assert all(v.item() == v0 for v in v1)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        H.sym_js_loss(za, zb, False)
+        H.l1_loss(za.view(-1), zb.view(-1), False)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            lj = H.sym_js_loss(za, zb, False)[0]
+            ll = H.l1_loss(za.view(-1), zb.view(-1), False)[0]
+            lj2 = H.sym_js_loss(zb, za, False)[0]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        gr.replay()
+        torch.cuda.synchronize()
+        assert lj.item() == v0 and abs(lj2.item() - v0) < 1e-6 * abs(v0) + 1e-9
+        assert abs(ll.item() - (za - zb).abs().double().mean().item()) < 1e-6
+
+
 def test_radam_flat(H, golden):
     g = golden('radam')
     flat = torch.cat([p.flatten() for p in g['p0']]).cuda()
