@@ -34,7 +34,16 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
   int sel;
   const int row = map_row(ct * cot + col, epi, hid, cout, &sel);
   float v = 0.f;
-  if (row >= 0 && c < cin) {
+  if (w_kind == ESS_W_CONV5_S2D) {
+    // the space-to-depth form of a 5x5 / stride-2 convolution (conv_bf16_wide.hip, ESS_SRC_S2D): virtual channel c = q * cin5 + cr
+    // of parity class q = py + 2 px; `tap` is the SLOT of the chunk's slab -- a class keeps its used taps first
+    const int cin5 = cin >> 2, q = c / cin5, cr = c - q * cin5, py = q & 1, px = q >> 1;
+    int t3 = tap;  // slot -> tap (ty * 3 + tx)
+    if (q == 2) { const int m[9] = {0, 1, 3, 4, 6, 7, 2, 5, 8}; t3 = m[tap]; }
+    if (q == 3) { const int m[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}; t3 = m[tap]; }
+    const int ky = 2 * (t3 / 3) + py, kx = 2 * (t3 % 3) + px;
+    if (row >= 0 && ky < 5 && kx < 5) v = w[(((size_t)row * cin5 + cr) * 5 + ky) * 5 + kx];
+  } else if (row >= 0 && c < cin) {
     const int ky = tap / ks, kx = tap - ky * ks;
     const float* src = sel ? w2 : w;
     if (w_kind == ESS_W_CONV) v = src[(((size_t)row * cin + c) * ks + ky) * ks + kx];
@@ -325,6 +334,33 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
     }
     conv_bf16_launch_pair(d->stride, mb, c8, grid, lds2, st, a);
     return ess_launch_status("conv2d_forward(bf16, tap-paired)");
+  }
+  if (d->mode0 == ESS_SRC_S2D) {
+    // the 5x5 / stride-2 convolution of a BF16_C8 tensor as a 3x3 over its space-to-depth view (validate() has checked the form):
+    // the wide-tile kernel only; 128-channel workgroup tiles where the output channels allow and the round count is no worse
+    ESS_CHECK_ARG(c8 && a.fmt_out == ESS_FMT_BF16_C8 && !a.out_bf && !a.residual && !a.out_f16 && pl.ck == 16 && pl.cout_tile == 64 &&
+                      (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU),
+                  "conv(bf16, S2D): BF16_C8 in and out, no residual / copy, act in {none, relu}");
+    const int cus = tuning().cus;
+    int best_cw = 0, best_tiles = 0, best_tx = 0, best_ty = 0;
+    double best = 1e300;
+    for (int cw = 2; cw >= 1; --cw) {
+      const int cot = 64 * cw;
+      if (d->C_out % cot) continue;
+      int th, tw;
+      conv_bf16_wide_tile(2, cw, &th, &tw);
+      const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
+      const int tiles = tx * ty * (d->C_out / cot) * d->N;
+      const double cost = (double)ceil_div(tiles, cus) * cot * th * tw;
+      if (cost < best) { best = cost; best_cw = cw; best_tiles = tiles; best_tx = tx; best_ty = ty; }
+    }
+    ESS_CHECK_ARG(best_cw > 0, "conv(bf16, S2D): C_out %d is not a multiple of 64", d->C_out);
+    ConvKArgs t = a;
+    t.tiles_x = best_tx; t.n_tiles = best_tx * best_ty;
+    t.persist = best_tiles > cus ? 1 : 0;
+    t.slab = pl.cout_tile;
+    conv_bf16_launch_wide(2, best_cw, d->epilogue, dim3((unsigned)(best_tiles > cus ? cus : best_tiles)), st, t);
+    return ess_launch_status("conv2d_forward(bf16, wide tile, space-to-depth 5x5/s2)");
   }
   // one nearest-x2-upsampled BF16_C8 source, 3x3 / stride 1 / pad 1, BF16_C8 / F16_C8 output: the polyphase kernel (conv_bf16_poly.hip;
   // 16 instead of 36 tap products per source pixel).  ESS_CONV_POLY=0: the general kernels with the upsampling in the tile loader

@@ -30,19 +30,35 @@
 // gain 3-4 % -- 42.3 -> 40.8, 25.2 -> 24.3, 25.9 -> 24.8, 113.4 -> 111.3 us: the output burst of a single-round launch streams past the
 // L2 --, but inside the train step the next kernel reads that output and the same-box A/B goes the other way: conv time in the step
 // 6.36-6.42 -> 6.45-6.49 ms, step 23.16-23.18 -> 23.19-23.20 ms.  Default policy.)
+//
+// S2D (round 5, second session): a 5x5 / stride-2 / pad-2 convolution is a 3x3 / stride-1 / pad-1 convolution over the SPACE-TO-DEPTH
+// view of its input -- out[y][x] = sum w[ky][kx] in[2y + ky - 2][2x + kx - 2], and with ky - 2 = 2 dy + py (py = row parity of the
+// input pixel) the 25 taps become, per parity class (py, px), the taps (dy, dx) in {-1, 0, (+1 only for parity 0)}^2 of the
+// half-resolution phase plane in[2 . + py][2 . + px]: 9 + 6 + 6 + 4 = 25 products.  So the frozen encoder's three downsampling
+// convolutions (e2vid/model/unet.py:117-181 encoders, submodules.py:176-186 RecurrentConvLayer.conv; 84 us each on the tap-paired
+// kernel: 8-channel chunks of 26 MFMAs per wave between barriers, 1.5 fragment reads per MFMA, 0.30 of peak) run HERE, on 16-channel
+// chunks of 90 / 60 / 60 / 40 MFMAs at 0.7 reads per MFMA: source mode ESS_SRC_S2D = the stored tensor is [N][Cin/8][2 Hin][2 Win][8],
+// the descriptor's C0 = 4 Cin VIRTUAL channels in class-major order (class q = py + 2 px owns channels [q Cin, (q + 1) Cin)), the
+// staging waves gather a chunk's pixel vectors at (2 gy + py, 2 gx + px), and the matrix waves run a class's chunk with its own tap list
+// (no products with the zero taps a dense 3x3 over 4 Cin channels would carry: 25 / 36 of the work).  The weight pack (w_kind
+// ESS_W_CONV5_S2D: from the [Cout][Cin][5][5] tensor) keeps a chunk's USED taps first (class order below), so the staging waves copy
+// only the used prefix of a chunk's slab.  Needs Cin % 32 == 0 (an even number of chunks per class keeps the fragment-set roles).
 #include "conv_bf16_common.h"
 
 namespace {
 
 using namespace essconv;
 
+// class q = py + 2 px: taps (ty * 3 + tx) a chunk of that class contracts, in the order its weight slab stores them
+//   q 0 (0, 0): 0 1 2 3 4 5 6 7 8      q 1 (py 1): 0 1 2 3 4 5      q 2 (px 1): 0 1 3 4 6 7      q 3 (1, 1): 0 1 3 4
+__host__ __device__ constexpr int s2d_ntaps(int q) { return q == 0 ? 9 : (q == 3 ? 4 : 6); }
 constexpr int WIDE_NB = 5;    // pixel blocks per matrix wave
 constexpr int WIDE_RP = 32;   // LDS row pitch in 16-byte vectors: 18 used; rows of a pixel block must start 0 mod 16 vectors apart (ds_read_b128 lane groups)
 constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
 
 // EPI: ESS_EPI_LINEAR (BF16_C8 outputs), ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h', bias in
 // the accumulators -- conv_epilogue_lstm_c8) or ESS_EPI_GRU_UR / ESS_EPI_GRU_OUT (the lean ConvGRU kernel pair: conv_epilogue_gru_*_c8)
-template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR, bool S2D = false>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16, NB = WIDE_NB, RP = WIDE_RP;
@@ -87,10 +103,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
     ESS_TILE_DECODE
     // ------------------------------------------------------------------ staging waves (BF16_C8 sources; see conv_bf16_ws.hip)
     const int iy0 = y0 - a.pad, ix0 = x0 - a.pad;
-    const int sh0 = a.mode0 != ESS_SRC_DIRECT ? 1 : 0, sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
-    const int Wp0 = a.Win >> sh0, Wp1 = a.Win >> sh1;
-    const size_t hw0 = (size_t)(a.Hin >> sh0) * Wp0, hw1 = (size_t)(a.Hin >> sh1) * Wp1;
-    const int nb0 = (a.C0 + 7) >> 3, nb1 = (a.C1 + 7) >> 3;
+    // S2D: the stored source has twice the (virtual) extent and a quarter of the (virtual) channels; a.Hin / a.Win are the virtual ones
+    const int sh0 = S2D ? 0 : (a.mode0 != ESS_SRC_DIRECT ? 1 : 0), sh1 = a.mode1 != ESS_SRC_DIRECT ? 1 : 0;
+    const int Wp0 = S2D ? 2 * a.Win : (a.Win >> sh0), Wp1 = a.Win >> sh1;
+    const size_t hw0 = S2D ? (size_t)4 * a.Hin * a.Win : (size_t)(a.Hin >> sh0) * Wp0, hw1 = (size_t)(a.Hin >> sh1) * Wp1;
+    const int nb0 = S2D ? (a.C0 >> 5) : ((a.C0 + 7) >> 3), nb1 = (a.C1 + 7) >> 3;  // (S2D: Cin / 8 stored blocks)
+    const int nq = S2D ? (a.n_chunks >> 2) : 1;                                     // (S2D: chunks per parity class)
     const u32x4* s0 = (const u32x4*)a.src0 + (size_t)n * nb0 * hw0;
     const u32x4* s1 = a.C1 ? (const u32x4*)a.src1 + (size_t)n * nb1 * hw1 : s0;
     unsigned v_pos0[KPC], v_pos1[KPC], v_keep0[KPC], v_keep1[KPC];
@@ -104,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const bool odd = ((gy | gx) & 1) != 0;
       const bool in0 = in && !(a.mode0 == ESS_SRC_ZERO_UP2 && odd), in1 = in && !(a.mode1 == ESS_SRC_ZERO_UP2 && odd);
       v_lds[k] = vi < NPOS ? iy * RP + ix : -1;
-      v_pos0[k] = in0 ? (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0)) : 0u;
+      v_pos0[k] = in0 ? (S2D ? (unsigned)(2 * gy * Wp0 + 2 * gx) : (unsigned)((gy >> sh0) * Wp0 + (gx >> sh0))) : 0u;
       v_pos1[k] = in1 ? (unsigned)((gy >> sh1) * Wp1 + (gx >> sh1)) : 0u;
       v_keep0[k] = in0 ? 0xffffffffu : 0u;
       v_keep1[k] = in1 ? 0xffffffffu : 0u;
@@ -126,6 +144,20 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #ifdef ESS_ABLATE
       if (a.deep & 4) return;  // (ablation build only, switch ESS_WS_ABL: no global loads)
 #endif
+      if constexpr (S2D) {
+        const int q = ch / nq, cq = ch - q * nq;                     // parity class, chunk inside the class
+        const unsigned off_q = (unsigned)((q & 1) * Wp0 + (q >> 1));  // pixel (py, px) of the 2 x 2 cell
+#pragma unroll
+        for (int cb = 0; cb < CB8; ++cb) {
+          const u32x4* sp = s0 + (size_t)(cq * 2 + cb) * hw0;
+#pragma unroll
+          for (int k = 0; k < KPC; ++k) r.pre[cb][k] = sp[v_pos0[k] + off_q];
+        }
+        const u32x4* wsrc = wbase + (size_t)ch * (KS * KS * CB8 * SLAB);
+        const int wlim = s2d_ntaps(q) * CB8 * COT;  // the used taps are the first ones of the slab (LDS index space is tap-major)
+#pragma unroll
+        for (int it = 0; it < WV; ++it) r.wpre[it] = wsrc[tid + it * 256 < wlim ? w_src[it] : 0];
+      } else {
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;
@@ -138,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const u32x4* wsrc = wbase + (size_t)ch * (KS * KS * CB8 * SLAB);
 #pragma unroll
       for (int it = 0; it < WV; ++it) r.wpre[it] = wsrc[w_src[it]];
+      }
     };
     auto commit = [&](int ch, int buf, const Set& r) {
 #ifdef ESS_ABLATE
@@ -148,8 +181,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #pragma unroll
       for (int cb = 0; cb < CB8; ++cb) {
         const int c0 = ch * CK + cb * 8;
-        const bool first = c0 < a.C0 || a.C1 == 0;
-        const unsigned blk_ok = ((first ? c0 : c0 - a.C0) >> 3) < (first ? nb0 : nb1) ? 0xffffffffu : 0u;
+        const bool first = S2D || c0 < a.C0 || a.C1 == 0;
+        const unsigned blk_ok = S2D ? 0xffffffffu : (((first ? c0 : c0 - a.C0) >> 3) < (first ? nb0 : nb1) ? 0xffffffffu : 0u);
 #pragma unroll
         for (int k = 0; k < KPC; ++k) {
           const unsigned m = (first ? v_keep0[k] : v_keep1[k]) & blk_ok;
@@ -158,8 +191,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
           if (v_lds[k] >= 0) in_t[cb * PLANE + v_lds[k]] = v;
         }
       }
+      const int wlim = S2D ? s2d_ntaps(ch / nq) * CB8 * COT : WSZ;
 #pragma unroll
-      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < WSZ) w_t[i] = r.wpre[it]; }
+      for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < wlim) w_t[i] = r.wpre[it]; }
     };
     const int nch = a.n_chunks;
     load_chunk(0, sa);
@@ -213,12 +247,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
   // that is used: tap 0 of chunk ch + 1 is read right behind the barrier that ends chunk ch, BEFORE the MFMAs of chunk ch's last
   // tap -- ten matrix instructions cover the LDS round trip that a chunk would otherwise start with (one matrix wave per SIMD:
   // nobody else fills that gap).
-#define ESS_READ_TAP(F_, TAP_, STG_)                                                                                             \
+#define ESS_READ_TAP(F_, TAP_, STG_) ESS_READ_TS(F_, TAP_, TAP_, STG_)
+  // (TAP_: the filter tap = where the pixel fragments sit in the input tile; SLOT_: where that tap's weights sit in the staged slab)
+#define ESS_READ_TS(F_, TAP_, SLOT_, STG_)                                                                                       \
     {                                                                                                                            \
       constexpr int ky_ = (TAP_) / KS, kx_ = (TAP_) % KS;                                                                        \
       const unsigned wa_ = (STG_) + a_base, ba_ = (STG_) + b_base;                                                               \
       _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                         \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.a[mb]) : "v"(wa_ + (unsigned)(mb * 32 * 16)), "n"((TAP_) * CB8 * COT * 16)); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.a[mb]) : "v"(wa_ + (unsigned)(mb * 32 * 16)), "n"((SLOT_) * CB8 * COT * 16)); \
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.b[0]) : "v"(ba_), "n"((0 * 2 * RP + ky_ * RP + kx_) * 16));        \
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.b[1]) : "v"(ba_), "n"((1 * 2 * RP + ky_ * RP + kx_) * 16));        \
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F_.b[2]) : "v"(ba_), "n"((2 * 2 * RP + ky_ * RP + kx_) * 16));        \
@@ -265,6 +301,28 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       ESS_TIE(FA_)                                                                                                               \
       ESS_MMA(FA_)                                                                                                               \
     }
+  // S2D chunks: the same pipeline over a class's own tap list (6 or 4 taps, slots 0 .. n - 1 of the slab).  An EVEN number of taps
+  // leaves the fragment sets in the roles they entered with (tap 0 of the next chunk goes back into FA_).
+#define ESS_STEP(FN_, FC_, TAP_, SLOT_, stg_) ESS_READ_TS(FN_, TAP_, SLOT_, stg_) ESS_WAIT(FC_, NR) ESS_MMA(FC_)
+#define ESS_CHUNK_TAIL_EVEN(FA_, FB_, CH_)                                                                                       \
+      ESS_WAIT(FB_, 0)                                                                                                           \
+      __syncthreads();                                                                                                           \
+      ESS_READ_TAP(FA_, 0, lds0 + (unsigned)((((CH_) + 1) & 1) * BUFSZ * 16))                                                    \
+      ESS_TIE(FB_)                                                                                                               \
+      ESS_MMA(FB_)
+#define ESS_CHUNK6(FA_, FB_, CH_, T1, T2, T3, T4, T5)                                                                            \
+    {                                                                                                                            \
+      const unsigned stg_ = lds0 + (unsigned)(((CH_) & 1) * BUFSZ * 16);                                                         \
+      ESS_STEP(FB_, FA_, T1, 1, stg_) ESS_STEP(FA_, FB_, T2, 2, stg_) ESS_STEP(FB_, FA_, T3, 3, stg_)                             \
+      ESS_STEP(FA_, FB_, T4, 4, stg_) ESS_STEP(FB_, FA_, T5, 5, stg_)                                                            \
+      ESS_CHUNK_TAIL_EVEN(FA_, FB_, CH_)                                                                                         \
+    }
+#define ESS_CHUNK4(FA_, FB_, CH_, T1, T2, T3)                                                                                    \
+    {                                                                                                                            \
+      const unsigned stg_ = lds0 + (unsigned)(((CH_) & 1) * BUFSZ * 16);                                                         \
+      ESS_STEP(FB_, FA_, T1, 1, stg_) ESS_STEP(FA_, FB_, T2, 2, stg_) ESS_STEP(FB_, FA_, T3, 3, stg_)                             \
+      ESS_CHUNK_TAIL_EVEN(FA_, FB_, CH_)                                                                                         \
+    }
   constexpr int NR = MBW + NB;  // LDS reads per tap
   const int nch = a.n_chunks;
   Frags f0, f1;
@@ -275,12 +333,28 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #endif
   {
     ESS_READ_TAP(f0, 0, lds0)
+    if constexpr (S2D) {
+      const int nq = nch >> 2;  // chunks per parity class (even: validate())
+      for (int ch = 0; ch < nq; ch += 2) {
+        ESS_CHUNK(f0, f1, ch)
+        ESS_CHUNK(f1, f0, ch + 1)
+      }
+      for (int ch = nq; ch < 2 * nq; ++ch) ESS_CHUNK6(f0, f1, ch, 1, 2, 3, 4, 5)      // py = 1: rows dy in {-1, 0}
+      for (int ch = 2 * nq; ch < 3 * nq; ++ch) ESS_CHUNK6(f0, f1, ch, 1, 3, 4, 6, 7)  // px = 1: columns dx in {-1, 0}
+      for (int ch = 3 * nq; ch < nch; ++ch) ESS_CHUNK4(f0, f1, ch, 1, 3, 4)           // both
+    } else {
     for (int ch = 0; ch < nch; ch += 2) {
       ESS_CHUNK(f0, f1, ch)
       if (ch + 1 < nch) ESS_CHUNK(f1, f0, ch + 1)
     }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the read issued behind the last chunk's barrier)
   }
+#undef ESS_CHUNK4
+#undef ESS_CHUNK6
+#undef ESS_CHUNK_TAIL_EVEN
+#undef ESS_STEP
+#undef ESS_READ_TS
 #undef ESS_CHUNK
 #undef ESS_TIE
 #undef ESS_READ_TAP
@@ -315,13 +389,13 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #undef ESS_TILE_DECODE
 }
 
-template <int MBW, int CW, int EPI = ESS_EPI_LINEAR>
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR, bool S2D = false>
 void launch_wide_t(dim3 grid, hipStream_t st, const ConvKArgs& a) {
   constexpr int PW = 4 / CW, TH = PW * WIDE_NB * 2, PLANE = (TH + 2) * WIDE_RP, COT = MBW * CW * 32;
   constexpr size_t lds = 2 * (size_t)(2 * PLANE + 9 * 2 * COT) * 16;
   static_assert(lds <= 160 * 1024, "two stages must fit the 160 KiB LDS");
-  ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI>, lds);
-  hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI>), grid, dim3(512), lds, st, a);
+  ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI, S2D>, lds);
+  hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI, S2D>), grid, dim3(512), lds, st, a);
 }
 
 }  // namespace
@@ -335,6 +409,11 @@ void conv_bf16_wide_tile(int mbw, int cw, int* th, int* tw) {
 }
 
 void conv_bf16_launch_wide(int mbw, int cw, int epi, dim3 grid, hipStream_t st, const ConvKArgs& a) {
+  if (a.mode0 == ESS_SRC_S2D) {  // (LINEAR, 64- or 128-channel workgroup tiles: the dispatcher offers <2, 2> and <2, 1> only)
+    if (cw == 2) launch_wide_t<2, 2, ESS_EPI_LINEAR, true>(grid, st, a);
+    else launch_wide_t<2, 1, ESS_EPI_LINEAR, true>(grid, st, a);
+    return;
+  }
   if (epi == ESS_EPI_LSTM) { launch_wide_t<2, 2, ESS_EPI_LSTM>(grid, st, a); return; }  // (recurrent epilogues: the dispatcher offers <2, 2> only)
   if (epi == ESS_EPI_GRU_UR) { launch_wide_t<2, 2, ESS_EPI_GRU_UR>(grid, st, a); return; }
   if (epi == ESS_EPI_GRU_OUT) { launch_wide_t<2, 2, ESS_EPI_GRU_OUT>(grid, st, a); return; }

@@ -1271,7 +1271,8 @@ inline int pick_mb(const EssConvDesc* d) {
   // activation staging and the weight re-fetch per MFMA
   // (measured: pays only for the deepest layer -- 512 -> 1024 @ 60x80: 779 -> 859 TFLOP/s; one workgroup per CU hurts the rest)
   static const int mb4_min_cin = [] { const char* e = getenv("ESS_CONV_MB4_MIN_CIN"); return e ? atoi(e) : 512; }();  // (tuning experiments)
-  if (ws_enabled() && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= mb4_min_cin) {
+  if (ws_enabled() && d->compute == ESS_COMPUTE_BF16 && d->ksize == 3 && d->stride == 1 && packed_rows(d) >= 256 && d->C0 + d->C1 >= mb4_min_cin &&
+      d->mode0 != ESS_SRC_S2D) {  // (the space-to-depth form runs on the wide-tile kernel over 64-row slabs)
     static const bool mb4 = [] { const char* e = getenv("ESS_CONV_MB4"); return !(e && e[0] == '0'); }();
     if (mb4) return 4;
   }
@@ -1361,9 +1362,14 @@ inline int validate(const EssConvDesc* d) {
                 d->W_in, d->ksize, d->stride, d->pad);
   for (int s = 0; s < 2; ++s) {
     const int m = s ? d->mode1 : d->mode0;
-    ESS_CHECK_ARG(m >= 0 && m <= 2, "conv: bad source mode");
-    if (m != ESS_SRC_DIRECT) ESS_CHECK_ARG(!(d->H_in & 1) && !(d->W_in & 1), "conv: x2 source needs even extent");
+    ESS_CHECK_ARG(m >= 0 && m <= (s ? 2 : 3), "conv: bad source mode");
+    if (m == ESS_SRC_NEAREST_UP2 || m == ESS_SRC_ZERO_UP2) ESS_CHECK_ARG(!(d->H_in & 1) && !(d->W_in & 1), "conv: x2 source needs even extent");
   }
+  if (d->mode0 == ESS_SRC_S2D)  // the space-to-depth view of a BF16_C8 tensor: 3x3 / stride 1 / pad 1 over 4 x the stored channels
+    ESS_CHECK_ARG(d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->C1 == 0 && (d->C0 % 128) == 0 && (d->C_out % 64) == 0 &&
+                      d->epilogue == ESS_EPI_LINEAR && d->out_split == 0 && d->compute == ESS_COMPUTE_BF16 &&
+                      (d->fmt0 == ESS_FMT_BF16_C8 || d->fmt0 == ESS_FMT_F32_NCHW),
+                  "conv: ESS_SRC_S2D needs 3x3 s1 p1, one source with C0 %% 128 == 0, C_out %% 64 == 0, LINEAR, bf16 compute");
   ESS_CHECK_ARG(d->epilogue >= 0 && d->epilogue <= 3, "conv: bad epilogue");
   ESS_CHECK_ARG(d->compute == ESS_COMPUTE_FP32 || d->compute == ESS_COMPUTE_BF16 || d->compute == ESS_COMPUTE_BF16X3, "conv: bad compute type");
   if (d->compute == ESS_COMPUTE_BF16X3)

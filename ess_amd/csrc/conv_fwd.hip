@@ -194,7 +194,8 @@ extern "C" int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const f
   if (rc) return rc;
   ESS_CHECK_ARG(w && packed, "pack_weights: null pointer");
   ESS_CHECK_ARG(d->epilogue != ESS_EPI_GRU_UR || w2, "pack_weights: GRU_UR needs the reset-gate weight as w2");
-  ESS_CHECK_ARG(w_kind == ESS_W_CONV || w_kind == ESS_W_TRANSPOSED, "pack_weights: bad w_kind");
+  ESS_CHECK_ARG(w_kind == ESS_W_CONV || w_kind == ESS_W_TRANSPOSED || w_kind == ESS_W_CONV5_S2D, "pack_weights: bad w_kind");
+  ESS_CHECK_ARG((w_kind == ESS_W_CONV5_S2D) == (d->mode0 == ESS_SRC_S2D), "pack_weights: ESS_W_CONV5_S2D goes with an ESS_SRC_S2D descriptor, and only with one");
   const ResolvedDesc rd = resolve_compute(d);
   d = &rd.d;
   EssConvPlan pl;
@@ -248,6 +249,7 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   const ResolvedDesc rd = resolve_compute(d);
   d = &rd.d;
   ESS_CHECK_ARG(src0 && packed_w, "conv: null pointer");
+  ESS_CHECK_ARG(d->mode0 != ESS_SRC_S2D || (d->fmt0 == ESS_FMT_BF16_C8 && d->fmt_out == ESS_FMT_BF16_C8), "conv: an ESS_SRC_S2D source is a BF16_C8 tensor, and so is the output");
   ESS_CHECK_ARG(out || (out_bf16 && d->out_split == 0 && (d->epilogue == ESS_EPI_LINEAR || d->epilogue == ESS_EPI_LSTM || d->epilogue == ESS_EPI_GRU_OUT)),
                 "conv: `out` may only be NULL when the BF16_C8 copy is requested (LINEAR / LSTM / GRU_OUT epilogues)");
   ESS_CHECK_ARG(d->C1 == 0 || src1, "conv: second source missing");

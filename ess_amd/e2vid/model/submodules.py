@@ -121,6 +121,12 @@ def _check_eval(mod, norm):
                                   'training/ess_trainer.py:54); call .eval() on the encoder')
 
 
+def _s2d_applies(k, stride, pad, cin, cout, H, W):
+    """Does a convolution of this geometry run as the space-to-depth 3x3 (ESS_SRC_S2D; switch ESS_CONV5_S2D=0: the tap-paired kernel)?"""
+    return (k, stride, pad) == (5, 2, 2) and cin % 32 == 0 and cout % 64 == 0 and H % 2 == 0 and W % 2 == 0 and \
+        os.environ.get('ESS_CONV5_S2D', '1')[:1] != '0'
+
+
 class ConvLayer(nn.Module):
     """conv2d (+BN/IN eval) (+activation) in one kernel.  Reference: submodules.py:7-31."""
 
@@ -179,7 +185,15 @@ class ConvLayer(nn.Module):
         # the fp32 epilogue's optional copy (8-byte stores): the same values (acc * scale + shift, ReLU, round to nearest even)
         as_out = skip_fp32 and residual is None and self.activation in (None, 'relu')
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
-            if as_out:
+            if as_out and _s2d_applies(k, c.stride[0], c.padding[0], C0, c.out_channels, H, W):
+                # 5x5 / stride 2 (the three downsampling convolutions of the frozen encoder, reference submodules.py:176-186) as a 3x3
+                # over the space-to-depth view of the BF16_C8 source, on the wide-tile 3x3 kernel (ESS_SRC_S2D: 16-channel chunks, the
+                # 25 real taps only) instead of the tap-paired 5x5 kernel; the same products, summed in a different order
+                s2 = hip.conv_spec(N, H // 2, W // 2, 4 * C0, 0, c.out_channels, 3, 1, 1, mode0=hip.SRC_S2D, act=_ACT[self.activation])
+                sc2, sh2 = self._fold.get(s2, c.bias, self.norm, getattr(self, 'norm_layer', None))
+                hip.conv_forward(s2, x8, None, packed_weight(s2, wt, kind=hip.W_CONV5_S2D), sc2, sh2, None, out=c8,
+                                 src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)
+            elif as_out:
                 hip.conv_forward(spec, x8, None, packed_weight(spec, wt), scale, shift, None, out=c8, src_fmt=hip.FMT_BF16_C8,
                                  out_fmt=hip.FMT_BF16_C8)
             else:

@@ -14,10 +14,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libess_hip.so')
 
-SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2 = 0, 1, 2
+SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2, SRC_S2D = 0, 1, 2, 3
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
-W_CONV, W_TRANSPOSED, W_ROWS = 0, 1, 2
+W_CONV, W_TRANSPOSED, W_ROWS, W_CONV5_S2D = 0, 1, 2, 3
 COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
 

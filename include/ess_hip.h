@@ -33,7 +33,13 @@ typedef void* ess_stream_t; /* hipStream_t */
 enum { ESS_OK = 0, ESS_EINVAL = -22, ESS_ENOTSUP = -95, ESS_ELAUNCH = -5 };
 
 /* how a conv source is read (fused into the LDS tile load) */
-enum { ESS_SRC_DIRECT = 0, ESS_SRC_NEAREST_UP2 = 1, ESS_SRC_ZERO_UP2 = 2 };
+enum { ESS_SRC_DIRECT = 0, ESS_SRC_NEAREST_UP2 = 1, ESS_SRC_ZERO_UP2 = 2,
+       ESS_SRC_S2D = 3 /* space-to-depth view of a BF16_C8 tensor stored at (2 H_in, 2 W_in) with C0 / 4 channels: virtual channel
+                        * q * (C0/4) + c of virtual pixel (y, x) is stored channel c at (2y + (q & 1), 2x + (q >> 1)).  With weights
+                        * packed as ESS_W_CONV5_S2D a 3x3 / stride 1 / pad 1 descriptor over this view IS the 5x5 / stride 2 / pad 2
+                        * convolution of the stored tensor (nn.Conv2d(k=5, s=2, p=2) of the frozen encoder,
+                        * e2vid/model/submodules.py:176-186, e2vid/model/unet.py:40-47): mode0 only, C1 = 0, fmt0 = fmt_out =
+                        * ESS_FMT_BF16_C8, LINEAR epilogue, bf16 compute, C0 % 128 == 0, C_out % 64 == 0.                       */ };
 /* conv epilogues (fused into the accumulator write-out) */
 enum {
   ESS_EPI_LINEAR = 0,  /* y = act(acc*scale + shift (+ residual))                                   */
@@ -67,9 +73,12 @@ enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
   ESS_W_TRANSPOSED = 1,  /* weight [C_in][C_out][k][k] used spatially flipped: nn.ConvTranspose2d
                             forward, or the data-gradient of a Conv2d (pass its weight)              */
-  ESS_W_ROWS = 2         /* ess_conv2d_pack_weights_multi only: the job's `w` is a per-output-channel vector (a bias,
+  ESS_W_ROWS = 2,        /* ess_conv2d_pack_weights_multi only: the job's `w` is a per-output-channel vector (a bias,
                             C_out floats) and `packed` the float buffer of ess_conv2d_pack_rows (fill 0) -- the
                             biases of the trainable convolutions ride in the weights' re-pack launch       */
+  ESS_W_CONV5_S2D = 3    /* ess_conv2d_pack_weights with an ESS_SRC_S2D descriptor (and only then): w is the 5x5 / stride-2
+                            convolution's weight [C_out][C0 / 4][5][5]; packed as the 3x3 taps of the four parity classes
+                            (tap (ty, tx) of class (py, px) = w[..][2 ty + py][2 tx + px], absent where that index is 5)  */
 };
 
 /* One 2-D convolution over the channel-concatenation of up to two sources.

@@ -75,6 +75,65 @@ C8_CONV_CASES = [
 ]
 
 
+S2D_CASES = [
+    # N, Cin, Cout, H, W (stored source extent), affine + relu
+    (2, 32, 64, 48, 80, True),      # encoder level 0 form (64-channel tiles: <2, 1>)
+    (1, 64, 128, 40, 64, True),     # level 1 (<2, 2> / <2, 1> by round count)
+    (2, 128, 256, 24, 32, True),    # level 2 (128-channel tiles), two chunks of 16 channels... eight per class
+    (1, 32, 64, 22, 38, False),     # ragged tiles (output 11 x 19), bias-free, no activation
+    (8, 32, 64, 480, 640, True),    # the DSEC shape itself (level 0, B = 8): several tiles per persistent workgroup
+]
+
+
+@pytest.mark.parametrize('case', S2D_CASES)
+def test_conv5x5_stride2_space_to_depth(H, case):
+    """The frozen encoder's 5x5 / stride-2 / pad-2 convolutions as a 3x3 over the space-to-depth view of the BF16_C8 source
+    (ESS_SRC_S2D + ESS_W_CONV5_S2D on the wide-tile kernel): against the tap-paired 5x5 kernel on the same BF16_C8 tensor (same bf16
+    operands, fp32 accumulation in another order: one bf16 ulp of the output) and against a plain fp32 torch convolution of the
+    bf16-rounded operands; every element written; refused where the form does not apply."""
+    N, Cin, Cout, Hs, Ws, affine = case
+    H.set_compute('bf16')
+    try:
+        g = torch.Generator().manual_seed(Cin + Hs)
+        x = bfr(torch.randn(N, Cin, Hs, Ws, generator=g))
+        w = torch.randn(Cout, Cin, 5, 5, generator=g) / math.sqrt(Cin * 25)
+        scale = (torch.rand(Cout, generator=g) + 0.5) if affine else None
+        shift = torch.randn(Cout, generator=g) if affine else None
+        act = H.ACT_RELU if affine else H.ACT_NONE
+        x8 = c8(H, x)
+        # the tap-paired kernel (the form every other 5x5 takes)
+        sp5 = H.conv_spec(N, Hs, Ws, Cin, 0, Cout, 5, 2, 2, act=act)
+        o5 = H.bf16_c8_empty(N, Cout, sp5.H_out, sp5.W_out, 'cuda')
+        H.conv_forward(sp5, x8, None, H.pack_weights(sp5, w.cuda()), None if scale is None else H.pack_rows(sp5, scale.cuda(), fill=1.0),
+                       None if shift is None else H.pack_rows(sp5, shift.cuda()), out=o5, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_BF16_C8)
+        # the space-to-depth form
+        sp3 = H.conv_spec(N, Hs // 2, Ws // 2, 4 * Cin, 0, Cout, 3, 1, 1, mode0=H.SRC_S2D, act=act)
+        assert (sp3.H_out, sp3.W_out) == (sp5.H_out, sp5.W_out)
+        o3 = H.bf16_c8_empty(N, Cout, sp3.H_out, sp3.W_out, 'cuda')
+        o3.fill_(float('nan'))
+        pw3 = H.pack_weights(sp3, w.cuda(), kind=H.W_CONV5_S2D)
+        H.conv_forward(sp3, x8, None, pw3, None if scale is None else H.pack_rows(sp3, scale.cuda(), fill=1.0),
+                       None if shift is None else H.pack_rows(sp3, shift.cuda()), out=o3, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_BF16_C8)
+        torch.cuda.synchronize()
+        got = un8(H, o3, Cout)
+        assert not torch.isnan(got).any(), 'elements left unwritten'
+        assert_bf16_close(got, un8(H, o5, Cout), 'space-to-depth vs tap-paired', ulps=1.0, floor=float(got.abs().mean()))
+        if N * Hs * Ws <= 2 * 48 * 80:  # (the CPU convolution of the small cases)
+            ref = F.conv2d(x, bfr(w), None, stride=2, padding=2)
+            if affine:
+                ref = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+            assert_bf16_close(got, bfr(ref), 'space-to-depth vs fp32 torch', ulps=1.0, floor=float(ref.abs().mean()))
+        # refused: the 5x5 pack on this descriptor / the S2D pack on a plain one / a fp32 source
+        with pytest.raises(H.EssHipError):
+            H.pack_weights(sp3, w.cuda())
+        with pytest.raises(H.EssHipError):
+            H.pack_weights(sp5, w.cuda(), kind=H.W_CONV5_S2D)
+        with pytest.raises(H.EssHipError):
+            H.conv_forward(sp3, x.cuda(), None, pw3, out=torch.empty(N, Cout, sp3.H_out, sp3.W_out, device='cuda'))
+    finally:
+        H.set_compute('fp32')
+
+
 @pytest.mark.parametrize('case', C8_CONV_CASES)
 def test_conv_c8_forms(H, case):
     N, C0, C1, Cout, Hv, Wv, k, s, p, m0, m1, act, affine, res, split, src_c8, out_c8 = case

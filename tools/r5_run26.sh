@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 600 python -m pytest tests/test_hip_c8.py -q -m gpu -k "space_to_depth" -x 2>&1 | tail -30
