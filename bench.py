@@ -278,6 +278,34 @@ def roofline_blocks(args, device):
         fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)
         gate_levels.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
         gate_ms += ms; gate_fl += fl
+    # ---- the frozen encoder's 5x5 / stride-2 downsampling convolutions (folded BN + ReLU, BF16_C8 in and out), three levels of one
+    # time step, in the form the product launches (e2vid/model/submodules.py ConvLayer.forward: the space-to-depth 3x3 on the wide-tile
+    # kernel where it applies, else the tap-paired 5x5 kernel)
+    enc_ms = enc_fl = 0.0
+    enc_levels = []
+    if bf16:
+        from ess_amd.e2vid.model.submodules import _s2d_applies
+        for lvl, cin in enumerate((32, 64, 128)):
+            Hs, Ws = args.height >> lvl, args.width >> lvl
+            cout = 2 * cin
+            x8 = hip.to_bf16_c8(torch.relu(torch.randn(B, cin, Hs, Ws, generator=g)).to(device))
+            w = (torch.randn(cout, cin, 5, 5, generator=g) / (25 * cin) ** 0.5).to(device)
+            sc, sh = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
+            s2d = _s2d_applies(5, 2, 2, cin, cout, Hs, Ws)
+            if s2d:
+                spec = hip.conv_spec(B, Hs // 2, Ws // 2, 4 * cin, 0, cout, 3, 1, 1, mode0=hip.SRC_S2D, act=hip.ACT_RELU)
+                pw = hip.pack_weights(spec, w, kind=hip.W_CONV5_S2D)
+            else:
+                spec = hip.conv_spec(B, Hs, Ws, cin, 0, cout, 5, 2, 2, act=hip.ACT_RELU)
+                pw = hip.pack_weights(spec, w)
+            ps, pb = hip.pack_rows(spec, sc, fill=1.0), hip.pack_rows(spec, sh)
+            o8 = hip.bf16_c8_empty(B, cout, spec.H_out, spec.W_out, device)
+            ms = _timed(ev, stream, lambda: hip.conv_forward(spec, x8, None, pw, ps, pb, out=o8, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8))
+            fl = 2.0 * B * spec.H_out * spec.W_out * 25 * cin * cout
+            enc_levels.append({'level': lvl, 'layer': f'{cin}->{cout} 5x5/s2 @{Hs}x{Ws}', 'form': 'space-to-depth 3x3, wide tile' if s2d else 'tap-paired 5x5',
+                               'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1)})
+            enc_ms += ms; enc_fl += fl
+            del x8, o8
     # ---- fused ConvGRU step: (update, reset) kernel + candidate kernel, three encoder levels of one time step
     gru_ms = gru_fl = 0.0
     gru_levels = []
@@ -324,6 +352,10 @@ def roofline_blocks(args, device):
                 'convgru_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, GRU_UR | GRU_OUT, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,GRU_UR | GRU_OUT,8>',
                                  'achieved': round(gru_fl / gru_ms / 1e9, 1), 'frac': round(gru_fl / gru_ms / 1e9 / peak, 4),
                                  **_pmc_summary(t_gru), 'per_level': gru_levels, 'traffic': t_gru},
+                **({'encoder_conv5x5_s2': {'kernel': 'conv_bf16_wide_kernel<2, CW, LINEAR, S2D> (the 5x5 / stride-2 convolutions of the frozen encoder as a 3x3 over '
+                                                     'the space-to-depth view of the BF16_C8 source) | conv_bf16_ws_pair_kernel<5, 2, 1>',
+                                           'achieved': round(enc_fl / enc_ms / 1e9, 1), 'frac': round(enc_fl / enc_ms / 1e9 / peak, 4),
+                                           'ms_per_launch_set': round(enc_ms, 4), 'per_level': enc_levels}} if enc_ms else {}),
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg,

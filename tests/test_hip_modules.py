@@ -587,8 +587,24 @@ def test_full_size_encoder_properties():
             one = run(ev[3:4].contiguous())
             assert all(torch.equal(x[3:4], y) for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
             if mode == 'bf16':
-                c = run(ev, strip_copies=True)
-                assert all(torch.equal(x, y) for x, y in zip(a, c)), 'BF16_C8-staged and fp32-staged encoders differ'
+                # the BF16_C8-staged and the fp32-staged encoder contract the same bf16 operands; on the SAME kernels they are bit-identical.
+                # (The 5x5 / stride-2 convolutions of the BF16_C8-only flow run as the space-to-depth 3x3 -- ESS_SRC_S2D, another summation
+                # order than the tap-paired kernel an fp32-staged step takes -- so the bit comparison is made with that form switched off,
+                # and the two forms are compared with each other at bf16 rounding level.)
+                import os
+                old = os.environ.get('ESS_CONV5_S2D')
+                os.environ['ESS_CONV5_S2D'] = '0'
+                try:
+                    a_pair = run(ev)
+                    c = run(ev, strip_copies=True)
+                finally:
+                    if old is None:
+                        del os.environ['ESS_CONV5_S2D']
+                    else:
+                        os.environ['ESS_CONV5_S2D'] = old
+                assert all(torch.equal(x, y) for x, y in zip(a_pair, c)), 'BF16_C8-staged and fp32-staged encoders differ'
+                assert all(relerr(x, y) < 2e-2 for x, y in zip(a, a_pair)), 'space-to-depth and tap-paired 5x5 / stride-2 forms differ'
+                del a_pair, c
             e = run(ev, lean=True)  # steps t < T-1 advance the state only (no fp32 hidden state / head output is written)
             assert all(torch.equal(x, y) for x, y in zip(a, e)), f'{mode}: lean recurrent steps change the result'
             outs[mode] = a
