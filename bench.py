@@ -284,16 +284,16 @@ def roofline_blocks(args, device):
     enc_ms = enc_fl = 0.0
     enc_levels = []
     if bf16:
-        from ess_amd.e2vid.model.submodules import _s2d_applies
+        from ess_amd.e2vid.model.submodules import _s2d_spec
         for lvl, cin in enumerate((32, 64, 128)):
             Hs, Ws = args.height >> lvl, args.width >> lvl
             cout = 2 * cin
             x8 = hip.to_bf16_c8(torch.relu(torch.randn(B, cin, Hs, Ws, generator=g)).to(device))
             w = (torch.randn(cout, cin, 5, 5, generator=g) / (25 * cin) ** 0.5).to(device)
             sc, sh = (torch.rand(cout, generator=g) + 0.5).to(device), torch.randn(cout, generator=g).to(device)
-            s2d = _s2d_applies(5, 2, 2, cin, cout, Hs, Ws)
+            spec = _s2d_spec(B, 5, 2, 2, cin, cout, Hs, Ws, hip.ACT_RELU)
+            s2d = spec is not None
             if s2d:
-                spec = hip.conv_spec(B, Hs // 2, Ws // 2, 4 * cin, 0, cout, 3, 1, 1, mode0=hip.SRC_S2D, act=hip.ACT_RELU)
                 pw = hip.pack_weights(spec, w, kind=hip.W_CONV5_S2D)
             else:
                 spec = hip.conv_spec(B, Hs, Ws, cin, 0, cout, 5, 2, 2, act=hip.ACT_RELU)

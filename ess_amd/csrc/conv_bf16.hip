@@ -297,6 +297,33 @@ bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const
 }
 }  // namespace
 
+// workgroup tile of the space-to-depth form (ESS_SRC_S2D): 128-channel tiles where the output channels allow and the round count is no
+// worse, else 64-channel tiles; *cw = 0 when C_out is not a multiple of 64
+void conv_bf16_s2d_pick(const EssConvDesc* d, int* cw_out, int* tiles_out, int* tx_out, int* ty_out) {
+  const int cus = tuning().cus;
+  double best = 1e300;
+  *cw_out = 0; *tiles_out = 0; *tx_out = 0; *ty_out = 0;
+  for (int cw = 2; cw >= 1; --cw) {
+    const int cot = 64 * cw;
+    if (d->C_out % cot) continue;
+    int th, tw;
+    conv_bf16_wide_tile(2, cw, &th, &tw);
+    const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
+    const int tiles = tx * ty * (d->C_out / cot) * d->N;
+    const double cost = (double)ceil_div(tiles, cus) * cot * th * tw;
+    if (cost < best) { best = cost; *cw_out = cw; *tiles_out = tiles; *tx_out = tx; *ty_out = ty; }
+  }
+}
+// Is the space-to-depth form the faster one for this launch?  One workgroup per CU on 64 x 640 / 128 x 320 tiles needs a launch that
+// fills the chip: measured against the tap-paired kernel (32-channel x 256-pixel tiles, two workgroups per CU) on the encoder's three
+// levels at B = 1 / 2 / 4 / 8 (tools/s2d_probe.py, profiles/r5_s2d_probe*.txt): 30 / 60 / 120 tiles 0.41 - 0.90 x, 240 tiles 1.09 - 1.22 x,
+// 480 / 960 tiles 1.14 - 1.23 x -> from three quarters of the compute units' worth of tiles on.
+bool conv_bf16_s2d_preferred(const EssConvDesc* d) {
+  int cw, tiles, tx, ty;
+  conv_bf16_s2d_pick(d, &cw, &tiles, &tx, &ty);
+  return cw > 0 && 4 * tiles >= 3 * tuning().cus;
+}
+
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st) {
   ESS_CHECK_ARG(g.IH * g.IW <= kpc(d->ksize, d->stride) * 256, "conv(bf16): input tile of %d positions exceeds the staging capacity",
                 g.IH * g.IW);
@@ -343,17 +370,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
                   "conv(bf16, S2D): BF16_C8 in and out, no residual / copy, act in {none, relu}");
     const int cus = tuning().cus;
     int best_cw = 0, best_tiles = 0, best_tx = 0, best_ty = 0;
-    double best = 1e300;
-    for (int cw = 2; cw >= 1; --cw) {
-      const int cot = 64 * cw;
-      if (d->C_out % cot) continue;
-      int th, tw;
-      conv_bf16_wide_tile(2, cw, &th, &tw);
-      const int tx = ceil_div(d->W_out, tw), ty = ceil_div(d->H_out, th);
-      const int tiles = tx * ty * (d->C_out / cot) * d->N;
-      const double cost = (double)ceil_div(tiles, cus) * cot * th * tw;
-      if (cost < best) { best = cost; best_cw = cw; best_tiles = tiles; best_tx = tx; best_ty = ty; }
-    }
+    conv_bf16_s2d_pick(d, &best_cw, &best_tiles, &best_tx, &best_ty);
     ESS_CHECK_ARG(best_cw > 0, "conv(bf16, S2D): C_out %d is not a multiple of 64", d->C_out);
     ConvKArgs t = a;
     t.tiles_x = best_tx; t.n_tiles = best_tx * best_ty;

@@ -1516,5 +1516,7 @@ int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_ki
                            hipStream_t st, bool split = false);
 int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds, const float* const* w, void* const* packed, int count,
                                  hipStream_t st);
+void conv_bf16_s2d_pick(const EssConvDesc* d, int* cw, int* tiles, int* tiles_x, int* tiles_y);
+bool conv_bf16_s2d_preferred(const EssConvDesc* d);
 
 }  // namespace essconv

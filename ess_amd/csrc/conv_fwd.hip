@@ -188,6 +188,11 @@ extern "C" int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan) {
   return ESS_OK;
 }
 
+extern "C" int ess_conv2d_s2d_preferred(const EssConvDesc* d) {
+  if (validate(d) != ESS_OK || d->mode0 != ESS_SRC_S2D) return 0;
+  return conv_bf16_s2d_preferred(d) ? 1 : 0;
+}
+
 extern "C" int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const float* w, const float* w2, void* packed,
                                        ess_stream_t stream) {
   int rc = validate(d);

@@ -121,10 +121,14 @@ def _check_eval(mod, norm):
                                   'training/ess_trainer.py:54); call .eval() on the encoder')
 
 
-def _s2d_applies(k, stride, pad, cin, cout, H, W):
-    """Does a convolution of this geometry run as the space-to-depth 3x3 (ESS_SRC_S2D; switch ESS_CONV5_S2D=0: the tap-paired kernel)?"""
-    return (k, stride, pad) == (5, 2, 2) and cin % 32 == 0 and cout % 64 == 0 and H % 2 == 0 and W % 2 == 0 and \
-        os.environ.get('ESS_CONV5_S2D', '1')[:1] != '0'
+def _s2d_spec(N, k, stride, pad, cin, cout, H, W, act):
+    """The ESS_SRC_S2D spec of a 5x5 / stride-2 / pad-2 convolution where that form exists AND is the faster one for this launch
+    (hip.s2d_preferred: it needs a launch that fills the chip), else None.  Switch ESS_CONV5_S2D: 0 = never, 2 = wherever it exists."""
+    mode = os.environ.get('ESS_CONV5_S2D', '1')[:1]
+    if (k, stride, pad) != (5, 2, 2) or cin % 32 or cout % 64 or H % 2 or W % 2 or mode == '0':
+        return None
+    s2 = hip.conv_spec(N, H // 2, W // 2, 4 * cin, 0, cout, 3, 1, 1, mode0=hip.SRC_S2D, act=act)
+    return s2 if (mode == '2' or hip.s2d_preferred(s2)) else None
 
 
 class ConvLayer(nn.Module):
@@ -185,11 +189,11 @@ class ConvLayer(nn.Module):
         # the fp32 epilogue's optional copy (8-byte stores): the same values (acc * scale + shift, ReLU, round to nearest even)
         as_out = skip_fp32 and residual is None and self.activation in (None, 'relu')
         if x8 is not None:  # stage from the producer's BF16_C8 copy (bit-identical, cheaper loads)
-            if as_out and _s2d_applies(k, c.stride[0], c.padding[0], C0, c.out_channels, H, W):
+            s2 = _s2d_spec(N, k, c.stride[0], c.padding[0], C0, c.out_channels, H, W, _ACT[self.activation]) if as_out else None
+            if s2 is not None:
                 # 5x5 / stride 2 (the three downsampling convolutions of the frozen encoder, reference submodules.py:176-186) as a 3x3
                 # over the space-to-depth view of the BF16_C8 source, on the wide-tile 3x3 kernel (ESS_SRC_S2D: 16-channel chunks, the
                 # 25 real taps only) instead of the tap-paired 5x5 kernel; the same products, summed in a different order
-                s2 = hip.conv_spec(N, H // 2, W // 2, 4 * C0, 0, c.out_channels, 3, 1, 1, mode0=hip.SRC_S2D, act=_ACT[self.activation])
                 sc2, sh2 = self._fold.get(s2, c.bias, self.norm, getattr(self, 'norm_layer', None))
                 hip.conv_forward(s2, x8, None, packed_weight(s2, wt, kind=hip.W_CONV5_S2D), sc2, sh2, None, out=c8,
                                  src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)

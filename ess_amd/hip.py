@@ -49,7 +49,7 @@ EXPORTS = [
     'ess_from_bf16_c8', 'ess_norm_workspace_c8', 'ess_instnorm_forward_c8', 'ess_instnorm_backward_c8', 'ess_batchnorm_train_forward_c8',
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
     'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices', 'ess_sum_scalars',
-    'ess_label_confusion', 'ess_augment_perspective_filter', 'ess_tuning_set', 'ess_tuning_get',
+    'ess_label_confusion', 'ess_augment_perspective_filter', 'ess_tuning_set', 'ess_tuning_get', 'ess_conv2d_s2d_preferred',
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         D = POINTER(EssConvDesc)
         sig = {
             'ess_conv2d_plan': [D, POINTER(EssConvPlan)],
+            'ess_conv2d_s2d_preferred': [D],
             'ess_conv2d_pack_weights': [D, c_int, P, P, P, P],
             'ess_conv2d_pack_rows': [D, P, P, F, P, P],
             'ess_conv2d_forward': [D, P, P, P, P, P, P, P, P, P, P, P, P],
@@ -212,6 +213,14 @@ def conv_spec(N, H_in, W_in, C0, C1, C_out, k, s, p, mode0=SRC_DIRECT, mode1=SRC
     if sp is None:
         sp = _desc_cache[key] = ConvSpec(key)
     return sp
+
+
+def s2d_preferred(spec):
+    """Is the space-to-depth form (an ESS_SRC_S2D spec) the faster way to run its 5x5 / stride-2 convolution on this device?  (cached)"""
+    v = getattr(spec, '_s2d_pref', None)
+    if v is None:
+        v = spec._s2d_pref = bool(lib().ess_conv2d_s2d_preferred(byref(spec.desc)))
+    return v
 
 
 def spec_of(key):

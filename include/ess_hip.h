@@ -132,6 +132,12 @@ int ess_version(void);
 
 int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
 
+/* 1 when `d` is a valid ESS_SRC_S2D descriptor AND the space-to-depth form is the faster way to run that 5x5 / stride-2 convolution
+ * on this device (its one-workgroup-per-CU tiles need a launch of at least 3/4 of the compute units' worth of tiles: B >= 4 at the
+ * DSEC shape; below that the tap-paired 5x5 kernel wins), else 0.  The caller picks the descriptor (and the weight pack) by it:
+ * ConvLayer.forward of the frozen encoder, e2vid/model/submodules.py:7-31,176-186.                                          */
+int ess_conv2d_s2d_preferred(const EssConvDesc* d);
+
 /* Re-layout a weight tensor for ess_conv2d_forward (tile-major, epilogue row permutation applied).
  * w_kind ESS_W_CONV: w is [C_out][C0+C1][k][k]; ESS_W_TRANSPOSED: w is [C0+C1][C_out][k][k].
  * For ESS_EPI_GRU_UR pass w = update_gate.weight and w2 = reset_gate.weight.                        */

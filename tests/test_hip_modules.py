@@ -585,7 +585,22 @@ def test_full_size_encoder_properties():
             b = run(ev)
             assert all(torch.equal(x, y) for x, y in zip(a, b)), f'{mode}: not deterministic'
             one = run(ev[3:4].contiguous())
-            assert all(torch.equal(x[3:4], y) for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
+            if mode == 'fp32':
+                assert all(torch.equal(x[3:4], y) for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
+            else:
+                # bf16: the 5x5 / stride-2 convolutions run as the space-to-depth 3x3 where the launch fills the chip (B = 8) and on the
+                # tap-paired kernel where it does not (B = 1): the same bf16 products in another fp32 summation order.  Bit-identical
+                # per sample with ONE form on both sides (switch 2: space-to-depth wherever it exists), bf16 rounding level otherwise.
+                assert all(relerr(x[3:4], y) < 2e-2 for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
+                import os
+                os.environ['ESS_CONV5_S2D'] = '2'
+                try:
+                    a2, one2 = run(ev), run(ev[3:4].contiguous())
+                finally:
+                    del os.environ['ESS_CONV5_S2D']
+                assert all(torch.equal(x, y) for x, y in zip(a, a2)), 'forcing the space-to-depth form changes a launch that already took it'
+                assert all(torch.equal(x[3:4], y) for x, y in zip(a2, one2)), f'{mode}: sample 3 depends on its batch (one form on both sides)'
+                del a2, one2
             if mode == 'bf16':
                 # the BF16_C8-staged and the fp32-staged encoder contract the same bf16 operands; on the SAME kernels they are bit-identical.
                 # (The 5x5 / stride-2 convolutions of the BF16_C8-only flow run as the space-to-depth 3x3 -- ESS_SRC_S2D, another summation
