@@ -366,7 +366,7 @@ def roofline_blocks(args, device):
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
                     '; HIP events on the launch stream, inside this process after the timed steps; launch sets repeated back to back, i.e. '
                     'at the sustained-matrix-load clock (the same kernels inside the step, between HBM-bound launches, run 5-20 % faster: '
-                    'rocprofv3 averages in profiles/r4_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7d)'}
+                    'rocprofv3 averages in profiles/r5b_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7d / 7e)'}
 
 
 def executed_flops_per_step(args):
