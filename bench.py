@@ -311,8 +311,9 @@ def roofline_blocks(args, device):
     gru_levels = []
     for lvl, hid in enumerate((64, 128, 256)):
         H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
-        s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
-        s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+        uact = hip.GRU_U_F16 if (bf16 and os.environ.get('ESS_GRU_U16', '1')[:1] != '0') else hip.GRU_U_F32  # (as ConvGRU.forward)
+        s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=uact, hidden=hid)
+        s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=uact, hidden=hid)
         wu, wr, wo = [(torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device) for _ in range(3)]
         bu, br, bo = [torch.randn(hid, generator=g).to(device) for _ in range(3)]
         x, h = [torch.randn(B, hid, H, W, generator=g).to(device) for _ in range(2)]
@@ -320,10 +321,11 @@ def roofline_blocks(args, device):
         pb1, pb2 = hip.pack_rows(s1, bu, br), hip.pack_rows(s2, bo)
         if bf16:
             # exactly the product launches of the time steps t < T-1 (ConvGRU.forward, lean): BF16_C8 x / h / r*h, channel-blocked
-            # fp32 h_prev / u / h', BF16_C8 copy of h'
+            # fp32 h_prev / h', the update gate u as an F16_C8 tensor (ESS_GRU_U_F16), BF16_C8 copy of h'
             x8, h8 = hip.to_bf16_c8(x), hip.to_bf16_c8(h)
             hb = h.view(B, hid // 8, 8, H, W).permute(0, 1, 3, 4, 2).contiguous()
-            u, hn = hip.f32_c8_empty(B, hid, H, W, device), hip.f32_c8_empty(B, hid, H, W, device)
+            u = (hip.f16_c8_raw_empty if uact == hip.GRU_U_F16 else hip.f32_c8_empty)(B, hid, H, W, device)
+            hn = hip.f32_c8_empty(B, hid, H, W, device)
             rh8, hn8 = hip.bf16_c8_empty(B, hid, H, W, device), hip.bf16_c8_empty(B, hid, H, W, device)
             f1 = lambda: hip.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=hip.FMT_BF16_C8,
                                           out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)

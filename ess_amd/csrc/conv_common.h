@@ -348,7 +348,10 @@ __device__ __forceinline__ void conv_epilogue_gru_ur(const ConvKArgs& a, f32x16 
         const int hb = (ct * MB + mb) * 2 + q2;
         float u[4], rh[4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) u[jj] = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + sh[8 * q2 + jj]);
+        for (int jj = 0; jj < 4; ++jj) {
+          u[jj] = ess_sigmoid(acc[mb][nb][8 * q2 + jj] + sh[8 * q2 + jj]);
+          if (a.act == ESS_GRU_U_F16) u[jj] = (float)(_Float16)u[jj];  // (uniform) the value the F16_C8 form of u carries, in an fp32 tensor
+        }
         ess_state_store4(u_io, hb, pixi[nb], half, voff[nb], u);
         if (need_r) {  // (uniform)
 #pragma unroll
@@ -377,6 +380,8 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
   const EssStateIO o_io = ess_state_io(a.out, a.wpk, n, a.hid, HW, out8);
   const ess_rsrc r_sh = ess_make_rsrc(a.shift, (size_t)(a.n_cout_tiles * COT) * 4);
   const int nbh = (a.hid + 7) >> 3;
+  const bool u16 = a.act == ESS_GRU_U_F16 && in8;
+  const ess_rsrc r_u16 = ess_make_rsrc(u16 ? (const char*)a.aux1 + (size_t)n * nbh * HW * 16 : (const char*)a.wpk, u16 ? (size_t)nbh * HW * 16 : 0);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     const int rowbase = ct * COT + mb * 32;
@@ -390,7 +395,17 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ess_state_load4(h_io, (ct * MB + mb) * 4 + j, pixi[nb], half, voff[nb], hv[j]);
-        ess_state_load4(u_io, (ct * MB + mb) * 4 + j, pixi[nb], half, voff[nb], uv[j]);
+        if (u16) {  // (uniform) u is an F16_C8 tensor (ESS_GRU_U_F16 with channel-blocked inputs): this lane's 4 channels = 8 bytes
+          typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
+          typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+          const int hb = (ct * MB + mb) * 4 + j;
+          const unsigned ou = (pixi[nb] >= 0 && hb < nbh) ? ((unsigned)hb * HW + (unsigned)pixi[nb]) * 16u + 8u * half : ESS_OOB;
+          const f16x4e uh = __builtin_bit_cast(f16x4e, (u32x2c)__builtin_amdgcn_raw_buffer_load_b64(r_u16, (int)ou, 0, ESS_GRU_AUX));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) uv[j][jj] = (float)uh[jj];
+        } else {
+          ess_state_load4(u_io, (ct * MB + mb) * 4 + j, pixi[nb], half, voff[nb], uv[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -418,11 +433,14 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
                                                         const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
   const int nbh = a.hid >> 3;
   const size_t state_b = (size_t)nbh * HW * 32;
   const bool need_r = a.out_bf != nullptr;
+  const bool u16 = a.act == ESS_GRU_U_F16;  // (uniform) u leaves as an F16_C8 tensor: 16 instead of 32 bytes per pixel and 8-channel block
   const ess_rsrc r_h = ess_make_rsrc((a.aux0 && need_r) ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.out, (a.aux0 && need_r) ? state_b : 0);
-  const ess_rsrc r_u = ess_make_rsrc(a.out + (size_t)n * nbh * 8 * HW, state_b);
+  const ess_rsrc r_u = u16 ? ess_make_rsrc((const char*)a.out + (size_t)n * nbh * HW * 16, (size_t)nbh * HW * 16)
+                           : ess_make_rsrc(a.out + (size_t)n * nbh * 8 * HW, state_b);
   const ess_rsrc r_rb = ess_make_rsrc(need_r ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.out, need_r ? (size_t)nbh * HW * 16 : 0);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -437,18 +455,29 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
         hp[nb][q2] = __builtin_amdgcn_raw_buffer_load_b128(r_h, (int)vo[nb][q2], 0, ESS_GRU_AUX);  // (absent / unused: zeros)
       }
       __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from sinking the loads to their first use)
-      uint2 pk[2];
+      uint2 pk[2], pu[2];
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         u32x4c uv;
         bf16x4 rb;
+        f16x4e uh;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          uv[jj] = __builtin_bit_cast(unsigned, ess_sigmoid(acc[mb][nb][8 * q2 + jj]));
+          const float ug = ess_sigmoid(acc[mb][nb][8 * q2 + jj]);
+          uv[jj] = __builtin_bit_cast(unsigned, ug);
+          uh[jj] = (_Float16)ug;
           if (need_r) rb[jj] = (__bf16)(ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj]) * __builtin_bit_cast(float, (unsigned)hp[nb][q2][jj]));
         }
-        __builtin_amdgcn_raw_buffer_store_b128(uv, r_u, (int)vo[nb][q2], 0, ESS_GRU_AUX);
+        if (!u16) __builtin_amdgcn_raw_buffer_store_b128(uv, r_u, (int)vo[nb][q2], 0, ESS_GRU_AUX);
         pk[q2] = __builtin_bit_cast(uint2, rb);
+        pu[q2] = __builtin_bit_cast(uint2, uh);
+      }
+      if (u16) {  // (uniform) whole pixel vectors, as r*h below: lanes 0-31 hidden block 2 (ct MB + mb), lanes 32-63 the next one
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pu[0].x, pu[1].x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pu[0].y, pu[1].y, false, false);
+        const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};
+        const unsigned o = pixi[nb] >= 0 ? ((unsigned)((ct * MB + mb) * 2 + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(vec, r_u, (int)o, 0, ESS_GRU_AUX);
       }
       if (need_r) {  // (uniform) lanes 0-31: hidden block 2 (ct MB + mb), lanes 32-63: the next one
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
@@ -469,7 +498,9 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
   const int nbh = a.hid >> 3;
   const size_t state_b = (size_t)nbh * HW * 32;
   const ess_rsrc r_h = ess_make_rsrc(a.aux0 ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.aux1, a.aux0 ? state_b : 0);
-  const ess_rsrc r_u = ess_make_rsrc(a.aux1 + (size_t)n * nbh * 8 * HW, state_b);
+  const bool u16 = a.act == ESS_GRU_U_F16;  // (uniform) u arrives as an F16_C8 tensor
+  const ess_rsrc r_u = u16 ? ess_make_rsrc((const char*)a.aux1 + (size_t)n * nbh * HW * 16, (size_t)nbh * HW * 16)
+                           : ess_make_rsrc(a.aux1 + (size_t)n * nbh * 8 * HW, state_b);
   const ess_rsrc r_o = ess_make_rsrc(a.out ? (const char*)(a.out + (size_t)n * nbh * 8 * HW) : (const char*)a.aux1, a.out ? state_b : 0);
   const ess_rsrc r_ob = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.aux1, a.out_bf ? (size_t)nbh * HW * 16 : 0);
 #pragma unroll
@@ -483,9 +514,36 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
         const int hb = (ct * MB + mb) * 4 + j;
         vo[j] = pixi[nb] >= 0 ? ((unsigned)hb * HW + (unsigned)pixi[nb]) * 32u + 16u * half : ESS_OOB;
         hv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_h, (int)vo[j], 0, ESS_GRU_AUX);
-        uv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_u, (int)vo[j], 0, ESS_GRU_AUX);
+        if (u16) {
+          // whole 16-byte pixel vectors, the mirror image of the (update, reset) kernel's store: lanes 0-31 fetch hidden block j, lanes
+          // 32-63 block j + 1 (j even), and a half-wave swap behind the barrier hands every lane its 4 channels of both blocks.
+          // (8-byte loads of the lane's own 4 channels -- two half-waves interleaved at 8-byte granularity -- measured + 10 us per
+          // launch over the fp32 form they were meant to beat; a conversion right here waits for each load in turn: + 15 us.)
+          if ((j & 1) == 0) {
+            const unsigned ou = pixi[nb] >= 0 ? ((unsigned)(hb + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
+            uv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_u, (int)ou, 0, ESS_GRU_AUX);
+          }
+        } else {
+          uv[j] = __builtin_amdgcn_raw_buffer_load_b128(r_u, (int)vo[j], 0, ESS_GRU_AUX);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (u16) {  // (uniform) swap, then 4 halfs in two registers -> 4 fp32 bit patterns
+        typedef _Float16 f16x2e __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap((unsigned)uv[j][0], (unsigned)uv[j][2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap((unsigned)uv[j][1], (unsigned)uv[j][3], false, false);
+          uv[j][0] = s0[0]; uv[j][1] = s1[0];          // block j:     this lane's channels 4 half .. + 3
+          uv[j + 1][0] = s0[1]; uv[j + 1][1] = s1[1];  // block j + 1
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f16x2e lo = __builtin_bit_cast(f16x2e, (unsigned)uv[j][0]), hi = __builtin_bit_cast(f16x2e, (unsigned)uv[j][1]);
+          uv[j][0] = __builtin_bit_cast(unsigned, (float)lo[0]); uv[j][1] = __builtin_bit_cast(unsigned, (float)lo[1]);
+          uv[j][2] = __builtin_bit_cast(unsigned, (float)hi[0]); uv[j][3] = __builtin_bit_cast(unsigned, (float)hi[1]);
+        }
+      }
       uint2 pk[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1405,6 +1463,7 @@ inline int validate(const EssConvDesc* d) {
     return ESS_OK;
   }
   if (d->epilogue == ESS_EPI_GRU_UR || d->epilogue == ESS_EPI_GRU_OUT) {
+    ESS_CHECK_ARG(d->act == ESS_GRU_U_F32 || (d->act == ESS_GRU_U_F16 && d->compute == ESS_COMPUTE_BF16), "conv(GRU): act is ESS_GRU_U_F32 or (bf16 compute) ESS_GRU_U_F16");
     // fmt_res describes h_prev (aux0) and, in the candidate kernel, u (aux1); fmt_out the fp32 outputs (u and r*h | h')
     ESS_CHECK_ARG((d->fmt_out == ESS_FMT_F32_NCHW || d->fmt_out == ESS_FMT_F32_C8) && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_F32_C8),
                   "conv(GRU): state tensors are ESS_FMT_F32_NCHW or ESS_FMT_F32_C8");

@@ -276,6 +276,12 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   EssConvPlan pl;
   make_plan(d, &pl, rd.split);
   ESS_CHECK_ARG(pl.lds_bytes <= 160 * 1024, "conv: LDS tile %d B exceeds 160 KiB", pl.lds_bytes);
+  if (d->epilogue == ESS_EPI_GRU_UR && d->act == ESS_GRU_U_F16 && d->fmt_out == ESS_FMT_F32_C8)
+    // an F16_C8 update gate is WRITTEN by the straight-line (update, reset) epilogue only (conv_epilogue in conv_common.h): its conditions.
+    // (The candidate launch reads it in either epilogue form.)
+    ESS_CHECK_ARG(shift && d->fmt0 == ESS_FMT_BF16_C8 && (d->hidden % (pl.cout_tile / 2)) == 0 && out && !out2 && (!aux0 || d->fmt_res == ESS_FMT_F32_C8),
+                  "conv(GRU_UR): an F16_C8 update gate (ESS_GRU_U_F16 with channel-blocked outputs) needs BF16_C8 sources, a bias, hidden %% %d == 0, "
+                  "no fp32 r*h output and a channel-blocked h_prev", pl.cout_tile / 2);
   const Geom g = choose_geom(d);
   ConvKArgs a{};
   a.src0 = (const float*)src0; a.src1 = (const float*)src1; a.wpk = packed_w;

@@ -875,6 +875,8 @@ inline EssConvDesc s2_phase_desc(const EssConvDesc* d) {
 int wvalidate(const EssConvDesc* d) {
   ESS_CHECK_ARG(d != nullptr, "wgrad: null descriptor");
   ESS_CHECK_ARG(d->epilogue == ESS_EPI_LINEAR && d->out_split == 0, "wgrad: only plain convolutions have a weight gradient here");
+  ESS_CHECK_ARG(d->mode0 >= ESS_SRC_DIRECT && d->mode0 <= ESS_SRC_ZERO_UP2 && d->mode1 >= ESS_SRC_DIRECT && d->mode1 <= ESS_SRC_ZERO_UP2,
+                "wgrad: source modes DIRECT / NEAREST_UP2 / ZERO_UP2 only (the space-to-depth form exists for the frozen encoder's forward)");
   const int cin = d->C0 + d->C1;
   const bool taps = cin == 1 && d->ksize == 7;
   ESS_CHECK_ARG(taps || d->ksize == 1 || d->ksize == 3, "wgrad: k=%d with C_in=%d unsupported", d->ksize, cin);

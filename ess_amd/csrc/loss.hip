@@ -148,7 +148,8 @@ __global__ void task_loss_value_kernel(const double* ws, float* loss, float scal
 // to zero for the next call.  Contract (include/ess_hip.h): ESS_LOSS_WORKSPACE_BYTES, counter zero before the FIRST use.  Replaces
 // memset + kernel (atomicAdd on one double) + finalize kernel: three graph nodes per loss term became one (a node boundary of the
 // replayed step costs 1.55 us, profiles/r5_graph_gap_probe.txt; memset and finalize ran 4.7 + 5.1 us).
-constexpr int LOSS_MAX_BLOCKS = 2048;
+constexpr int LOSS_MAX_BLOCKS = 2048;  // = the grid cap of the launches below (wave_uniform_grid(.., LOSS_MAX_BLOCKS)) = partial slots of ESS_LOSS_WORKSPACE_BYTES
+static_assert(8 * (1 + LOSS_MAX_BLOCKS) == ESS_LOSS_WORKSPACE_BYTES, "loss workspace contract");
 __device__ __forceinline__ void mean_finish(double block_acc, double* ws, float* loss, double denom, float scale, double* red) {
   __shared__ int s_last;
   if (threadIdx.x == 0) {
@@ -390,10 +391,10 @@ extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, floa
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * hw;
   if (K <= 16)
-    hipLaunchKernelGGL((sym_js_kernel<16>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+    hipLaunchKernelGGL((sym_js_kernel<16>), dim3(wave_uniform_grid(total, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
                        loss_scale, N, K, hw, loss);
   else
-    hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+    hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
                        loss_scale, N, K, hw, loss);
   return ess_launch_status("sym_js_loss");
 }
@@ -403,10 +404,10 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
   ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0)
-    hipLaunchKernelGGL(l1_x4_kernel, dim3(wave_uniform_grid((size_t)n / 4, 2048)), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b,
+    hipLaunchKernelGGL(l1_x4_kernel, dim3(wave_uniform_grid((size_t)n / 4, LOSS_MAX_BLOCKS)), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b,
                        (double*)workspace, (f32x4*)da, loss_scale, n / 4, n, loss);
   else
-    hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, 2048)), dim3(256), 0, st, a, b, (double*)workspace, da,
+    hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
                        loss_scale, n, loss);
   return ess_launch_status("l1_loss");
 }
@@ -416,7 +417,7 @@ extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* d
   ESS_CHECK_ARG(a && b && loss && workspace && n_vectors > 0 && n > 0 && n <= 8 * n_vectors, "l1_loss_c8: bad arguments");
   ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0, "l1_loss_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(l1_c8_kernel, dim3(wave_uniform_grid((size_t)n_vectors, 2048)), dim3(256), 0, st, (const uint4*)a, (const uint4*)b,
+  hipLaunchKernelGGL(l1_c8_kernel, dim3(wave_uniform_grid((size_t)n_vectors, LOSS_MAX_BLOCKS)), dim3(256), 0, st, (const uint4*)a, (const uint4*)b,
                      (double*)workspace, (uint4*)da, loss_scale, n_vectors, n, loss);
   return ess_launch_status("l1_loss_c8");
 }

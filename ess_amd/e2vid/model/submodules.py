@@ -480,8 +480,17 @@ class ConvGRU(nn.Module):
         # both kernels run over x alone with the x columns of the weights (half the MFMA work, no zero tensors; the reset rows of
         # the first kernel are computed and dropped)
         C1 = 0 if first else hid
-        s1 = hip.conv_spec(N, H, W, C, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
-        s2 = hip.conv_spec(N, H, W, C, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+        # bf16 arithmetic: the update gate travels between the two launches rounded to IEEE half (ESS_GRU_U_F16: an F16_C8 tensor where
+        # the states are channel-blocked, the rounded value in the fp32 tensor otherwise -- the same bits either way); switch ESS_GRU_U16=0
+        uact = hip.GRU_U_F16 if (hip.get_compute() == 'bf16' and os.environ.get('ESS_GRU_U16', '1')[:1] != '0') else hip.GRU_U_F32
+        s1 = hip.conv_spec(N, H, W, C, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=uact, hidden=hid)
+        s2 = hip.conv_spec(N, H, W, C, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=uact, hidden=hid)
+        if uact == hip.GRU_U_F16 and hid % (s1.plan.cout_tile // 2):
+            # (an F16_C8 u exists in the straight-line epilogues only: every hidden channel of a workgroup's tile real -- the library
+            # refuses the combination otherwise; E2VID's 64 / 128 / 256 hidden channels qualify)
+            uact = hip.GRU_U_F32
+            s1 = hip.conv_spec(N, H, W, C, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=uact, hidden=hid)
+            s2 = hip.conv_spec(N, H, W, C, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=uact, hidden=hid)
         b1, b2 = self._biases(s1, s2)
         if first:
             wu, wr, wo = self._x_columns(C)
@@ -498,7 +507,10 @@ class ConvGRU(nn.Module):
                 h32, afmt = hb, hip.FMT_F32_C8
             else:
                 h32, afmt = _fp32(prev_state), hip.FMT_F32_NCHW
-            u = hip.f32_c8_empty(N, hid, H, W, dev) if afmt == hip.FMT_F32_C8 else torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+            if afmt == hip.FMT_F32_C8:
+                u = hip.f16_c8_raw_empty(N, hid, H, W, dev) if s1.desc.act == hip.GRU_U_F16 else hip.f32_c8_empty(N, hid, H, W, dev)
+            else:
+                u = torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
             rh8 = None if first else hip.bf16_c8_empty(N, hid, H, W, dev)
             hip.conv_forward(s1, x8, h8, pw1, None, b1, aux0=h32, out=u, out2=None, out_bf=rh8, src_fmt=hip.FMT_BF16_C8,
                              out_fmt=afmt, aux_fmt=afmt)

@@ -18,6 +18,7 @@ SRC_DIRECT, SRC_NEAREST_UP2, SRC_ZERO_UP2, SRC_S2D = 0, 1, 2, 3
 EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED, W_ROWS, W_CONV5_S2D = 0, 1, 2, 3
+GRU_U_F32, GRU_U_F16 = 0, 1
 COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
 
@@ -272,9 +273,13 @@ def conv_forward(spec, src0, src1, packed_w, scale=None, shift=None, residual=No
     rdt = torch.bfloat16 if out_fmt in (FMT_BF16_C8, FMT_F16_C8) else torch.float32  # (an F16_C8 output takes a BF16_C8 residual)
     res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else ((FMT_BF16_C8 if out_fmt == FMT_F16_C8 else out_fmt) if residual is not None else FMT_F32_NCHW)
     desc = spec.desc if (src_fmt, out_fmt, res_fmt) == (FMT_F32_NCHW,) * 3 else spec.desc_fmt(src_fmt, out_fmt, res_fmt)
+    # ConvGRU with ESS_GRU_U_F16 and channel-blocked states: the update gate (out of GRU_UR, aux1 of GRU_OUT) is an IEEE-half tensor
+    u16 = spec.desc.act == GRU_U_F16 and spec.desc.epilogue in (EPI_GRU_UR, EPI_GRU_OUT)
+    udt_out = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_UR and out_fmt == FMT_F32_C8) else odt
+    udt_aux = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_OUT and res_fmt == FMT_F32_C8) else torch.float32
     _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt),
-                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, rdt), ptr(aux0), ptr(aux1),
-                                    ptr(out, odt), ptr(out2, odt), ptr(out_bf, torch.bfloat16), stream()),
+                                    ptr(packed_w, torch.uint8), ptr(scale), ptr(shift), ptr(residual, rdt), ptr(aux0), ptr(aux1, udt_aux),
+                                    ptr(out, udt_out), ptr(out2, odt), ptr(out_bf, torch.bfloat16), stream()),
            'ess_conv2d_forward')
     return out
 
@@ -292,6 +297,12 @@ def c8_stageable(ksize, stride, pad):
 def bf16_c8_empty(N, C, H, W, device):
     """Uninitialised BF16_C8 tensor for a logical [N, C, H, W] activation: bf16 [N][ceil(C/8)][H][W][8]."""
     return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.bfloat16, device=device)
+
+
+def f16_c8_raw_empty(N, C, H, W, device):
+    """Uninitialised IEEE-half [N][ceil(C/8)][H][W][8] tensor that only kernels read (ConvGRU: the update gate between its two
+    launches, ESS_GRU_U_F16)."""
+    return torch.empty(N, (C + 7) // 8, H, W, 8, dtype=torch.float16, device=device)
 
 
 def f32_c8_empty(N, C, H, W, device):

@@ -68,6 +68,12 @@ enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1,
  * kernel reads (x of ess_instnorm_* / ess_batchnorm_train_*_c8 with x_f16 = 1): pre-normalisation tensors keep 11 significant bits. */
 enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3,
        ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / ConvGRU hidden states between time steps (recurrent epilogues only) */ };
+/* ConvGRU: the update gate u between the (update, reset) kernel and the candidate kernel (EssConvDesc.act of the two GRU epilogues).
+ * ESS_GRU_U_F16: u is rounded to IEEE half (11 significant bits of a value in (0, 1); the gates come from bf16 operands) -- with
+ * fmt_out / fmt_res = ESS_FMT_F32_C8 the tensor itself is an F16_C8 tensor ([N][hid/8][H][W][8] halfs: half the bytes of the launch
+ * pair's most bandwidth-bound operand), with fp32 NCHW states the fp32 tensor carries the rounded value, so that a sequence gives the
+ * same bits whichever storage its steps use.  bf16 compute only.  Reference: e2vid/model/submodules.py:255-273 (`update`).          */
+enum { ESS_GRU_U_F32 = 0, ESS_GRU_U_F16 = 1 };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -97,7 +103,8 @@ typedef struct EssConvDesc {
   int32_t C_out, H_out, W_out;
   int32_t ksize, stride, pad;
   int32_t epilogue;     /* ESS_EPI_*                                                                 */
-  int32_t act;          /* ESS_ACT_* (LINEAR epilogue only)                                          */
+  int32_t act;          /* ESS_ACT_* (LINEAR epilogue); GRU epilogues: ESS_GRU_U_* -- how the update gate u travels
+                           from the GRU_UR launch to the GRU_OUT launch (both launches carry the same value)  */
   int32_t hidden;       /* recurrent epilogues: hidden channels (C_out = 4*hidden LSTM, 2*hidden
                            GRU_UR, hidden GRU_OUT)                                                   */
   int32_t out_split;    /* LINEAR: >0 writes channels [0,out_split) to `out` and the rest to `out2`

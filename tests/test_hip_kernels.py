@@ -968,6 +968,75 @@ def test_conv_wide_tile_gru_bit_identical(H, case):
     assert relerr(got, ref) < 2e-3
 
 
+@pytest.mark.parametrize('case', [(2, 64, 24, 40), (1, 128, 40, 48), (2, 256, 20, 32)])
+def test_conv_gru_update_gate_as_half(H, case):
+    """ESS_GRU_U_F16: the update gate between the two ConvGRU launches as an F16_C8 tensor (channel-blocked states, straight-line
+    epilogues; ws and wide-tile kernels) and as the rounded value in an fp32 NCHW tensor (general epilogues): the SAME h' bit for
+    bit in both storage forms and on both kernels; u itself = the IEEE-half rounding of the F32 form's u; h' within 2^-11 of the
+    F32-gate step (u in (0, 1), |h'| blend of h and tanh); refused where the straight-line epilogue does not apply."""
+    N, hid, Hh, Ww = case
+    g = torch.Generator().manual_seed(hid + Hh)
+    x = torch.randn(N, hid, Hh, Ww, generator=g).bfloat16().float()
+    hprev = torch.randn(N, hid, Hh, Ww, generator=g)
+    x8, h8 = H.to_bf16_c8(dev(x)), H.to_bf16_c8(dev(hprev))
+    hb = dev(hprev.view(N, hid // 8, 8, Hh, Ww).permute(0, 1, 3, 4, 2).contiguous())
+    wu, wr, wo = [torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5 for _ in range(3)]
+    bu, br, bo = [torch.randn(hid, generator=g) for _ in range(3)]
+
+    def specs(act):
+        s1 = H.conv_spec(N, Hh, Ww, hid, hid, 2 * hid, 3, 1, 1, epi=H.EPI_GRU_UR, act=act, hidden=hid, compute=H.COMPUTE_BF16)
+        s2 = H.conv_spec(N, Hh, Ww, hid, hid, hid, 3, 1, 1, epi=H.EPI_GRU_OUT, act=act, hidden=hid, compute=H.COMPUTE_BF16)
+        return s1, s2, H.pack_weights(s1, dev(wu), dev(wr)), H.pack_weights(s2, dev(wo)), H.pack_rows(s1, dev(bu), dev(br)), H.pack_rows(s2, dev(bo))
+
+    def blocked(act):
+        s1, s2, pw1, pw2, pb1, pb2 = specs(act)
+        u = (H.f16_c8_raw_empty if act == H.GRU_U_F16 else H.f32_c8_empty)(N, hid, Hh, Ww, 'cuda')
+        u.fill_(float('nan'))
+        hn = H.f32_c8_empty(N, hid, Hh, Ww, 'cuda')
+        rh8, hn8 = H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda'), H.bf16_c8_empty(N, hid, Hh, Ww, 'cuda')
+        H.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=hb, out=u, out_bf=rh8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8, aux_fmt=H.FMT_F32_C8)
+        H.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8,
+                       aux_fmt=H.FMT_F32_C8)
+        torch.cuda.synchronize()
+        un = lambda t: t.float().cpu().permute(0, 1, 4, 2, 3).reshape(N, hid, Hh, Ww)  # noqa: E731
+        return un(u), un(hn), hn8.view(torch.int16).clone()
+
+    def planes(act):
+        s1, s2, pw1, pw2, pb1, pb2 = specs(act)
+        u, rh, hn = [torch.empty(N, hid, Hh, Ww, device='cuda') for _ in range(3)]
+        H.conv_forward(s1, x8, h8, pw1, None, pb1, aux0=dev(hprev), out=u, out2=rh, src_fmt=H.FMT_BF16_C8)
+        rh8 = H.to_bf16_c8(rh)
+        H.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=dev(hprev), aux1=u, out=hn, src_fmt=H.FMT_BF16_C8)
+        torch.cuda.synchronize()
+        return u.cpu(), hn.cpu()
+
+    prev = H.tuning_get('conv_wide')
+    try:
+        res = {}
+        for mode in WIDE_SETTINGS:
+            H.tuning_set('conv_wide', mode)
+            res[mode] = (blocked(H.GRU_U_F16), blocked(H.GRU_U_F32))
+    finally:
+        H.tuning_set('conv_wide', prev)
+    (u16, h16, c16), (u32, h32, _) = res[WIDE_SETTINGS[0]]
+    for mode in WIDE_SETTINGS[1:]:
+        assert torch.equal(res[mode][0][0], u16) and torch.equal(res[mode][0][1], h16) and torch.equal(res[mode][0][2], c16), mode
+    assert not torch.isnan(u16).any() and torch.equal(u16, u32.half().float()), 'u is not the half rounding of the fp32 gate'
+    assert float((h16 - h32).abs().max()) < 2.0 ** -10 * float(torch.maximum(hprev.abs().max(), torch.tensor(1.0)))
+    up, hp = planes(H.GRU_U_F16)
+    assert torch.equal(up, u16) and torch.equal(hp, h16), 'fp32-plane form (general epilogues) and F16_C8 form (straight-line epilogues) differ'
+    # refused: an F16_C8 gate where a tile would hold padded hidden channels (hid = 40), and under fp32 compute
+    with pytest.raises(H.EssHipError):
+        s1 = H.conv_spec(1, 8, 16, 40, 40, 80, 3, 1, 1, epi=H.EPI_GRU_UR, act=H.GRU_U_F16, hidden=40, compute=H.COMPUTE_BF16)
+        H.conv_forward(s1, H.bf16_c8_empty(1, 40, 8, 16, 'cuda'), H.bf16_c8_empty(1, 40, 8, 16, 'cuda'),
+                       H.pack_weights(s1, dev(torch.zeros(40, 80, 3, 3)), dev(torch.zeros(40, 80, 3, 3))), None,
+                       H.pack_rows(s1, dev(torch.zeros(40)), dev(torch.zeros(40))), aux0=H.f32_c8_empty(1, 40, 8, 16, 'cuda'),
+                       out=H.f16_c8_raw_empty(1, 40, 8, 16, 'cuda'), out_bf=H.bf16_c8_empty(1, 40, 8, 16, 'cuda'),
+                       src_fmt=H.FMT_BF16_C8, out_fmt=H.FMT_F32_C8, aux_fmt=H.FMT_F32_C8)
+    with pytest.raises(H.EssHipError):
+        H.conv_spec(1, 8, 16, 64, 64, 128, 3, 1, 1, epi=H.EPI_GRU_UR, act=H.GRU_U_F16, hidden=64, compute=H.COMPUTE_FP32)
+
+
 @pytest.mark.parametrize('case', WIDE_CASES)
 def test_conv_wide_tile_bit_identical(H, case):
     N, C0, C1, Co, Hh, Ww, m0, form = case
