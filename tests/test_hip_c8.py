@@ -81,6 +81,7 @@ S2D_CASES = [
     (1, 64, 128, 40, 64, True),     # level 1 (<2, 2> / <2, 1> by round count)
     (2, 128, 256, 24, 32, True),    # level 2 (128-channel tiles), two chunks of 16 channels... eight per class
     (1, 32, 64, 22, 38, False),     # ragged tiles (output 11 x 19), bias-free, no activation
+    (3, 96, 192, 26, 34, True),     # six chunks per class, 192 output channels (64-channel workgroup tiles only), ragged
     (8, 32, 64, 480, 640, True),    # the DSEC shape itself (level 0, B = 8): several tiles per persistent workgroup
 ]
 
