@@ -150,10 +150,10 @@ def decoder_conv3x3_layers(args):
 
 def _traffic_from_profiles(tag):
     """HBM bytes per launch set and the SQ-counter readings of the same launches (mfma_busy, sclk, LDS) from the PMC passes of
-    tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r5_traffic.json (r4 / r3 as fall-backs)
+    tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r5b_traffic.json (round 5, second session; r5 / r4 / r3 as fall-backs)
     (builder-side PMC passes over tools/traffic_probe.py, not re-measured in this run -- rocprofv3 cannot wrap a process from the
     inside); falls back to round 3's file; None when this shape / kernel was not profiled."""
-    for name in ('r5_traffic.json', 'r4_traffic.json', 'r3_traffic.json'):
+    for name in ('r5b_traffic.json', 'r5_traffic.json', 'r4_traffic.json', 'r3_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 t = json.load(f).get(tag)
@@ -177,7 +177,7 @@ def _pmc_summary(t):
         if 'mfma_busy' in out:
             out['mfma_busy_at_sclk'] = round(out['mfma_busy'] * 2.4 / out['sclk_GHz'], 4)
     if out:
-        out['pmc_note'] = ('rocprofv3 --pmc passes (profiles/r5_conv_pmc.txt): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) -- matrix-pipe '
+        out['pmc_note'] = ('rocprofv3 --pmc passes (profiles/r5b_conv_pmc.txt): mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz) -- matrix-pipe '
                            'issue slots used at the NOMINAL clock; sclk_GHz = SQ_BUSY_CYCLES / 32 shader engines / kernel time, the clock the launches ran at; '
                            'mfma_busy_at_sclk = the same slots against that clock; hbm_GBps = (2 FETCH_SIZE + WRITE_SIZE) / kernel time against the 8 TB/s HBM3E peak')
     return out
@@ -341,7 +341,7 @@ def roofline_blocks(args, device):
         gru_ms += ms1 + ms2; gru_fl += fl
     tag = f'{args.compute}/{B}/{args.height}x{args.width}'
     conv_t = conv_fl / conv_ms / 1e9
-    t_conv, t_gate, t_gru, t_wg = [_traffic_from_profiles(g_ + '/' + tag) for g_ in ('conv3x3', 'gate', 'gru', 'wgrad')]
+    t_conv, t_gate, t_gru, t_wg, t_enc = [_traffic_from_profiles(g_ + '/' + tag) for g_ in ('conv3x3', 'gate', 'gru', 'wgrad', 'enc5x5s2')]
     return {'bound': 'mfma', **_pmc_summary(t_conv),
             'kernel': ('conv_bf16_ws_k3s1_kernel<MB, LINEAR, BF16_C8 sources> | conv_bf16_wide_kernel<MBW, CW> (plain 3x3 conv of the trainable networks; picked per launch by round count)' if bf16
                        else 'conv_f32_kernel<3,1,MB,LINEAR,8>') + ': the 16 launches of one decoder forward',
@@ -357,7 +357,7 @@ def roofline_blocks(args, device):
                 **({'encoder_conv5x5_s2': {'kernel': 'conv_bf16_wide_kernel<2, CW, LINEAR, S2D> (the 5x5 / stride-2 convolutions of the frozen encoder as a 3x3 over '
                                                      'the space-to-depth view of the BF16_C8 source) | conv_bf16_ws_pair_kernel<5, 2, 1>',
                                            'achieved': round(enc_fl / enc_ms / 1e9, 1), 'frac': round(enc_fl / enc_ms / 1e9 / peak, 4),
-                                           'ms_per_launch_set': round(enc_ms, 4), 'per_level': enc_levels}} if enc_ms else {}),
+                                           **_pmc_summary(t_enc), 'ms_per_launch_set': round(enc_ms, 4), 'per_level': enc_levels, 'traffic': t_enc}} if enc_ms else {}),
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg,

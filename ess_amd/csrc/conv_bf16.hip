@@ -37,7 +37,10 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
   if (w_kind == ESS_W_CONV5_S2D) {
     // the space-to-depth form of a 5x5 / stride-2 convolution (conv_bf16_wide.hip, ESS_SRC_S2D): virtual channel c = q * cin5 + cr
     // of parity class q = py + 2 px; `tap` is the SLOT of the chunk's slab -- a class keeps its used taps first
-    const int cin5 = cin >> 2, q = c / cin5, cr = c - q * cin5, py = q & 1, px = q >> 1;
+    // chunk position c / 16 -> (class, 16-channel group): conv_bf16_wide.hip s2d_class / s2d_group (column parities of a row parity adjacent)
+    const int cin5 = cin >> 2, nq = cin5 >> 4, pos = c >> 4;
+    const int q = pos < 2 * nq ? ((pos & 1) ? 2 : 0) : ((pos & 1) ? 3 : 1);
+    const int cr = (((pos < 2 * nq ? pos : pos - 2 * nq) >> 1) << 4) + (c & 15), py = q & 1, px = q >> 1;
     int t3 = tap;  // slot -> tap (ty * 3 + tx)
     if (q == 2) { const int m[9] = {0, 1, 3, 4, 6, 7, 2, 5, 8}; t3 = m[tap]; }
     if (q == 3) { const int m[9] = {0, 1, 3, 4, 2, 5, 6, 7, 8}; t3 = m[tap]; }

@@ -38,7 +38,7 @@
 // convolutions (e2vid/model/unet.py:117-181 encoders, submodules.py:176-186 RecurrentConvLayer.conv; 84 us each on the tap-paired
 // kernel: 8-channel chunks of 26 MFMAs per wave between barriers, 1.5 fragment reads per MFMA, 0.30 of peak) run HERE, on 16-channel
 // chunks of 90 / 60 / 60 / 40 MFMAs at 0.7 reads per MFMA: source mode ESS_SRC_S2D = the stored tensor is [N][Cin/8][2 Hin][2 Win][8],
-// the descriptor's C0 = 4 Cin VIRTUAL channels in class-major order (class q = py + 2 px owns channels [q Cin, (q + 1) Cin)), the
+// the descriptor's C0 = 4 Cin VIRTUAL channels, 16 per chunk, in the chunk order of s2d_class / s2d_group below (class q = py + 2 px), the
 // staging waves gather a chunk's pixel vectors at (2 gy + py, 2 gx + px), and the matrix waves run a class's chunk with its own tap list
 // (no products with the zero taps a dense 3x3 over 4 Cin channels would carry: 25 / 36 of the work).  The weight pack (w_kind
 // ESS_W_CONV5_S2D: from the [Cout][Cin][5][5] tensor) keeps a chunk's USED taps first (class order below), so the staging waves copy
@@ -52,6 +52,13 @@ using namespace essconv;
 // class q = py + 2 px: taps (ty * 3 + tx) a chunk of that class contracts, in the order its weight slab stores them
 //   q 0 (0, 0): 0 1 2 3 4 5 6 7 8      q 1 (py 1): 0 1 2 3 4 5      q 2 (px 1): 0 1 3 4 6 7      q 3 (1, 1): 0 1 3 4
 __host__ __device__ constexpr int s2d_ntaps(int q) { return q == 0 ? 9 : (q == 3 ? 4 : 6); }
+// Chunk ORDER of the space-to-depth form (= order of the virtual channels, 16 per chunk; nq = chunks per class): the two column parities
+// of one row parity sit next to each other -- (q 0, g), (q 2, g) for every channel group g, then (q 1, g), (q 3, g) -- because they
+// read the two halves of the same 32-byte pixel pairs, i.e. the same cache lines: class-major order (all of q 0, then q 1, ...) put
+// 2 nq chunks of every workgroup of the XCD between the two touches of a line, more than its 4 MB L2 holds, and the counters showed
+// every input line fetched twice (profiles/r5b_conv_pmc_before_interleave.txt: 310 MB read for 157 MB of input at level 0, 5.2 TB/s).
+__host__ __device__ constexpr int s2d_class(int p, int nq) { return p < 2 * nq ? ((p & 1) ? 2 : 0) : ((p & 1) ? 3 : 1); }
+__host__ __device__ constexpr int s2d_group(int p, int nq) { return (p < 2 * nq ? p : p - 2 * nq) >> 1; }
 constexpr int WIDE_NB = 5;    // pixel blocks per matrix wave
 constexpr int WIDE_RP = 32;   // LDS row pitch in 16-byte vectors: 18 used; rows of a pixel block must start 0 mod 16 vectors apart (ds_read_b128 lane groups)
 constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       if (a.deep & 4) return;  // (ablation build only, switch ESS_WS_ABL: no global loads)
 #endif
       if constexpr (S2D) {
-        const int q = ch / nq, cq = ch - q * nq;                     // parity class, chunk inside the class
+        const int q = s2d_class(ch, nq), cq = s2d_group(ch, nq);      // parity class, 16-channel group inside the class
         const unsigned off_q = (unsigned)((q & 1) * Wp0 + (q >> 1));  // pixel (py, px) of the 2 x 2 cell
 #pragma unroll
         for (int cb = 0; cb < CB8; ++cb) {
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
           if (v_lds[k] >= 0) in_t[cb * PLANE + v_lds[k]] = v;
         }
       }
-      const int wlim = S2D ? s2d_ntaps(ch / nq) * CB8 * COT : WSZ;
+      const int wlim = S2D ? s2d_ntaps(s2d_class(ch, nq)) * CB8 * COT : WSZ;
 #pragma unroll
       for (int it = 0; it < WV; ++it) { const int i = tid + it * 256; if (i < wlim) w_t[i] = r.wpre[it]; }
     };
@@ -334,14 +341,17 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
   {
     ESS_READ_TAP(f0, 0, lds0)
     if constexpr (S2D) {
-      const int nq = nch >> 2;  // chunks per parity class (even: validate())
-      for (int ch = 0; ch < nq; ch += 2) {
+      const int nq = nch >> 2;  // chunks per parity class (even: validate()); chunk order: s2d_class / s2d_group above
+      for (int ch = 0; ch < 2 * nq; ch += 4) {  // row parity 0: (q 0: nine taps -- the fragment sets swap roles), (q 2: six -- they keep them)
         ESS_CHUNK(f0, f1, ch)
-        ESS_CHUNK(f1, f0, ch + 1)
+        ESS_CHUNK6(f1, f0, ch + 1, 1, 3, 4, 6, 7)  // px = 1: columns dx in {-1, 0}
+        ESS_CHUNK(f1, f0, ch + 2)
+        ESS_CHUNK6(f0, f1, ch + 3, 1, 3, 4, 6, 7)
       }
-      for (int ch = nq; ch < 2 * nq; ++ch) ESS_CHUNK6(f0, f1, ch, 1, 2, 3, 4, 5)      // py = 1: rows dy in {-1, 0}
-      for (int ch = 2 * nq; ch < 3 * nq; ++ch) ESS_CHUNK6(f0, f1, ch, 1, 3, 4, 6, 7)  // px = 1: columns dx in {-1, 0}
-      for (int ch = 3 * nq; ch < nch; ++ch) ESS_CHUNK4(f0, f1, ch, 1, 3, 4)           // both
+      for (int ch = 2 * nq; ch < nch; ch += 2) {  // row parity 1 (rows dy in {-1, 0}): q 1, then q 3
+        ESS_CHUNK6(f0, f1, ch, 1, 2, 3, 4, 5)
+        ESS_CHUNK4(f0, f1, ch + 1, 1, 3, 4)
+      }
     } else {
     for (int ch = 0; ch < nch; ch += 2) {
       ESS_CHUNK(f0, f1, ch)

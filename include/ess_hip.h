@@ -34,8 +34,10 @@ enum { ESS_OK = 0, ESS_EINVAL = -22, ESS_ENOTSUP = -95, ESS_ELAUNCH = -5 };
 
 /* how a conv source is read (fused into the LDS tile load) */
 enum { ESS_SRC_DIRECT = 0, ESS_SRC_NEAREST_UP2 = 1, ESS_SRC_ZERO_UP2 = 2,
-       ESS_SRC_S2D = 3 /* space-to-depth view of a BF16_C8 tensor stored at (2 H_in, 2 W_in) with C0 / 4 channels: virtual channel
-                        * q * (C0/4) + c of virtual pixel (y, x) is stored channel c at (2y + (q & 1), 2x + (q >> 1)).  With weights
+       ESS_SRC_S2D = 3 /* space-to-depth view of a BF16_C8 tensor stored at (2 H_in, 2 W_in) with C0 / 4 channels: the virtual channels
+                        * of parity class q = (row parity) + 2 (column parity) at virtual pixel (y, x) are the stored channels at
+                        * (2y + (q & 1), 2x + (q >> 1)); their ORDER (which virtual channel index is which class / stored channel) is
+                        * internal to the ESS_W_CONV5_S2D weight pack and the kernel that reads it.  With weights
                         * packed as ESS_W_CONV5_S2D a 3x3 / stride 1 / pad 1 descriptor over this view IS the 5x5 / stride 2 / pad 2
                         * convolution of the stored tensor (nn.Conv2d(k=5, s=2, p=2) of the frozen encoder,
                         * e2vid/model/submodules.py:176-186, e2vid/model/unet.py:40-47): mode0 only, C1 = 0, fmt0 = fmt_out =

@@ -43,7 +43,7 @@ for (C0, C1, Cout, Hv, Wv, m0, cnt) in bench.decoder_conv3x3_layers(args):
         hip.conv_forward(spec, x0, x1, pw, None, pb, out=out, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)
     torch.cuda.synchronize()
     px_in = B * (C0 * (Hv * Wv // (4 if m0 else 1)) + C1 * Hv * Wv)
-    plan.append({'group': 'conv3x3', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
+    plan.append({'group': 'conv3x3', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel|conv_bf16_poly_up2_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
                  'count': cnt, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 2 * 9 * (C0 + C1) * Cout,
                  'flops': 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout})
     # weight gradient of the same layer (BF16_C8 X and dY; split-K slabs + reduce = two dispatches per call)
@@ -78,15 +78,15 @@ for lvl, hid in enumerate((64, 128, 256)):
 # ---- ConvGRU pair (lean launches of ConvGRU.forward): (update, reset) kernel, then candidate kernel
 for lvl, hid in enumerate((64, 128, 256)):
     H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
-    s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, hidden=hid)
-    s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, hidden=hid)
+    s1 = hip.conv_spec(B, H, W, hid, hid, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=hip.GRU_U_F16, hidden=hid)   # (the product's form since
+    s2 = hip.conv_spec(B, H, W, hid, hid, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=hip.GRU_U_F16, hidden=hid)      # round 5: u as IEEE half)
     wu, wr, wo = [(torch.randn(hid, 2 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(dev) for _ in range(3)]
     bu, br, bo = [torch.randn(hid, generator=g).to(dev) for _ in range(3)]
     pw1, pw2 = hip.pack_weights(s1, wu, wr), hip.pack_weights(s2, wo)
     pb1, pb2 = hip.pack_rows(s1, bu, br), hip.pack_rows(s2, bo)
     x8, h8 = act(hid, H, W), act(hid, H, W)
     hb = torch.randn(B, hid // 8, H, W, 8, generator=g).to(dev)
-    u, hn = hip.f32_c8_empty(B, hid, H, W, dev), hip.f32_c8_empty(B, hid, H, W, dev)
+    u, hn = hip.f16_c8_raw_empty(B, hid, H, W, dev), hip.f32_c8_empty(B, hid, H, W, dev)
     rh8, hn8 = hip.bf16_c8_empty(B, hid, H, W, dev), hip.bf16_c8_empty(B, hid, H, W, dev)
     n = B * hid * H * W
     torch.cuda.synchronize()
@@ -95,13 +95,34 @@ for lvl, hid in enumerate((64, 128, 256)):
                          aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} update+reset', 'count': 1,
-                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (4 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
+                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + 4 * n + (2 + 2) * n + 2 * 9 * 2 * hid * 2 * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * (2 * hid)})
     for _ in range(WARM + REPS):
         hip.conv_forward(s2, x8, rh8, pw2, None, pb2, aux0=hb, aux1=u, out=hn, out_bf=hn8, src_fmt=hip.FMT_BF16_C8,
                          out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
     torch.cuda.synchronize()
     plan.append({'group': 'gru', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W} candidate', 'count': 1,
-                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + (4 + 4) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
+                 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * 2 * n + (4 + 2) * n + (4 + 2) * n + 2 * 9 * 2 * hid * hid,
                  'flops': 2.0 * B * H * W * 9 * (2 * hid) * hid})
+# ---- the frozen encoder's 5x5 / stride-2 convolutions in the product's form (space-to-depth 3x3 on the wide-tile kernel at B = 8)
+from ess_amd.e2vid.model.submodules import _s2d_spec  # noqa: E402
+for lvl, cin in enumerate((32, 64, 128)):
+    Hs, Ws, cout = args.height >> lvl, args.width >> lvl, 2 * cin
+    x8 = hip.to_bf16_c8(torch.relu(torch.randn(B, cin, Hs, Ws, generator=g)).to(dev))
+    w = (torch.randn(cout, cin, 5, 5, generator=g) / (25 * cin) ** 0.5).to(dev)
+    spec = _s2d_spec(B, 5, 2, 2, cin, cout, Hs, Ws, hip.ACT_RELU)
+    s2d = spec is not None
+    if not s2d:
+        spec = hip.conv_spec(B, Hs, Ws, cin, 0, cout, 5, 2, 2, act=hip.ACT_RELU)
+    pw = hip.pack_weights(spec, w, kind=hip.W_CONV5_S2D if s2d else hip.W_CONV)
+    ps, pb = hip.pack_rows(spec, (torch.rand(cout, generator=g) + 0.5).to(dev), fill=1.0), hip.pack_rows(spec, torch.randn(cout, generator=g).to(dev))
+    o8 = hip.bf16_c8_empty(B, cout, spec.H_out, spec.W_out, dev)
+    torch.cuda.synchronize()
+    for _ in range(WARM + REPS):
+        hip.conv_forward(spec, x8, None, pw, ps, pb, out=o8, src_fmt=hip.FMT_BF16_C8, out_fmt=hip.FMT_BF16_C8)
+    torch.cuda.synchronize()
+    plan.append({'group': 'enc5x5s2', 'kernel': 'conv_bf16_wide_kernel|conv_bf16_ws_pair_kernel', 'layer': f'{cin}->{cout} 5x5/s2 @{Hs}x{Ws}' + (' s2d' if s2d else ' pair'),
+                 'count': 1, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * B * cin * Hs * Ws + 2 * B * cout * spec.H_out * spec.W_out + 2 * 25 * cin * cout,
+                 'flops': 2.0 * B * spec.H_out * spec.W_out * 25 * cin * cout})
+    del x8, o8
 print('PLAN ' + json.dumps(plan))
