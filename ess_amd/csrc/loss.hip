@@ -141,33 +141,26 @@ __global__ void task_loss_value_kernel(const double* ws, float* loss, float scal
   *loss = (float)(L * scale);
 }
 
-// ------------------------------------------------------------------ mean-type losses finish inside their ONE launch
-// ws (doubles): [0] = arrival counter (low 32 bits), [1 + b] = partial sum of block b.  Every block stores its partial (plain store, no
-// atomic on the sum), releases it and takes a ticket; the block that draws the last ticket adds the partials IN BLOCK ORDER -- the
-// value does not depend on which block arrives last or in what order the others did -- writes the loss and puts the counter back
-// to zero for the next call.  Contract (include/ess_hip.h): ESS_LOSS_WORKSPACE_BYTES, counter zero before the FIRST use.  Replaces
-// memset + kernel (atomicAdd on one double) + finalize kernel: three graph nodes per loss term became one (a node boundary of the
-// replayed step costs 1.55 us, profiles/r5_graph_gap_probe.txt; memset and finalize ran 4.7 + 5.1 us).
+// ------------------------------------------------------------------ mean-type losses: partials + an ordered finalize
+// ws (doubles): [1 + b] = partial sum of workgroup b ([0] unused).  Every workgroup stores its partial (plain store, no atomic, no
+// memset in front); a one-workgroup finalize launch adds the partials IN WORKGROUP ORDER -- a value independent of scheduling, where
+// the earlier atomicAdd on one double was not -- and writes the loss.  Two graph nodes per loss term instead of three (memset +
+// kernel + finalize; a node boundary of the replayed step costs 1.55 us, profiles/r5_graph_gap_probe.txt).
+// Measured and dropped (round 5): finishing inside the ONE launch -- the workgroup that draws the last ticket of an arrival counter
+// adds the partials -- needs a device-scope release per workgroup, and on this part that is an L2 write-back in front of every ticket
+// while the L2 is full of the gradient the kernel has just written: l1_c8_kernel 45 -> 117 us, sym_js_kernel 97 -> 183 us per
+// launch (profiles/r5b_uda_bf16_eager_kernel_stats.txt before the fix), + 0.65 ms per step for 22 nodes saved.
 constexpr int LOSS_MAX_BLOCKS = 2048;  // = the grid cap of the launches below (wave_uniform_grid(.., LOSS_MAX_BLOCKS)) = partial slots of ESS_LOSS_WORKSPACE_BYTES
 static_assert(8 * (1 + LOSS_MAX_BLOCKS) == ESS_LOSS_WORKSPACE_BYTES, "loss workspace contract");
-__device__ __forceinline__ void mean_finish(double block_acc, double* ws, float* loss, double denom, float scale, double* red) {
-  __shared__ int s_last;
-  if (threadIdx.x == 0) {
-    ws[1 + blockIdx.x] = block_acc;
-    __threadfence();  // the partial is visible device-wide before the ticket is
-    s_last = atomicAdd((unsigned*)ws, 1u) == gridDim.x - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();  // (acquire side: nothing of the partials may come from a stale line)
+__device__ __forceinline__ void mean_partial(double block_acc, double* ws) {
+  if (threadIdx.x == 0) ws[1 + blockIdx.x] = block_acc;
+}
+__global__ __launch_bounds__(256) void mean_finalize_kernel(const double* ws, float* loss, double denom, float scale, int nblocks) {
+  __shared__ double red[16];
   double a = 0;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)
-    a += __hip_atomic_load(ws + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < nblocks; i += 256) a += ws[1 + i];
   a = block_sum_d(a, red);
-  if (threadIdx.x == 0) {
-    *loss = (float)(a / denom * scale);
-    __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) *loss = (float)(a / denom * scale);
 }
 
 // ------------------------------------------------------------------ symmetric JS (as two mean-KL terms)
@@ -221,7 +214,7 @@ __global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ z
     }
   }
   acc = block_sum_d(acc, red);
-  mean_finish(acc, ws, loss, (double)total * K, scale, red);
+  mean_partial(acc, ws);
 }
 
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, double* ws,
@@ -235,7 +228,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
     if (da) da[i] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
   }
   acc = block_sum_d(acc, red);
-  mean_finish(acc, ws, loss, (double)n, scale, red);
+  mean_partial(acc, ws);
 }
 
 // 16-byte variant (n % 4 == 0, aligned pointers): same per-element arithmetic, a quarter of the memory instructions
@@ -258,7 +251,7 @@ __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a,
     if (da) da[i] = g;
   }
   acc = block_sum_d(acc, red);
-  mean_finish(acc, ws, loss, (double)n, scale, red);
+  mean_partial(acc, ws);
 }
 
 // L1 over BF16_C8 tensors (the latent / intermediate-prediction cycle losses of the bf16 configuration): 8 elements per 16-byte
@@ -287,7 +280,7 @@ __global__ __launch_bounds__(256) void l1_c8_kernel(const uint4* __restrict__ a,
     if (da) da[i] = __builtin_bit_cast(uint4, g);
   }
   acc = block_sum_d(acc, red);
-  mean_finish(acc, ws, loss, (double)n, scale, red);
+  mean_partial(acc, ws);
 }
 
 // ------------------------------------------------------------------ RAdam over a flat buffer
@@ -396,6 +389,8 @@ extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, floa
   else
     hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
                        loss_scale, N, K, hw, loss);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)total * K, loss_scale,
+                     (int)wave_uniform_grid(total, LOSS_MAX_BLOCKS));
   return ess_launch_status("sym_js_loss");
 }
 
@@ -403,12 +398,16 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
                            ess_stream_t stream) {
   ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0)
-    hipLaunchKernelGGL(l1_x4_kernel, dim3(wave_uniform_grid((size_t)n / 4, LOSS_MAX_BLOCKS)), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b,
-                       (double*)workspace, (f32x4*)da, loss_scale, n / 4, n, loss);
-  else
-    hipLaunchKernelGGL(l1_kernel, dim3(wave_uniform_grid((size_t)n, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, n, loss);
+  unsigned grid;
+  if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0) {
+    grid = wave_uniform_grid((size_t)n / 4, LOSS_MAX_BLOCKS);
+    hipLaunchKernelGGL(l1_x4_kernel, dim3(grid), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (double*)workspace, (f32x4*)da, loss_scale,
+                       n / 4, n, loss);
+  } else {
+    grid = wave_uniform_grid((size_t)n, LOSS_MAX_BLOCKS);
+    hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(256), 0, st, a, b, (double*)workspace, da, loss_scale, n, loss);
+  }
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)n, loss_scale, (int)grid);
   return ess_launch_status("l1_loss");
 }
 
@@ -417,8 +416,10 @@ extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* d
   ESS_CHECK_ARG(a && b && loss && workspace && n_vectors > 0 && n > 0 && n <= 8 * n_vectors, "l1_loss_c8: bad arguments");
   ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0, "l1_loss_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(l1_c8_kernel, dim3(wave_uniform_grid((size_t)n_vectors, LOSS_MAX_BLOCKS)), dim3(256), 0, st, (const uint4*)a, (const uint4*)b,
-                     (double*)workspace, (uint4*)da, loss_scale, n_vectors, n, loss);
+  const unsigned grid = wave_uniform_grid((size_t)n_vectors, LOSS_MAX_BLOCKS);
+  hipLaunchKernelGGL(l1_c8_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)a, (const uint4*)b, (double*)workspace, (uint4*)da, loss_scale,
+                     n_vectors, n, loss);
+  hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)n, loss_scale, (int)grid);
   return ess_launch_status("l1_loss_c8");
 }
 

@@ -370,13 +370,13 @@ def workspace(nbytes, device, tag='ws', zero=False):
     return buf
 
 
-LOSS_WORKSPACE_BYTES = 8 * (1 + 2048)  # ESS_LOSS_WORKSPACE_BYTES of include/ess_hip.h: arrival counter + one partial per block
+LOSS_WORKSPACE_BYTES = 8 * (1 + 2048)  # ESS_LOSS_WORKSPACE_BYTES of include/ess_hip.h: one partial per workgroup
 
 
 def _mean_loss_ws(device):
-    """Workspace of the single-launch mean losses (ess_sym_js_loss / ess_l1_loss / ess_l1_loss_c8): zero before its first use, left
-    zero by every call (the last block resets the counter) -- its own tag, the task loss leaves sums in its workspace."""
-    return workspace(LOSS_WORKSPACE_BYTES, device, 'mean_loss', zero=True)
+    """Workspace of the mean losses (ess_sym_js_loss / ess_l1_loss / ess_l1_loss_c8): one partial per workgroup, written in full by
+    every call."""
+    return workspace(LOSS_WORKSPACE_BYTES, device, 'mean_loss')
 
 
 def conv_wgrad(spec, src0, src1, dy, dw, db=None, accumulate=False):

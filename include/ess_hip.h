@@ -350,10 +350,10 @@ size_t ess_task_loss_workspace(int32_t K);
 int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
                   int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
                   void* workspace, ess_stream_t stream);
-/* Workspace of the mean-type losses below (ess_sym_js_loss, ess_l1_loss, ess_l1_loss_c8): an arrival counter + one partial sum per
- * workgroup.  Each of them is ONE launch: the workgroup that arrives last adds the partials in workgroup order (the value does not
- * depend on arrival order), writes the loss and resets the counter.  The buffer must be ZERO-FILLED BEFORE ITS FIRST USE; every call
- * leaves it ready for the next one.  Do not share it with ess_task_loss (which leaves its sums behind) or between streams. */
+/* Workspace of the mean-type losses below (ess_sym_js_loss, ess_l1_loss, ess_l1_loss_c8): one partial sum per workgroup.  Each loss is
+ * TWO launches: the kernel proper (every workgroup stores its partial: no atomics, no memset in front) and a one-workgroup finalize
+ * that adds the partials in workgroup order -- the value does not depend on scheduling.  Nothing to initialise.  Do not share the
+ * buffer between streams.                                                                                                     */
 #define ESS_LOSS_WORKSPACE_BYTES (8 * (1 + 2048))
 /* symJSDivLoss (utils/loss_functions.py:27-37): loss (1 float) and gradient w.r.t. `a` only
  * (the other argument is always computed under no_grad by the trainers).  workspace: ESS_LOSS_WORKSPACE_BYTES (see above). */

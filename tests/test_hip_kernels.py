@@ -397,11 +397,11 @@ def test_losses_against_golden_and_oracle(H, golden):
     assert abs(l.item() - gd['dice'].item()) < 5e-6
 
 
-def test_mean_losses_single_launch(H):
-    """ess_l1_loss / ess_l1_loss_c8 / ess_sym_js_loss finish inside their one launch (partials in workgroup order, arrival counter in
-    the workspace, reset by the last workgroup): full 2048-workgroup grids, odd sizes that take the scalar kernel, many calls in a
-    row on one workspace (the counter must come back to zero every time), bit-identical values call to call, a side stream with
-    its own workspace, and replays of a captured graph."""
+def test_mean_losses_ordered_partials(H):
+    """ess_l1_loss / ess_l1_loss_c8 / ess_sym_js_loss = the kernel proper (one partial per workgroup, no atomics, no memset) + a
+    one-workgroup finalize that adds the partials in workgroup order: full 2048-workgroup grids, odd sizes that take the scalar
+    kernel, many calls in a row on one workspace, bit-identical values call to call, a side stream with its own workspace, and
+    replays of a captured graph."""
     g = torch.Generator().manual_seed(11)
     cases = [(8 * 256 * 60 * 80,), (2048 * 256 * 4 + 4,), (1237,), (3,)]
     for (n,) in cases:
