@@ -132,14 +132,14 @@ __global__ __launch_bounds__(256) void task_loss_kernel(const float* __restrict_
 }
 
 // totals ws[0 .. 2 + 3K) = sum over workgroups (in workgroup order) of the partials the first pass left behind them
+// (one workgroup per total -- 2 + 3K of them side by side: one workgroup walking the 35 totals in turn took 94 us, more than the pass it follows)
 __global__ __launch_bounds__(256) void task_loss_reduce_kernel(double* ws, int nblocks, int K) {
   __shared__ double red[16];
-  for (int i = 0; i < 2 + 3 * K; ++i) {
-    double a = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) a += ws[TL_SLOTS + (size_t)b * TL_SLOTS + i];
-    a = block_sum_d(a, red);
-    if (threadIdx.x == 0) ws[i] = a;
-  }
+  const int i = blockIdx.x;
+  double a = 0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) a += ws[TL_SLOTS + (size_t)b * TL_SLOTS + i];
+  a = block_sum_d(a, red);
+  if (threadIdx.x == 0) ws[i] = a;
 }
 
 __global__ void task_loss_value_kernel(const double* ws, float* loss, float scale, int K, int ignore, int use_dice,
@@ -381,7 +381,7 @@ extern "C" int ess_task_loss(const float* logits, const int64_t* labels, float* 
   // first pass: per-workgroup partial sums (35 doubles at K = 11); then their ordered total.  (The partials were 2 + 3K global double
   // atomics per workgroup on the same 35 addresses and a memset in front: 102 us for 128 MB of input; see the mean losses above.)
   if (K <= 16) ESS_TL(16, false, nullptr); else ESS_TL(32, false, nullptr);
-  hipLaunchKernelGGL(task_loss_reduce_kernel, dim3(1), dim3(256), 0, st, (double*)workspace, (int)grid, K);
+  hipLaunchKernelGGL(task_loss_reduce_kernel, dim3(2 + 3 * K), dim3(256), 0, st, (double*)workspace, (int)grid, K);
   if (dlogits) {
     if (K <= 16) ESS_TL(16, true, dlogits); else ESS_TL(32, true, dlogits);
   } else

@@ -39,13 +39,13 @@ for pname, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
             a['ns'] += dur
 import shutil
 shutil.rmtree(out, ignore_errors=True)
-rows = sorted(acc.items(), key=lambda kv: -(2 * kv[1]['fetch'] + kv[1]['write']))
+rows = sorted(acc.items(), key=lambda kv: -kv[1]['ns'])  # by total time: a kernel that moves nothing and still takes 94 us belongs at the top too
 tot = sum(2 * a['fetch'] + a['write'] for _, a in rows)
 print(f'# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over an eager run of bench.py --steps 2 --warmup 1 {" ".join(extra)}: per kernel, all its launches')
 print(f'# total HBM-side traffic {(tot / 1e9):.2f} GB over 3 steps + set-up = {(tot / 3e9):.2f} GB per step')
-print(f'{"calls":>6} {"avg_us":>8} {"read_MB":>9} {"write_MB":>9} {"TB/s":>6}  kernel   (MB per call; read = 2 x FETCH_SIZE)')
-for k, a in rows[:45]:
+print(f'{"calls":>6} {"tot_ms":>8} {"avg_us":>8} {"read_MB":>9} {"write_MB":>9} {"TB/s":>6}  kernel   (MB per call; read = 2 x FETCH_SIZE)')
+for k, a in rows[:60]:
     c = max(a['calls'], 1)
     rd, wr = 2 * a['fetch'] / c / 1e6, a['write'] / c / 1e6
     us = a['ns'] / c / 1e3
-    print(f'{a["calls"]:6d} {us:8.1f} {rd:9.1f} {wr:9.1f} {(rd + wr) / max(us, 1e-3):6.2f}  {k[:90]}')
+    print(f'{a["calls"]:6d} {a["ns"] / 1e6:8.2f} {us:8.1f} {rd:9.1f} {wr:9.1f} {(rd + wr) / max(us, 1e-3):6.2f}  {k[:90]}')
