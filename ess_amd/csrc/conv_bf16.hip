@@ -111,34 +111,44 @@ struct PackJob {
 constexpr int PACK_JOBS = 48;
 struct PackJobs { PackJob j[PACK_JOBS]; int count; };
 
+// One 16-byte output vector (the 8 input channels of a (tap, block, row) slot) per thread: the index arithmetic of a slot -- five
+// integer divisions -- is paid once per eight elements and the store is one coalesced 16-byte write; the eight source floats sit
+// ks * ks floats apart ([row][c][ky][kx]), the taps of the same (row, c) are picked up by neighbouring slots out of the same lines.
+// (One ELEMENT per thread, round 3's form: 61 us per launch of the decoder's ~40 tensors, 1.0 TB/s -- bound by its divisions.)
 __global__ void pack_weights_bf16_multi_kernel(const PackJobs jobs) {
   int k = 0;
   while (k + 1 < jobs.count && (int)blockIdx.x >= jobs.j[k].blk_end) ++k;
   const PackJob& jb = jobs.j[k];
   const int blk0 = k ? jobs.j[k - 1].blk_end : 0;
-  const long long i = (long long)(blockIdx.x - blk0) * blockDim.x + threadIdx.x;
-  if (i >= jb.total) return;
+  const long long v = (long long)(blockIdx.x - blk0) * blockDim.x + threadIdx.x;  // vector (rows jobs: element) index
   if (jb.w_kind == ESS_W_ROWS) {  // a bias vector, tile-padded with zeros (LINEAR: packed row = output channel)
-    ((float*)jb.out)[i] = i < jb.cout ? jb.w[i] : 0.f;
+    if (v < jb.total) ((float*)jb.out)[v] = v < jb.cout ? jb.w[v] : 0.f;
     return;
   }
-  long long t = i;
-  const int kp = t & 7; t >>= 3;
+  if (v * 8 >= jb.total) return;
+  long long t = v;
   const int col = t % jb.cot; t /= jb.cot;
   const int cb8 = jb.ck >> 3;
   const int cb = t % cb8; t /= cb8;
-  const int tap = t % (jb.ks * jb.ks); t /= jb.ks * jb.ks;
+  const int kk = jb.ks * jb.ks;
+  const int tap = t % kk; t /= kk;
   const int ch = t % jb.n_chunks;
   const int ct = t / jb.n_chunks;
-  const int c = ch * jb.ck + cb * 8 + kp;
+  const int c0 = ch * jb.ck + cb * 8;
   const int row = ct * jb.cot + col;  // LINEAR: packed row = output channel
-  float v = 0.f;
-  if (row < jb.cout && c < jb.cin) {
-    const int ky = tap / jb.ks, kx = tap - ky * jb.ks;
-    if (jb.w_kind == ESS_W_CONV) v = jb.w[(((size_t)row * jb.cin + c) * jb.ks + ky) * jb.ks + kx];
-    else v = jb.w[(((size_t)c * jb.cout + row) * jb.ks + (jb.ks - 1 - ky)) * jb.ks + (jb.ks - 1 - kx)];
+  const int ky = tap / jb.ks, kx = tap - ky * jb.ks;
+  float f[8];
+#pragma unroll
+  for (int kp = 0; kp < 8; ++kp) {
+    const int c = c0 + kp;
+    float x = 0.f;
+    if (row < jb.cout && c < jb.cin) {
+      if (jb.w_kind == ESS_W_CONV) x = jb.w[(((size_t)row * jb.cin + c) * jb.ks + ky) * jb.ks + kx];
+      else x = jb.w[(((size_t)c * jb.cout + row) * jb.ks + (jb.ks - 1 - ky)) * jb.ks + (jb.ks - 1 - kx)];
+    }
+    f[kp] = x;
   }
-  jb.out[i] = (__bf16)v;
+  ((u32x4*)jb.out)[v] = pack8(f);
 }
 
 // returns ESS_EINVAL (nothing launched) when a descriptor is not a plain bf16 LINEAR layout
@@ -164,7 +174,7 @@ int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds,
       jb.total = kinds[i0 + k] == ESS_W_ROWS ? pl.rows_padded : pl.packed_elems;
       jb.cot = pl.cout_tile; jb.ck = pl.ck; jb.n_chunks = pl.n_chunks; jb.ks = d->ksize; jb.cin = d->C0 + d->C1; jb.cout = d->C_out;
       jb.w_kind = kinds[i0 + k];
-      blocks += (int)ceil_div64(jb.total, 256);
+      blocks += (int)ceil_div64(kinds[i0 + k] == ESS_W_ROWS ? jb.total : jb.total / 8, 256);  // (a weight job: one 16-byte vector per thread)
       jb.blk_end = blocks;
     }
     hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jobs);
