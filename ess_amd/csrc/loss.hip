@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void mean_finalize_kernel(const double* ws, fl
 // ------------------------------------------------------------------ symmetric JS (as two mean-KL terms)
 template <int KM>
 __global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ za, const float* __restrict__ zb, double* ws,
-                                                     float* __restrict__ da, float scale, int N, int K, int hw, float* loss) {
+                                                     float* __restrict__ da, float scale, int N, int K, int hw) {
   __shared__ double red[16];
   const size_t total = (size_t)N * hw;
   const float invM = 1.f / ((float)total * K);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void sym_js_kernel(const float* __restrict__ z
 }
 
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, const float* __restrict__ b, double* ws,
-                                                 float* __restrict__ da, float scale, int64_t n, float* loss) {
+                                                 float* __restrict__ da, float scale, int64_t n) {
   __shared__ double red[16];
   const float gs = scale / (float)n;
   double acc = 0;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ a, co
 
 // 16-byte variant (n % 4 == 0, aligned pointers): same per-element arithmetic, a quarter of the memory instructions
 __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, double* ws,
-                                                    f32x4* __restrict__ da, float scale, int64_t n4, int64_t n, float* loss) {
+                                                    f32x4* __restrict__ da, float scale, int64_t n4, int64_t n) {
   __shared__ double red[16];
   const float gs = scale / (float)n;
   double acc = 0;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void l1_x4_kernel(const f32x4* __restrict__ a,
 // vector, fp32 differences, the gradient sign(a - b) * scale / n written as BF16_C8.  Padded tail channels are zero in both
 // operands: they add nothing to the sum and get a zero gradient; `n` is the number of REAL elements.
 __global__ __launch_bounds__(256) void l1_c8_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, double* ws,
-                                                    uint4* __restrict__ da, float scale, int64_t nvec, int64_t n, float* loss) {
+                                                    uint4* __restrict__ da, float scale, int64_t nvec, int64_t n) {
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   __shared__ double red[16];
   const float gs = scale / (float)n;
@@ -399,10 +399,10 @@ extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, floa
   const size_t total = (size_t)N * hw;
   if (K <= 16)
     hipLaunchKernelGGL((sym_js_kernel<16>), dim3(wave_uniform_grid(total, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, N, K, hw, loss);
+                       loss_scale, N, K, hw);
   else
     hipLaunchKernelGGL((sym_js_kernel<32>), dim3(wave_uniform_grid(total, LOSS_MAX_BLOCKS)), dim3(256), 0, st, a, b, (double*)workspace, da,
-                       loss_scale, N, K, hw, loss);
+                       loss_scale, N, K, hw);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)total * K, loss_scale,
                      (int)wave_uniform_grid(total, LOSS_MAX_BLOCKS));
   return ess_launch_status("sym_js_loss");
@@ -416,10 +416,10 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
   if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0) {
     grid = wave_uniform_grid((size_t)n / 4, LOSS_MAX_BLOCKS);
     hipLaunchKernelGGL(l1_x4_kernel, dim3(grid), dim3(256), 0, st, (const f32x4*)a, (const f32x4*)b, (double*)workspace, (f32x4*)da, loss_scale,
-                       n / 4, n, loss);
+                       n / 4, n);
   } else {
     grid = wave_uniform_grid((size_t)n, LOSS_MAX_BLOCKS);
-    hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(256), 0, st, a, b, (double*)workspace, da, loss_scale, n, loss);
+    hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(256), 0, st, a, b, (double*)workspace, da, loss_scale, n);
   }
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)n, loss_scale, (int)grid);
   return ess_launch_status("l1_loss");
@@ -432,7 +432,7 @@ extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* d
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = wave_uniform_grid((size_t)n_vectors, LOSS_MAX_BLOCKS);
   hipLaunchKernelGGL(l1_c8_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)a, (const uint4*)b, (double*)workspace, (uint4*)da, loss_scale,
-                     n_vectors, n, loss);
+                     n_vectors, n);
   hipLaunchKernelGGL(mean_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, loss, (double)n, loss_scale, (int)grid);
   return ess_launch_status("l1_loss_c8");
 }
