@@ -1,0 +1,100 @@
+"""CPU ablation for the round-6 'mixed' configuration: which rounding points of the events -> prediction path
+may stay at 16 bits while the per-pixel argmax still agrees with the fp32 oracle on >= 99.99 % of the pixels of the TRAINED fixture
+of tests/test_hip_bf16_separated.py (480x640, B = 1).  Encoder variants round the OPERANDS of every encoder convolution (what the
+matrix core sees); decoder variants round latents / weights / pre-norm / post-norm tensors one class at a time.
+Needs gpurun_out/sep_sd_d.pt (tools/dump_separated_decoder.py on a GPU box).  Test infrastructure: imports the oracle."""
+import sys, time, types
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from oracle import ess_oracle as O
+from test_hip_bf16_separated import structured_batch
+torch.set_num_threads(8)
+B, T, C, H, W, K = 1, 5, 2, 480, 640, 11
+cfg = O.e2vid_config(num_bins=C)
+sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 141)
+sd = torch.load('gpurun_out/sep_sd_d.pt')
+ev, lab = structured_batch(B, T, C, H, W, K, seed=7)
+bf = lambda t: t.to(torch.bfloat16).float()
+hf = lambda t: t.to(torch.float16).float()
+ident = lambda t: t
+
+
+def encoder(rx, rw):
+    """latents of the oracle's recurrent encoder with the operands of every convolution rounded by rx (activations) / rw (weights)"""
+    real = O.F
+    shim = types.SimpleNamespace(**{k: getattr(real, k) for k in dir(real) if not k.startswith('__')})
+    shim.conv2d = lambda x, w, b=None, *a, **k: real.conv2d(rx(x), rw(w), b, *a, **k)
+    O.F = shim
+    try:
+        t0 = time.time()
+        _, _, lat = O.reconstruct_sequence(sd_e, cfg, ev, T, skip_dead_work=True)
+        print('  (encoder %.0f s)' % (time.time() - t0), flush=True)
+    finally:
+        O.F = real
+    return lat
+
+
+def decoder(lat, r_lat, r_w, r_pre, r_post, r_headw):
+    def ins(pfx, x, relu=True, res=None):
+        y = r_pre(F.conv2d(x, r_w(sd[pfx + '.weight']), sd[pfx + '.bias'], padding=1))
+        y = F.instance_norm(y, eps=1e-5)
+        if relu: y = torch.relu(y)
+        if res is not None: y = y + res
+        return r_post(y)
+    with torch.no_grad():
+        x = r_lat(lat[8])
+        for i in range(5):
+            y = ins(f'decoder_scale_1.{i}.model.0', x, True)
+            x = ins(f'decoder_scale_1.{i}.model.3', y, False, res=x)
+        up = lambda v: F.interpolate(v, scale_factor=2, mode='nearest')
+        x = ins('decoder_scale_1.5.model.0', x)
+        x = torch.cat([up(x), r_lat(lat[4])], 1)
+        x = ins('decoder_scale_2.1.model.0', ins('decoder_scale_2.0.model.0', x))
+        x = torch.cat([up(x), r_lat(lat[2])], 1)
+        x = ins('decoder_scale_3.1.model.0', ins('decoder_scale_3.0.model.0', x))
+        x = ins('decoder_scale_4.0.model.0', up(x))
+        return F.conv2d(x, r_headw(sd['decoder_scale_5.0.weight']), sd['decoder_scale_5.0.bias'])
+
+
+lat32 = encoder(ident, ident)
+ref = decoder(lat32, ident, ident, ident, ident, ident)
+ref_lbl = ref.argmax(1)
+conf_ref = O.confusion_matrix(ref_lbl, lab, K)
+miou_ref = O.miou_acc(conf_ref)[0].item()
+
+
+def rep(name, got):
+    d = (got - ref).abs()
+    lbl = got.argmax(1)
+    miou = O.miou_acc(O.confusion_matrix(lbl, lab, K))[0].item()
+    print('%-64s max %.4f mean %.5f flips %5d agree %.6f dmIoU(pct) %+.4f' % (name, d.max().item(), d.mean().item(), int((lbl != ref_lbl).sum()),
+          (lbl == ref_lbl).float().mean().item(), miou - miou_ref), flush=True)
+
+
+def lat_err(name, lat):
+    print('%-64s latent max abs err %s' % (name, {k: '%.2e' % (lat[k] - lat32[k]).abs().max().item() for k in (2, 4, 8)}), flush=True)
+
+
+which = sys.argv[1:] or ['dec', 'enc']
+if 'dec' in which:
+    print('--- decoder rounding points, fp32 latents from the fp32 encoder (= split-operand encoder) ---')
+    rep('all bf16, pre-norm f16 (today, but exact encoder)', decoder(lat32, bf, bf, hf, bf, bf))
+    rep('A: exact latents (hi/lo), w bf16, pre f16, post bf16', decoder(lat32, ident, bf, hf, bf, bf))
+    rep('B: A with pre-norm fp32', decoder(lat32, ident, bf, ident, bf, bf))
+    rep('B2: A with pre-norm fp32, weights fp32', decoder(lat32, ident, ident, ident, bf, ident))
+    rep('C: everything f16 (latents, w, pre, post)', decoder(lat32, hf, hf, hf, hf, hf))
+    rep('D: f16, exact latents, pre f16', decoder(lat32, ident, hf, hf, hf, hf))
+    rep('E: f16, exact latents, pre fp32', decoder(lat32, ident, hf, ident, hf, hf))
+    rep('F: post f16, w bf16, pre f16, exact latents', decoder(lat32, ident, bf, hf, hf, bf))
+if 'enc' in which:
+    print('--- encoder operand rounding, decoder as variant B / as fp32 ---')
+    for name, rx, rw in (('bf16 operands (today)', bf, bf), ('f16 operands', hf, hf), ('activations exact, weights bf16 (2-term)', ident, bf),
+                         ('activations exact, weights f16', ident, hf),
+                         ('activations f16, weights exact', hf, ident)):
+        lat = encoder(rx, rw)
+        lat_err('encoder ' + name, lat)
+        rep('encoder %s + fp32 decoder' % name, decoder(lat, ident, ident, ident, ident, ident))
+        rep('encoder %s + decoder B' % name, decoder(lat, ident, bf, ident, bf, bf))
+        rep('encoder %s + decoder E' % name, decoder(lat, ident, hf, ident, hf, hf))
+        rep('encoder %s + decoder E, latents as ONE f16 operand' % name, decoder(lat, hf, hf, ident, hf, hf))
