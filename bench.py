@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--recurrent', default='convlstm', choices=['convlstm', 'convgru'],
                     help='recurrent block of the frozen E2VID encoder (reference e2vid/model/submodules.py:175-273); BASELINE config 5 '
                          'names the ConvGRU variant')
-    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32', 'bf16x3'],
+    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32', 'bf16x3', 'mixed'],
                     help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3), exact fp32 MFMA, or '
                          'split-operand bf16 (fp32 tensors, three bf16 MFMAs per product: the parity-grade configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -221,7 +221,7 @@ def roofline_blocks(args, device):
     ev = HipEvents()
     stream = torch.cuda.current_stream().cuda_stream
     B = args.batch
-    bf16 = args.compute == 'bf16'
+    bf16 = args.compute in ('bf16', 'mixed')
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     g = torch.Generator(device='cpu').manual_seed(0)
 
@@ -656,7 +656,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         grids = world * args.batch * args.T * args.steps / elapsed
-        bf16 = args.compute == 'bf16'
+        bf16 = args.compute in ('bf16', 'mixed')
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
         step_flops = executed_flops_per_step(args)
         storage = ('activations and activation gradients of the decoder / image encoder stored as BF16_C8 only (pre-normalisation conv outputs as F16_C8), BF16_C8 staging '

@@ -12,7 +12,7 @@ void ess_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ess_last_error(void) { return g_err; }
-extern "C" int ess_version(void) { return 100; }
+extern "C" int ess_version(void) { return 110; }  // 110 (round 6): workspace_bytes on the loss entry points, ESS_COMPUTE_F16, the mixed-configuration bridges
 
 // ---- dynamic-LDS opt-in, once per (kernel, device): see ess_allow_lds in common.h
 #include <map>

@@ -17,7 +17,7 @@ using namespace essconv;
 
 // split (ESS_COMPUTE_BF16X3): every (tile, chunk) block is followed by a second one holding lo = bf16(w - float(bf16(w)))
 __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16* out, int64_t total, int cot, int ck,
-                                         int n_chunks, int ks, int cin, int cout, int epi, int hid, int w_kind, int split) {
+                                         int n_chunks, int ks, int cin, int cout, int epi, int hid, int w_kind, int split, int f16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   int64_t t = i;
@@ -52,13 +52,14 @@ __global__ void pack_weights_bf16_kernel(const float* w, const float* w2, __bf16
     if (w_kind == ESS_W_CONV) v = src[(((size_t)row * cin + c) * ks + ky) * ks + kx];
     else v = src[(((size_t)c * cout + row) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
   }
+  if (f16) { ((_Float16*)out)[i] = ess_f16_sat(v); return; }  // (ESS_COMPUTE_F16: half weights, no split form)
   const __bf16 hi = (__bf16)v;
   out[i] = lo ? (__bf16)(v - (float)hi) : hi;
 }
 
 // weights for the tap-paired kernel: [tile][chunk of 8 channels][pair][half][cout][8]
 __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64_t total, int cot, int n_chunks, int ks, int cin,
-                                              int cout, int w_kind, int split) {
+                                              int cout, int w_kind, int split, int f16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int nt = ks * ks, np = (nt + 1) / 2;
@@ -78,6 +79,7 @@ __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64
     if (w_kind == ESS_W_CONV) v = w[(((size_t)row * cin + c) * ks + ky) * ks + kx];
     else v = w[(((size_t)c * cout + row) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
   }
+  if (f16) { ((_Float16*)out)[i] = ess_f16_sat(v); return; }
   const __bf16 hi = (__bf16)v;
   out[i] = lo ? (__bf16)(v - (float)hi) : hi;
 }
@@ -86,15 +88,16 @@ __global__ void pack_weights_bf16_pair_kernel(const float* w, __bf16* out, int64
 namespace essconv {
 
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
-                           hipStream_t st, bool split) {
+                           hipStream_t st, bool split, bool f16) {
   const int64_t total = pl.packed_elems;
+  ESS_CHECK_ARG(!(split && f16), "pack_weights: no split-operand form of half weights");
   if (is_paired(d)) {
     hipLaunchKernelGGL(pack_weights_bf16_pair_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, (__bf16*)packed, total,
-                       pl.cout_tile, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, w_kind, split ? 1 : 0);
+                       pl.cout_tile, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, w_kind, split ? 1 : 0, f16 ? 1 : 0);
     return ess_launch_status("pack_weights_bf16(paired)");
   }
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, w, w2, (__bf16*)packed,
-                     total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue, d->hidden, w_kind, split ? 1 : 0);
+                     total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue, d->hidden, w_kind, split ? 1 : 0, f16 ? 1 : 0);
   return ess_launch_status("pack_weights_bf16");
 }
 
@@ -107,6 +110,7 @@ struct PackJob {
   long long total;
   int blk_end;  // exclusive end of this job's block range
   int cot, ck, n_chunks, ks, cin, cout, w_kind;
+  int f16;  // ESS_COMPUTE_F16: half elements
 };
 constexpr int PACK_JOBS = 48;
 struct PackJobs { PackJob j[PACK_JOBS]; int count; };
@@ -148,7 +152,7 @@ __global__ void pack_weights_bf16_multi_kernel(const PackJobs jobs) {
     }
     f[kp] = x;
   }
-  ((u32x4*)jb.out)[v] = pack8(f);
+  ((u32x4*)jb.out)[v] = jb.f16 ? pack8h(f) : pack8(f);
 }
 
 // returns ESS_EINVAL (nothing launched) when a descriptor is not a plain bf16 LINEAR layout
@@ -157,19 +161,22 @@ int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds,
   for (int i = 0; i < count; ++i) {
     int rc = validate(&descs[i]);
     if (rc) return rc;
-    ESS_CHECK_ARG(is_bf16(&descs[i]) && descs[i].epilogue == ESS_EPI_LINEAR && w[i] && packed[i] &&
-                      ((!is_paired(&descs[i]) && (kinds[i] == ESS_W_CONV || kinds[i] == ESS_W_TRANSPOSED)) || kinds[i] == ESS_W_ROWS),
-                  "pack_weights_multi: job %d is not a plain bf16 LINEAR layout", i);
+    const ResolvedDesc rd = resolve_compute(&descs[i]);  // (ESS_COMPUTE_F16 -> the bf16 layouts with half elements)
+    ESS_CHECK_ARG(descs[i].compute != ESS_COMPUTE_BF16X3 && is_bf16(&rd.d) && descs[i].epilogue == ESS_EPI_LINEAR && w[i] && packed[i] &&
+                      ((!is_paired(&rd.d) && (kinds[i] == ESS_W_CONV || kinds[i] == ESS_W_TRANSPOSED)) || kinds[i] == ESS_W_ROWS),
+                  "pack_weights_multi: job %d is not a plain bf16 / f16 LINEAR layout", i);
   }
   for (int i0 = 0; i0 < count; i0 += PACK_JOBS) {
     PackJobs jobs{};
     int blocks = 0;
     jobs.count = count - i0 < PACK_JOBS ? count - i0 : PACK_JOBS;
     for (int k = 0; k < jobs.count; ++k) {
-      const EssConvDesc* d = &descs[i0 + k];
+      const ResolvedDesc rd = resolve_compute(&descs[i0 + k]);
+      const EssConvDesc* d = &rd.d;
       EssConvPlan pl;
       make_plan(d, &pl);
       PackJob& jb = jobs.j[k];
+      jb.f16 = rd.f16 ? 1 : 0;
       jb.w = w[i0 + k]; jb.out = (__bf16*)packed[i0 + k];
       jb.total = kinds[i0 + k] == ESS_W_ROWS ? pl.rows_padded : pl.packed_elems;
       jb.cot = pl.cout_tile; jb.ck = pl.ck; jb.n_chunks = pl.n_chunks; jb.ks = d->ksize; jb.cin = d->C0 + d->C1; jb.cout = d->C_out;
@@ -281,6 +288,7 @@ bool wide_pick(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const
   const bool relu = d->act == ESS_ACT_RELU, res = a.residual != nullptr;
   if (!(d->act == ESS_ACT_NONE || relu)) return false;
   if (a.out_f16 && (relu || res)) return false;
+  if (a.f16 && res) return false;  // (the H instantiations of the wide-tile kernel carry no residual form)
   if (d->out_split > 0 && (relu || res || a.out_f16 || (d->out_split & 15) || a.scale)) return false;  // (conv_epilogue_c8_dgrad's form)
   // kappa: margin the wide kernel must win by.  Measured (tools/wide_probe.py, B = 8): per unit of work and round it runs exactly
   // as fast as the ws kernel (256 -> 256 @ 60 x 80: model 52.7 -> 42.2 us, measured 50.7 -> 42.4), but with one workgroup per CU
@@ -350,6 +358,12 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   ESS_CHECK_ARG(!a.split || (((ws_enabled() && d->ksize == 3 && d->stride == 1 && pl.ck == 16) || is_paired(d) || split_generic) && !c8 && a.fmt_out == ESS_FMT_F32_NCHW),
                 "conv(bf16): split operands run on the 3x3 / stride-1 wave-specialised, the 5x5 tap-paired and the 3x3 / stride-2 generic kernels with fp32 tensors");
   if (c8) ESS_CHECK_ARG((((uintptr_t)a.src0 | (uintptr_t)a.src1) & 15) == 0, "conv(bf16): BF16_C8 sources must be 16-byte aligned");
+  // ESS_COMPUTE_F16: F16_C8 sources through the kernels' H instantiations; fp32 NCHW sources only where a kernel rounds them to half itself
+  if (a.f16)
+    ESS_CHECK_ARG(c8 || (is_paired(d) && !a.residual && !a.split && conv_bf16_head_applies(d, pl)),
+                  "conv(f16): sources must be F16_C8 tensors (fp32 NCHW only for the 2..5-channel 5x5 head)");
+  if (a.f16) ESS_CHECK_ARG(!a.split && d->act != ESS_ACT_SUMPOOL2 && (a.fmt_out == ESS_FMT_F32_NCHW || d->out_split == 0 || d->epilogue != ESS_EPI_LINEAR),
+                           "conv(f16): forward forms only");
   if (!c8 && !a.residual && conv_bf16_stem_applies(d, pl)) {  // 1-channel 7x7 / stride 2 stem: K = the filter rows
     conv_bf16_launch_stem(d, pl, st, a);
     return ess_launch_status("conv2d_forward(bf16, 7x7 stem)");
@@ -378,7 +392,7 @@ int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g,
   if (d->mode0 == ESS_SRC_S2D) {
     // the 5x5 / stride-2 convolution of a BF16_C8 tensor as a 3x3 over its space-to-depth view (validate() has checked the form):
     // the wide-tile kernel only; 128-channel workgroup tiles where the output channels allow and the round count is no worse
-    ESS_CHECK_ARG(c8 && a.fmt_out == ESS_FMT_BF16_C8 && !a.out_bf && !a.residual && !a.out_f16 && pl.ck == 16 && pl.cout_tile == 64 &&
+    ESS_CHECK_ARG(c8 && a.fmt_out == ESS_FMT_BF16_C8 && !a.out_bf && !a.residual && !a.out_f16 && pl.ck == 16 && pl.cout_tile == 64 && (!a.hilo || (d->C_out % 64) == 0) &&
                       (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU),
                   "conv(bf16, S2D): BF16_C8 in and out, no residual / copy, act in {none, relu}");
     const int cus = tuning().cus;

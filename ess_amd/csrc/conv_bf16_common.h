@@ -19,12 +19,27 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
   return __builtin_bit_cast(u32x4, b);
 }
 
+__device__ __forceinline__ u32x4 pack8h(const float (&v)[8]) {  // IEEE half, saturating (ESS_COMPUTE_F16)
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  f16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b[j] = ess_f16_sat(v[j]);
+  return __builtin_bit_cast(u32x4, b);
+}
+// one K-step of the matrix cores on two 16-byte fragments: bfloat16 or, H, IEEE-half elements (same rate, same layouts)
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+template <bool H>
+__device__ __forceinline__ f32x16 ess_mfma16(u32x4 a, u32x4 b, f32x16 c) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8m, a), __builtin_bit_cast(f16x8m, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // pixel positions a thread stages per 8-channel block (compile-time bound of the register prefetch), by filter geometry
 constexpr int kpc(int ks, int s) { return stage_kpc(ks, s); }
 constexpr unsigned OOB = 0x80000000u;  // beyond any buffer: the bounds-checked load returns 0
 
 // conv_bf16_generic.hip
-void conv_bf16_launch_generic(int key, int mb, int cb8, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
+void conv_bf16_launch_generic(int key, int mb, int cb8, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);  // (a.f16: the H instantiations, in every launcher below)
 // conv_bf16_ws.hip
 void conv_bf16_launch_ws(int mb, int epi, bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a);
 // conv_bf16_head.hip: 5x5 / stride 1 on a 1- or 2-channel fp32 image (the recurrent encoder's head), reads the tap-paired pack

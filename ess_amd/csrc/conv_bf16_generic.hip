@@ -14,8 +14,10 @@ namespace {
 
 using namespace essconv;
 
-template <int KS, int S, int MB, int EPI, int CB8, bool SRCBF = false>
+// H (SRCBF only): IEEE-half operands and 16-bit outputs (ESS_COMPUTE_F16)
+template <int KS, int S, int MB, int EPI, int CB8, bool SRCBF = false, bool H = false>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
+  static_assert(!H || SRCBF, "half operands come as F16_C8 tensors");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int COT = MB * 32;
   constexpr int CK = CB8 * 8;
@@ -204,21 +206,21 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvKArgs a) {
         const u32x4* ip = in_t + toff;
 #pragma unroll
         for (int kk = 0; kk < CB8; kk += 2) {
-          bf16x8 af[MB], bfr[NBW];
+          u32x4 af[MB], bfr[NBW];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) af[mb] = __builtin_bit_cast(bf16x8, wp[kk * COT + mb * 32]);
+          for (int mb = 0; mb < MB; ++mb) af[mb] = wp[kk * COT + mb * 32];
 #pragma unroll
-          for (int nb = 0; nb < NBW; ++nb) bfr[nb] = __builtin_bit_cast(bf16x8, ip[boff[nb] + kk * a.plane]);
+          for (int nb = 0; nb < NBW; ++nb) bfr[nb] = ip[boff[nb] + kk * a.plane];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = ess_mfma16<H>(af[mb], bfr[nb], acc[mb][nb]);
         }
       }
     }
   }
-  conv_epilogue<MB, EPI>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  conv_epilogue<MB, EPI, true, H>(a, acc, ct, n, half, x0 + lx, y0, ly);
 }
 
 template <int KS, int S, int MB, int CB8>
@@ -238,6 +240,11 @@ void launch_epi(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs&
 // trainable networks' 1x1 head, ResNet downsample convs and their data-gradients
 template <int KS, int S, int MB, int CB8>
 void launch_c8(dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if (a.f16) {  // ESS_COMPUTE_F16
+    ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8, true, true>, lds);
+    hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8, true, true>), grid, dim3(256), lds, st, a);
+    return;
+  }
   ess_allow_lds(conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8, true>, lds);
   hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MB, ESS_EPI_LINEAR, CB8, true>), grid, dim3(256), lds, st, a);
 }

@@ -18,10 +18,10 @@ constexpr int HT_W = 32, HT_H = 32, HT_IW = 40, HT_IH = HT_H + 4;
 
 // NC: channel capacity of the instance (2: the BASELINE voxel grids; 5: the reference's own default, nr_temporal_bins = 5,
 // config/settings_DSEC.yaml:15) -- R = 5 NC filter rows = NS = ceil(R / 2) K-steps; a missing last row carries zero weights.
-template <bool SC, int NC>
+// H: IEEE-half operands (the fp32 image rounded to half in registers, half weights from the pack) and half 16-bit output (ESS_COMPUTE_F16)
+template <bool SC, int NC, bool H = false>
 __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a, int tiles_x, int tiles_y) {
   constexpr int R = 5 * NC, NS = (R + 1) / 2;
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
   __shared__ float tile[NC * HT_IH * HT_IW];
   __shared__ __attribute__((aligned(16))) u32x4 wfrag[NS * 2 * 32];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = src[j];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[s]), __builtin_bit_cast(bf16x8, pack8(v)), acc, 0, 0, 0);
+      acc = ess_mfma16<H>(af[s], H ? pack8h(v) : pack8(v), acc);
     }
     const bool inb = x < a.Wout;
     const unsigned pix = (unsigned)(y * a.Wout + x);
@@ -130,13 +130,13 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
         uint2 pk[2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          bf16x4 b;
+          float q[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int c = ct * 32 + 8 * (jp + jj) + 4 * half + i;
-            b[i] = (__bf16)(c < a.Cout ? v[4 * (jp + jj) + i] : 0.f);
+            q[i] = c < a.Cout ? v[4 * (jp + jj) + i] : 0.f;
           }
-          pk[jj] = __builtin_bit_cast(uint2, b);
+          pk[jj] = ess_cvt4<H>(q[0], q[1], q[2], q[3]);
         }
         // exchange halves: lanes 0-31 end up with the whole vector of block jp, lanes 32-63 with that of block jp + 1
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
@@ -334,6 +334,16 @@ void conv_bf16_launch_stem(const EssConvDesc* d, const EssConvPlan& pl, hipStrea
 void conv_bf16_launch_head(const EssConvDesc* d, const EssConvPlan& pl, hipStream_t st, const ConvKArgs& a) {
   const int tiles_x = ceil_div(d->W_out, HT_W), tiles_y = ceil_div(d->H_out, HT_H);
   const dim3 grid((unsigned)(tiles_x * tiles_y * pl.n_cout_tiles * d->N));
+  if (a.f16) {  // ESS_COMPUTE_F16
+    if (d->C0 <= 2) {
+      if (a.scale) hipLaunchKernelGGL((conv_bf16_head5_kernel<true, 2, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+      else hipLaunchKernelGGL((conv_bf16_head5_kernel<false, 2, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+    } else {
+      if (a.scale) hipLaunchKernelGGL((conv_bf16_head5_kernel<true, 5, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+      else hipLaunchKernelGGL((conv_bf16_head5_kernel<false, 5, true>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
+    }
+    return;
+  }
   if (d->C0 <= 2) {
     if (a.scale) hipLaunchKernelGGL((conv_bf16_head5_kernel<true, 2>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv_bf16_head5_kernel<false, 2>), grid, dim3(256), 0, st, a, tiles_x, tiles_y);

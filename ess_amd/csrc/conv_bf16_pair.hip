@@ -22,8 +22,10 @@ __device__ __forceinline__ void pair_steps(F&& f) {
 // a stage is one 8-channel input tile + 26.6 KB of weights, double-buffered like the 3x3 kernel, one barrier per chunk.
 // OUT8: BF16_C8 output(s) -- an instantiation that contains conv_epilogue_c8 and nothing of the fp32 epilogue variants (as in
 // conv_bf16_ws.hip: the all-variants function carries ~30 k instructions of epilogues and their spills).
-template <int KS, int S, int MB, bool SRCBF, bool OUT8 = false>
+// H (SRCBF only): IEEE-half operands and 16-bit outputs (ESS_COMPUTE_F16)
+template <int KS, int S, int MB, bool SRCBF, bool OUT8 = false, bool H = false>
 __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws_pair_kernel(const ConvKArgs a) {
+  static_assert(!H || SRCBF, "half operands come as F16_C8 tensors");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int NT = KS * KS, NP = (NT + 1) / 2;
   constexpr int COT = MB * 32;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F.a[mb]), __builtin_bit_cast(bf16x8, F.b[nb]), acc[mb][nb], 0, 0, 0);
+          acc[mb][nb] = ess_mfma16<H>(F.a[mb], F.b[nb], acc[mb][nb]);
     };
     pair_steps<0, D>([&](auto PR) { read_pair(PR, f[decltype(PR)::value]); });
     pair_steps<0, NP>([&](auto PR) {
@@ -313,8 +315,8 @@ __global__ __launch_bounds__(512, (S == 2 && MB == 2) ? 2 : 4) void conv_bf16_ws
     __syncthreads();
   }
   __builtin_amdgcn_s_setprio(0);
-  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly);
-  else conv_epilogue<MB, ESS_EPI_LINEAR, false>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  if constexpr (OUT8) conv_epilogue_c8<MB, H>(a, acc, ct, n, half, x0 + lx, y0, ly);
+  else conv_epilogue<MB, ESS_EPI_LINEAR, false, H>(a, acc, ct, n, half, x0 + lx, y0, ly);
   }  // tile loop
 #undef ESS_TILE_LOOP
 #undef ESS_TILE_DECODE
@@ -325,6 +327,12 @@ template <int S, int MB>
 void launch_pair(bool c8, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
 #define ESS_PAIR(C8_, O8_) { ess_allow_lds(conv_bf16_ws_pair_kernel<5, S, MB, C8_, O8_>, lds); hipLaunchKernelGGL((conv_bf16_ws_pair_kernel<5, S, MB, C8_, O8_>), grid, dim3(512), lds, st, a); }
   const bool out8 = a.fmt_out == ESS_FMT_BF16_C8;
+  if (c8 && a.f16) {  // ESS_COMPUTE_F16
+#define ESS_PAIRH(O8_) { ess_allow_lds(conv_bf16_ws_pair_kernel<5, S, MB, true, O8_, true>, lds); hipLaunchKernelGGL((conv_bf16_ws_pair_kernel<5, S, MB, true, O8_, true>), grid, dim3(512), lds, st, a); }
+    if (out8) ESS_PAIRH(true) else ESS_PAIRH(false)
+#undef ESS_PAIRH
+    return;
+  }
   if (c8) { if (out8) ESS_PAIR(true, true) else ESS_PAIR(true, false) }
   else { if (out8) ESS_PAIR(false, true) else ESS_PAIR(false, false) }
 #undef ESS_PAIR

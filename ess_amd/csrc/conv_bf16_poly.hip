@@ -47,6 +47,8 @@ constexpr bool p_uses(int t, int c) {
 constexpr int p_pair(int t, int c) { return c * 4 + (t / 3 - (c >> 1)) * 2 + (t % 3 - (c & 1)); }
 constexpr int p_na(int t) { return t > 8 ? 0 : (int)p_uses(t, 0) + (int)p_uses(t, 1) + (int)p_uses(t, 2) + (int)p_uses(t, 3); }
 
+// H: IEEE-half operands and output (ESS_COMPUTE_F16)
+template <bool H = false>
 __global__ __launch_bounds__(512, 2) void conv_bf16_poly_up2_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
@@ -81,13 +83,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_poly_up2_kernel(const ConvKA
       for (int ky = ky0; ky <= ky1; ++ky)
         for (int kx = kx0; kx <= kx1; ++kx) {
           const u32x4 v = wsrc[(ky * 3 + kx) * 2 * SLAB];
+          if constexpr (H) {
+            const f16x8m hv = __builtin_bit_cast(f16x8m, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)hv[e];
+          } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             s[2 * e] += __builtin_bit_cast(float, v[e] << 16);
             s[2 * e + 1] += __builtin_bit_cast(float, v[e] & 0xffff0000u);
           }
+          }
         }
-      w_l[j] = pack8(s);
+      w_l[j] = H ? pack8h(s) : pack8(s);
     }
   }
 
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_poly_up2_kernel(const ConvKA
 #define ESS_P_MMA_C(F_, T_, C_)                                                                                                  \
     if constexpr (p_uses((T_), (C_))) {                                                                                          \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                         \
-        acc[C_][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F_.a[C_]), __builtin_bit_cast(bf16x8, F_.b[nb]), acc[C_][nb], 0, 0, 0); \
+        acc[C_][nb] = ess_mfma16<H>(F_.a[C_], F_.b[nb], acc[C_][nb]); \
     }
 #define ESS_P_MMA(F_, T_) { ESS_P_MMA_C(F_, T_, 0) ESS_P_MMA_C(F_, T_, 1) ESS_P_MMA_C(F_, T_, 2) ESS_P_MMA_C(F_, T_, 3) }
   // ---- K loop over the tile's chunks, no barrier inside: per frame tap the two pixel fragments and the weight fragments of the
@@ -222,10 +230,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_poly_up2_kernel(const ConvKA
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) ly2[nb] = 2 * ly[nb];
   // (spelled out per class: left as a loop, hipcc keeps the four inlined epilogues rolled and the accumulators in scratch)
-  conv_epilogue_c8<1>(a, (f32x16(&)[1][NBW])acc[0], ct, n, half, 2 * (x0 + p), 2 * y0, ly2, biased);
-  conv_epilogue_c8<1>(a, (f32x16(&)[1][NBW])acc[1], ct, n, half, 2 * (x0 + p) + 1, 2 * y0, ly2, biased);
-  conv_epilogue_c8<1>(a, (f32x16(&)[1][NBW])acc[2], ct, n, half, 2 * (x0 + p), 2 * y0 + 1, ly2, biased);
-  conv_epilogue_c8<1>(a, (f32x16(&)[1][NBW])acc[3], ct, n, half, 2 * (x0 + p) + 1, 2 * y0 + 1, ly2, biased);
+  conv_epilogue_c8<1, H>(a, (f32x16(&)[1][NBW])acc[0], ct, n, half, 2 * (x0 + p), 2 * y0, ly2, biased);
+  conv_epilogue_c8<1, H>(a, (f32x16(&)[1][NBW])acc[1], ct, n, half, 2 * (x0 + p) + 1, 2 * y0, ly2, biased);
+  conv_epilogue_c8<1, H>(a, (f32x16(&)[1][NBW])acc[2], ct, n, half, 2 * (x0 + p), 2 * y0 + 1, ly2, biased);
+  conv_epilogue_c8<1, H>(a, (f32x16(&)[1][NBW])acc[3], ct, n, half, 2 * (x0 + p) + 1, 2 * y0 + 1, ly2, biased);
   __syncthreads();  // B_{it+1}: the next tile is staged
   }  // tile loop
 #undef ESS_P_TILE_DECODE
@@ -241,8 +249,13 @@ void conv_bf16_poly_tile(int* th, int* tw, int* max_cin) { *th = P_TH; *tw = P_T
 void conv_bf16_launch_poly(dim3 grid, hipStream_t st, const ConvKArgs& a) {
   constexpr size_t lds = (size_t)(P_WTOT + 2 * P_STAGE) * 16;
   static_assert(lds <= 160 * 1024, "resident weights + two tile stages must fit the LDS");
-  ess_allow_lds(conv_bf16_poly_up2_kernel, lds);
-  hipLaunchKernelGGL(conv_bf16_poly_up2_kernel, grid, dim3(512), lds, st, a);
+  if (a.f16) {  // ESS_COMPUTE_F16
+    ess_allow_lds(conv_bf16_poly_up2_kernel<true>, lds);
+    hipLaunchKernelGGL(conv_bf16_poly_up2_kernel<true>, grid, dim3(512), lds, st, a);
+    return;
+  }
+  ess_allow_lds(conv_bf16_poly_up2_kernel<false>, lds);
+  hipLaunchKernelGGL(conv_bf16_poly_up2_kernel<false>, grid, dim3(512), lds, st, a);
 }
 
 }  // namespace essconv

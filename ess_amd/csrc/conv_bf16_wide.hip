@@ -65,7 +65,8 @@ constexpr int WIDE_IW = 18;   // 16 + 2 halo columns
 
 // EPI: ESS_EPI_LINEAR (BF16_C8 outputs), ESS_EPI_LSTM (the lean ConvLSTM step: F32_C8 cell state in / out, BF16_C8 copy of h', bias in
 // the accumulators -- conv_epilogue_lstm_c8) or ESS_EPI_GRU_UR / ESS_EPI_GRU_OUT (the lean ConvGRU kernel pair: conv_epilogue_gru_*_c8)
-template <int MBW, int CW, int EPI = ESS_EPI_LINEAR, bool S2D = false>
+// H: IEEE-half operands and 16-bit outputs (ESS_COMPUTE_F16) -- the same kernel with v_mfma_f32_32x32x16_f16 and half conversions in the epilogue
+template <int MBW, int CW, int EPI = ESS_EPI_LINEAR, bool S2D = false, bool H = false>
 __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16, NB = WIDE_NB, RP = WIDE_RP;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
 #define ESS_MMA(F_)                                                                                                              \
     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                            \
       _Pragma("unroll") for (int mb = 0; mb < MBW; ++mb)                                                                         \
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F_.a[mb]), __builtin_bit_cast(bf16x8, F_.b[nb]), acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = ess_mfma16<H>(F_.a[mb], F_.b[nb], acc[mb][nb]);
   // one chunk: on entry tap 0 is in flight into FA_; on exit tap 0 of the next chunk (if any) is in flight into FB_
 #define ESS_CHUNK(FA_, FB_, CH_)                                                                                                 \
     {                                                                                                                            \
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const int y = y0 + ly[nb], x = x0 + ox;
       pixi[nb] = (y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1;
     }
-    conv_epilogue_lstm_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+    conv_epilogue_lstm_c8<MBW, NB, H>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
   } else if constexpr (EPI == ESS_EPI_GRU_UR || EPI == ESS_EPI_GRU_OUT) {
     int pixi[NB];
 #pragma unroll
@@ -389,10 +390,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16_wide_kernel(const ConvKArgs 
       const int y = y0 + ly[nb], x = x0 + ox;
       pixi[nb] = (y < a.Hout && x < a.Wout) ? y * a.Wout + x : -1;
     }
-    if constexpr (EPI == ESS_EPI_GRU_UR) conv_epilogue_gru_ur_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
-    else conv_epilogue_gru_out_c8<MBW>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+    if constexpr (EPI == ESS_EPI_GRU_UR) conv_epilogue_gru_ur_c8<MBW, NB, H>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
+    else conv_epilogue_gru_out_c8<MBW, NB, H>(a, acc, ct_w, n, half, pixi, (unsigned)(a.Hout * a.Wout));
   } else {
-    conv_epilogue_c8_wide<MBW>(a, acc, ct_w, n, half, x0 + ox, y0, ly, biased);
+    conv_epilogue_c8_wide<MBW, NB, H>(a, acc, ct_w, n, half, x0 + ox, y0, ly, biased);
   }
   }  // tile loop
 #undef ESS_TILE_LOOP
@@ -404,6 +405,11 @@ void launch_wide_t(dim3 grid, hipStream_t st, const ConvKArgs& a) {
   constexpr int PW = 4 / CW, TH = PW * WIDE_NB * 2, PLANE = (TH + 2) * WIDE_RP, COT = MBW * CW * 32;
   constexpr size_t lds = 2 * (size_t)(2 * PLANE + 9 * 2 * COT) * 16;
   static_assert(lds <= 160 * 1024, "two stages must fit the 160 KiB LDS");
+  if (a.f16) {  // ESS_COMPUTE_F16
+    ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI, S2D, true>, lds);
+    hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI, S2D, true>), grid, dim3(512), lds, st, a);
+    return;
+  }
   ess_allow_lds(conv_bf16_wide_kernel<MBW, CW, EPI, S2D>, lds);
   hipLaunchKernelGGL((conv_bf16_wide_kernel<MBW, CW, EPI, S2D>), grid, dim3(512), lds, st, a);
 }

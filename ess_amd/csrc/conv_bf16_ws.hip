@@ -30,8 +30,10 @@ using namespace essconv;
 // OUT8: the output(s) are BF16_C8 tensors (LINEAR epilogue): an instantiation of its own that contains conv_epilogue_c8 and
 // nothing of the fp32 epilogue variants -- the all-variants kernel is ~57k instructions with ~300 spilled registers in its
 // epilogues, this one a tenth of that.
-template <int MB, int EPI, bool SRCBF, bool OUT8 = false>
+// H (SRCBF only): IEEE-half operands and 16-bit outputs (ESS_COMPUTE_F16)
+template <int MB, int EPI, bool SRCBF, bool OUT8 = false, bool H = false>
 __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel(const ConvKArgs a) {
+  static_assert(!H || SRCBF, "half operands come as F16_C8 tensors");
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
   constexpr int KS = 3, CB8 = 2, CK = 16;
   constexpr int COT = MB * 32;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #define ESS_MMA(F_)                                                                                                              \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                                            \
       _Pragma("unroll") for (int nb = 0; nb < NBW; ++nb)                                                                         \
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F_.a[mb]), __builtin_bit_cast(bf16x8, F_.b[nb]), acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = ess_mfma16<H>(F_.a[mb], F_.b[nb], acc[mb][nb]);
     constexpr int NR = MB + NBW;  // LDS reads per tap
 #ifdef ESS_ABLATE
     if (a.deep & 2) { __syncthreads(); continue; }  // (ablation build only: no fragment reads, no MFMAs)
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 #ifdef ESS_ABLATE
   if (a.deep & 8) continue;  // (ablation build only: no epilogue)
 #endif
-  if constexpr (OUT8) conv_epilogue_c8<MB>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
-  else conv_epilogue<MB, EPI, false>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
+  if constexpr (OUT8) conv_epilogue_c8<MB, H>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
+  else conv_epilogue<MB, EPI, false, H>(a, acc, ct, n, half, x0 + lx, y0, ly, biased);
   ESS_CT(47);
   if constexpr (EPI != ESS_EPI_LSTM) ESS_CW(43);
   }  // tile loop
@@ -402,6 +404,18 @@ __global__ __launch_bounds__(512, MB == 4 ? 2 : 4) void conv_bf16_ws_k3s1_kernel
 
 template <int MB, bool SRCBF>
 void launch_ws(int epi, dim3 grid, size_t lds, hipStream_t st, const ConvKArgs& a) {
+  if constexpr (SRCBF) {
+    if (a.f16) {  // ESS_COMPUTE_F16 (the dispatcher lets only F16_C8 sources through)
+#define ESS_WSH(E_, O8_) { ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, E_, true, O8_, true>, lds); hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, E_, true, O8_, true>), grid, dim3(512), lds, st, a); }
+      if (a.fmt_out == ESS_FMT_BF16_C8) ESS_WSH(ESS_EPI_LINEAR, true)
+      else if (epi == ESS_EPI_LSTM) ESS_WSH(ESS_EPI_LSTM, false)
+      else if (epi == ESS_EPI_GRU_UR) ESS_WSH(ESS_EPI_GRU_UR, false)
+      else if (epi == ESS_EPI_GRU_OUT) ESS_WSH(ESS_EPI_GRU_OUT, false)
+      else ESS_WSH(ESS_EPI_LINEAR, false)
+#undef ESS_WSH
+      return;
+    }
+  }
   if (a.fmt_out == ESS_FMT_BF16_C8) {  // (validated: LINEAR epilogue)
     ess_allow_lds(conv_bf16_ws_k3s1_kernel<MB, ESS_EPI_LINEAR, SRCBF, true>, lds);
     hipLaunchKernelGGL((conv_bf16_ws_k3s1_kernel<MB, ESS_EPI_LINEAR, SRCBF, true>), grid, dim3(512), lds, st, a);

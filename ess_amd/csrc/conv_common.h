@@ -43,7 +43,13 @@ struct ConvKArgs {
   int slab;        // wide-tile kernel: output rows of one packed weight slab (the plan's cout_tile: 32, 64 or 128)
   int split;       // split-operand bf16 (ESS_COMPUTE_BF16X3): every 16-channel chunk is contracted three times -- (w_hi, x_hi), (w_hi, x_lo), (w_lo, x_hi)
   int deep;        // ablation bits of -DESS_ABLATE builds (always 0 in the shipped library: the kernels do not test it)
+  int f16;         // ESS_COMPUTE_F16: the 16-bit operands (C8 sources, packed weights, C8 residual) and every 16-bit output / copy are IEEE half; the launchers pick the kernels' H = true instantiations
+  int hilo;        // (f16) the 16-bit output / copy leaves as [hi | lo]: blocks [0, CB) = half(v), blocks [CB, 2 CB) = half(v - hi)  (ESS_FMT_F16_C8_HILO / ESS_LSTM_H_HILO)
 };
+
+// 4 floats -> four 16-bit elements: bfloat16 (round to nearest even) or, H, IEEE half (saturating: ess_f16_sat below)
+template <bool H> __device__ __forceinline__ uint2 ess_cvt4(float v0, float v1, float v2, float v3);
+template <bool H> __device__ __forceinline__ void ess_up4(uint2 r, float (&f)[4]);
 
 
 // ---- shared epilogue: accumulator block (MFMA 32x32 C/D layout: col = lane&31 = pixel, row = (r&3)+8(r>>2)+4(lane>>5)
@@ -69,6 +75,38 @@ __device__ __forceinline__ _Float16 ess_f16_sat(float v) {
   const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
   return (_Float16)(v != v ? v : c);
 }
+template <> __device__ __forceinline__ uint2 ess_cvt4<false>(float v0, float v1, float v2, float v3) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 b;
+  b[0] = (__bf16)v0; b[1] = (__bf16)v1; b[2] = (__bf16)v2; b[3] = (__bf16)v3;
+  return __builtin_bit_cast(uint2, b);
+}
+template <> __device__ __forceinline__ uint2 ess_cvt4<true>(float v0, float v1, float v2, float v3) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 h;
+  h[0] = ess_f16_sat(v0); h[1] = ess_f16_sat(v1); h[2] = ess_f16_sat(v2); h[3] = ess_f16_sat(v3);
+  return __builtin_bit_cast(uint2, h);
+}
+// the lo parts of a [hi | lo] half pair: half(v - float(half(v)))  (|v| <= 65504: exact difference, ~22 significant bits in the pair)
+__device__ __forceinline__ uint2 ess_cvt4_lo(float v0, float v1, float v2, float v3) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 h;
+  h[0] = (_Float16)(v0 - (float)ess_f16_sat(v0)); h[1] = (_Float16)(v1 - (float)ess_f16_sat(v1));
+  h[2] = (_Float16)(v2 - (float)ess_f16_sat(v2)); h[3] = (_Float16)(v3 - (float)ess_f16_sat(v3));
+  return __builtin_bit_cast(uint2, h);
+}
+template <> __device__ __forceinline__ void ess_up4<false>(uint2 r, float (&f)[4]) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const bf16x4 b = __builtin_bit_cast(bf16x4, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = (float)b[i];
+}
+template <> __device__ __forceinline__ void ess_up4<true>(uint2 r, float (&f)[4]) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const f16x4 b = __builtin_bit_cast(f16x4, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = (float)b[i];
+}
 __device__ __forceinline__ float ess_bload(ess_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
@@ -80,19 +118,17 @@ __device__ __forceinline__ void ess_bstore(float v, ess_rsrc r, unsigned voff, u
 // bias-only case keeps no dead registers
 // BF16_C8 copy of an output: this lane's 4 consecutive channels (4*half .. 4*half+3 of 8-channel block `blk`) of pixel
 // `pix` are 8 bytes; the two half-waves interleave to full 16-byte pixel vectors, 32 pixels = 512 contiguous bytes.
+template <bool H = false>
 __device__ __forceinline__ void ess_store_bf16x4(void* base, size_t sample_blk0, int blk, unsigned HW, int pix, int half,
                                                  float v0, float v1, float v2, float v3) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  bf16x4 b;
-  b[0] = (__bf16)v0; b[1] = (__bf16)v1; b[2] = (__bf16)v2; b[3] = (__bf16)v3;
-  *(uint2*)((char*)base + ((sample_blk0 + blk) * HW + pix) * 16 + 8 * half) = __builtin_bit_cast(uint2, b);
+  *(uint2*)((char*)base + ((sample_blk0 + blk) * HW + pix) * 16 + 8 * half) = ess_cvt4<H>(v0, v1, v2, v3);
 }
 
 // FIX pins the wave-uniform run-time options at compile time for the combinations the train step launches most (each
 // one is a branch inside 16 x MB x NBW unrolled rows otherwise -- code size and registers):
 //   0: nothing pinned;  1: no activation, no BF16_C8 copy, one fp32 output;  2: ReLU, one output (copy / fp32 optional);
 //   3: no activation, no copy, split output (the data-gradient of a concat convolution)
-template <int MB, int EPI, bool SC, bool IN, int FIX = 0>
+template <int MB, int EPI, bool SC, bool IN, int FIX = 0, bool H = false>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
                                                    const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned plane_b) {
   constexpr int COT = MB * 32;
@@ -149,7 +185,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKArgs& a, f32x16 (&
         if (has_bf) {  // wave-uniform
           q[r & 3] = co < c_out ? v : 0.f;  // tail channels of the last block are zero
           if ((r & 3) == 3 && pixi[nb] >= 0 && (rowbase >> 3) + (r >> 2) < nblk)
-            ess_store_bf16x4(a.out_bf, (size_t)n * nblk, (rowbase >> 3) + (r >> 2), HW, pixi[nb], half, q[0], q[1], q[2], q[3]);
+            ess_store_bf16x4<H>(a.out_bf, (size_t)n * nblk, (rowbase >> 3) + (r >> 2), HW, pixi[nb], half, q[0], q[1], q[2], q[3]);
         }
         if (FIX == 3 || split > 0) {  // the two halves of a wave may straddle the split: tensor and channel are chosen per lane
           const unsigned pixo = voff[nb] == ESS_OOB ? ESS_OOB : voff[nb] - 4u * half * plane_b;
@@ -315,7 +351,7 @@ __device__ __forceinline__ void ess_state_store4(const EssStateIO& s, int hb, in
 // accumulator register 8*q2 + jj is the update and 8*q2 + 4 + jj the reset gate of hidden (ct*MB+mb)*16 + q2*8 + 4*half + jj.
 // u = sigmoid(.) -> out;  (sigmoid(.) * h_prev) -> out2 (fp32) and / or out_bf (BF16_C8).  h_prev NULL reads as zeros; with
 // neither out2 nor out_bf the reset gate is not evaluated (first time step of a sequence: r*h = 0 whatever r is).
-template <int MB>
+template <int MB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_gru_ur(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
                                                      const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned HW, bool biased) {
   constexpr int COT = MB * 32;
@@ -361,7 +397,7 @@ __device__ __forceinline__ void conv_epilogue_gru_ur(const ConvKArgs& a, f32x16 
           }
           if (a.out2) ess_state_store4(rh_io, hb, pixi[nb], half, voff[nb], rh);
           if (a.out_bf && pixi[nb] >= 0 && hb < nbh)
-            ess_store_bf16x4(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, rh[0], rh[1], rh[2], rh[3]);
+            ess_store_bf16x4<H>(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, rh[0], rh[1], rh[2], rh[3]);
         }
       }
     }
@@ -370,7 +406,7 @@ __device__ __forceinline__ void conv_epilogue_gru_ur(const ConvKArgs& a, f32x16 
 
 // candidate: packed row = hidden channel, so accumulator register 4*j + jj belongs to hidden (ct*MB+mb)*32 + 8*j + 4*half + jj.
 // h' = h_prev (1 - u) + tanh(.) u -> out (fp32, may be NULL when only the copy is wanted) and / or out_bf (BF16_C8 copy).
-template <int MB>
+template <int MB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half,
                                                       const unsigned (&voff)[NBW], const int (&pixi)[NBW], unsigned HW, bool biased) {
   constexpr int COT = MB * 32;
@@ -419,7 +455,7 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
         }
         if (a.out) ess_state_store4(o_io, hb, pixi[nb], half, voff[nb], hn);
         if (a.out_bf && pixi[nb] >= 0 && hb < nbh)
-          ess_store_bf16x4(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, hn[0], hn[1], hn[2], hn[3]);
+          ess_store_bf16x4<H>(a.out_bf, (size_t)n * nbh, hb, HW, pixi[nb], half, hn[0], hn[1], hn[2], hn[3]);
       }
     }
   }
@@ -428,7 +464,7 @@ __device__ __forceinline__ void conv_epilogue_gru_out(const ConvKArgs& a, f32x16
 // ---- the two ConvGRU epilogues of the lean time steps as straight-line code (what conv_epilogue_lstm_c8 is to the LSTM one):
 // F32_C8 states in and out, bias in the accumulators, every hidden channel of the tile real; state loads issued first, 16-byte
 // stores, the BF16_C8 tensors (r*h, the copy of h') as whole pixel vectors via a half-wave swap between two hidden blocks.
-template <int MB, int NB>
+template <int MB, int NB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
                                                         const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
@@ -459,17 +495,17 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         u32x4c uv;
-        bf16x4 rb;
         f16x4e uh;
+        float rf[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float ug = ess_sigmoid(acc[mb][nb][8 * q2 + jj]);
           uv[jj] = __builtin_bit_cast(unsigned, ug);
           uh[jj] = (_Float16)ug;
-          if (need_r) rb[jj] = (__bf16)(ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj]) * __builtin_bit_cast(float, (unsigned)hp[nb][q2][jj]));
+          if (need_r) rf[jj] = ess_sigmoid(acc[mb][nb][8 * q2 + 4 + jj]) * __builtin_bit_cast(float, (unsigned)hp[nb][q2][jj]);
         }
         if (!u16) __builtin_amdgcn_raw_buffer_store_b128(uv, r_u, (int)vo[nb][q2], 0, ESS_GRU_AUX);
-        pk[q2] = __builtin_bit_cast(uint2, rb);
+        pk[q2] = ess_cvt4<H>(rf[0], rf[1], rf[2], rf[3]);
         pu[q2] = __builtin_bit_cast(uint2, uh);
       }
       if (u16) {  // (uniform) whole pixel vectors, as r*h below: lanes 0-31 hidden block 2 (ct MB + mb), lanes 32-63 the next one
@@ -490,7 +526,7 @@ __device__ __forceinline__ void conv_epilogue_gru_ur_c8(const ConvKArgs& a, f32x
   }
 }
 
-template <int MB, int NB>
+template <int MB, int NB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
                                                          const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
@@ -548,17 +584,17 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x4c ov;
-        bf16x4 ob;
+        float of[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float o = ess_tanh(acc[mb][nb][4 * j + jj]);
           const float hprev = __builtin_bit_cast(float, (unsigned)hv[j][jj]), u = __builtin_bit_cast(float, (unsigned)uv[j][jj]);
           const float hn = hprev * (1.f - u) + o * u;
           ov[jj] = __builtin_bit_cast(unsigned, hn);
-          ob[jj] = (__bf16)hn;
+          of[jj] = hn;
         }
         if (a.out) __builtin_amdgcn_raw_buffer_store_b128(ov, r_o, (int)vo[j], 0, ESS_GRU_AUX);  // (uniform)
-        pk[j] = __builtin_bit_cast(uint2, ob);
+        pk[j] = ess_cvt4<H>(of[0], of[1], of[2], of[3]);
       }
       if (a.out_bf) {  // (uniform)
 #pragma unroll
@@ -600,7 +636,7 @@ __device__ __forceinline__ void conv_bias_init(const ConvKArgs& a, f32x16 (&acc)
 // ReLU, out_split (channels >= out_split go to out2: the data-gradient of a concat convolution; out_split % 8 == 0),
 // SUMPOOL2 (the first output leaves as the 2x2 pixel sum at half resolution: gradient of a nearest-x2-upsampled source).
 // Channels past C_out inside the last block are written as zeros (the BF16_C8 contract).
-template <int MB, bool SC, bool SH>
+template <int MB, bool SC, bool SH, bool H = false>
 __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                                       int y0, const int (&ly)[NBW]) {
   static_assert(NBW == 2, "the one-row pooled pairing assumes two pixel blocks per wave");
@@ -686,9 +722,10 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
             const auto s0 = __builtin_amdgcn_permlane32_swap(rv[nb][0], rv[nb][2], false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(rv[nb][1], rv[nb][3], false, false);
             const uint2 rr = jj == 0 ? make_uint2(s0[0], s1[0]) : make_uint2(s0[1], s1[1]);
-            const bf16x4 rb = __builtin_bit_cast(bf16x4, rr);
+            float rf[4];
+            ess_up4<H>(rr, rf);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[nb][i] += (float)rb[i];
+            for (int i = 0; i < 4; ++i) v[nb][i] += rf[i];
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -713,17 +750,10 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
         }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-          if (a.out_f16) {  // (uniform)
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = ess_f16_sat(v[nb][i]);
-            pk[jj][nb] = __builtin_bit_cast(uint2, h);
+          if (H || a.out_f16) {  // (uniform)
+            pk[jj][nb] = ess_cvt4<true>(v[nb][0], v[nb][1], v[nb][2], v[nb][3]);
           } else {
-            bf16x4 b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[nb][i];
-            pk[jj][nb] = __builtin_bit_cast(uint2, b);
+            pk[jj][nb] = ess_cvt4<false>(v[nb][0], v[nb][1], v[nb][2], v[nb][3]);
           }
         }
       }
@@ -753,16 +783,16 @@ __device__ __forceinline__ void conv_epilogue_c8_impl(const ConvKArgs& a, f32x16
 // straight-line code: the general function spends 2.5-4 k cycles per 32-channel block in uniform branches, channel masks and
 // selects (cycle stamps, round 3: 7.3-8.5 k cycles per 64 x 64 tile of a bias-only layer with nothing to load), this one is
 // per block 64 optional v_max, 32 packed conversions, 8 half-wave swaps and four 16-byte stores.
-template <int MB, bool SC, bool SH, bool F16, bool RELU, bool RES, int NB>
+template <int MB, bool SC, bool SH, bool F16, bool RELU, bool RES, int NB, bool H = false, bool HILO = false>
 __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
                                                        int x, int y0, const int (&ly)[NB]) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  static_assert(!HILO || H, "a [hi | lo] output is a half tensor");
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
   constexpr int COT = MB * 32;
   const unsigned HW = (unsigned)(a.Hout * a.Wout);
   const int nblk = a.Cout >> 3;
-  const ess_rsrc r_o = ess_make_rsrc((const char*)a.out + (size_t)n * nblk * HW * 16, (size_t)nblk * HW * 16);
+  // (HILO: the output tensor holds 2 nblk blocks per sample -- hi in [0, nblk), lo in [nblk, 2 nblk))
+  const ess_rsrc r_o = ess_make_rsrc((const char*)a.out + (size_t)n * (HILO ? 2 : 1) * nblk * HW * 16, (size_t)(HILO ? 2 : 1) * nblk * HW * 16);
   const ess_rsrc r_rs = ess_make_rsrc((const char*)(RES ? a.residual : a.out) + (size_t)n * nblk * HW * 16, RES ? (size_t)nblk * HW * 16 : 0);
   unsigned pix16[NB];
 #pragma unroll
@@ -796,6 +826,7 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
 #pragma unroll
     for (int jp = 0; jp < 4; jp += 2) {
       uint2 pk[2][NB];
+      uint2 pl[HILO ? 2 : 1][HILO ? NB : 1];  // (HILO) the lo parts
       uint2 rr[2][NB];  // residual, exchanged to the accumulator layout: [block of the pair][pixel block] = this lane's 4 channels
       if constexpr (RES) {
 #pragma unroll
@@ -823,25 +854,17 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
             v[0] += shv[j].x; v[1] += shv[j].y; v[2] += shv[j].z; v[3] += shv[j].w;
           }
           if constexpr (RES) {
-            const bf16x4 rb = __builtin_bit_cast(bf16x4, rr[jj][nb]);
+            float rf[4];
+            ess_up4<H>(rr[jj][nb], rf);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += (float)rb[i];
+            for (int i = 0; i < 4; ++i) v[i] += rf[i];
           }
           if constexpr (RELU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
           }
-          if constexpr (F16) {
-            f16x4 h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[i] = ess_f16_sat(v[i]);
-            pk[jj][nb] = __builtin_bit_cast(uint2, h);
-          } else {
-            bf16x4 b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = (__bf16)v[i];
-            pk[jj][nb] = __builtin_bit_cast(uint2, b);
-          }
+          pk[jj][nb] = ess_cvt4<F16 || H>(v[0], v[1], v[2], v[3]);
+          if constexpr (HILO) pl[jj][nb] = ess_cvt4_lo(v[0], v[1], v[2], v[3]);
         }
       }
       const unsigned plane = (unsigned)((rowbase >> 3) + jp + half) * HW * 16u;
@@ -851,6 +874,12 @@ __device__ __forceinline__ void conv_epilogue_c8_plain(const ConvKArgs& a, f32x1
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][nb].y, pk[1][nb].y, false, false);
         const u32x4e vec = {s0[0], s1[0], s0[1], s1[1]};
         __builtin_amdgcn_raw_buffer_store_b128(vec, r_o, (int)(pix16[nb] != ESS_OOB ? plane + pix16[nb] : ESS_OOB), 0, ESS_C8_AUX);
+        if constexpr (HILO) {
+          const auto t0 = __builtin_amdgcn_permlane32_swap(pl[0][nb].x, pl[1][nb].x, false, false);
+          const auto t1 = __builtin_amdgcn_permlane32_swap(pl[0][nb].y, pl[1][nb].y, false, false);
+          const u32x4e vlo = {t0[0], t1[0], t0[1], t1[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(vlo, r_o, (int)(pix16[nb] != ESS_OOB ? plane + (unsigned)nblk * HW * 16u + pix16[nb] : ESS_OOB), 0, ESS_C8_AUX);
+        }
       }
     }
   }
@@ -938,11 +967,26 @@ __device__ __forceinline__ void conv_epilogue_c8_dgrad(const ConvKArgs& a, f32x1
   }
 }
 
-template <int MB, bool SC, bool SH>
+template <int MB, bool SC, bool SH, bool H = false>
 __device__ __forceinline__ void conv_epilogue_c8_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                                      int y0, const int (&ly)[NBW]) {
   // (all uniform) the plain form needs every channel of this workgroup's tile to exist, so the masks can go
   const bool relu = a.act == ESS_ACT_RELU, res = a.residual != nullptr;
+  if constexpr (H) {  // half operands: half outputs; forward forms only (no data-gradient form); [hi | lo] only in the plain form (the entry point checks)
+    const bool plain_h = a.out_split <= 0 && (a.act == ESS_ACT_NONE || relu) && (a.Cout % (MB * 32)) == 0;
+    if (!plain_h) { conv_epilogue_c8_impl<MB, SC, SH, true>(a, acc, ct, n, half, x, y0, ly); return; }
+    if (a.hilo) {
+      if (relu) conv_epilogue_c8_plain<MB, SC, SH, true, true, false, NBW, true, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_plain<MB, SC, SH, true, false, false, NBW, true, true>(a, acc, ct, n, half, x, y0, ly);
+    } else if (res) {
+      if (relu) conv_epilogue_c8_plain<MB, SC, SH, true, true, true, NBW, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_plain<MB, SC, SH, true, false, true, NBW, true>(a, acc, ct, n, half, x, y0, ly);
+    } else {
+      if (relu) conv_epilogue_c8_plain<MB, SC, SH, true, true, false, NBW, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_plain<MB, SC, SH, true, false, false, NBW, true>(a, acc, ct, n, half, x, y0, ly);
+    }
+    return;
+  }
   const bool plain = a.out_split <= 0 && (a.act == ESS_ACT_NONE || relu) && (a.Cout % (MB * 32)) == 0 && !(a.out_f16 && (relu || res));
   if constexpr (!SC && !SH) {
     const bool pool = a.act == ESS_ACT_SUMPOOL2;
@@ -967,18 +1011,18 @@ __device__ __forceinline__ void conv_epilogue_c8_sel(const ConvKArgs& a, f32x16 
 }
 
 // biased: the caller started its accumulators from the shift vector (conv_bias_init), nothing is left to add here
-template <int MB>
+template <int MB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                                  int y0, const int (&ly)[NBW], bool biased = false) {
 #ifndef ESS_C8_EPI_GENERAL
   if (biased) {  // (uniform)
-    conv_epilogue_c8_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+    conv_epilogue_c8_sel<MB, false, false, H>(a, acc, ct, n, half, x, y0, ly);
   } else if (a.scale) {
-    if (a.shift) conv_epilogue_c8_sel<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
-    else conv_epilogue_c8_sel<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
+    if (a.shift) conv_epilogue_c8_sel<MB, true, true, H>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_sel<MB, true, false, H>(a, acc, ct, n, half, x, y0, ly);
   } else {
-    if (a.shift) conv_epilogue_c8_sel<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
-    else conv_epilogue_c8_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+    if (a.shift) conv_epilogue_c8_sel<MB, false, true, H>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_sel<MB, false, false, H>(a, acc, ct, n, half, x, y0, ly);
   }
   return;
 #endif
@@ -996,10 +1040,20 @@ __device__ __forceinline__ void conv_epilogue_c8(const ConvKArgs& a, f32x16 (&ac
 // Epilogue of the wide-tile kernel (conv_bf16_wide.hip; NB = 5 pixel blocks per wave): the straight-line forms only.  The
 // dispatcher routes a launch to that kernel only when one of them applies (conv_bf16.hip, wide_pick / wide_pick_recurrent): one output with
 // every channel of the tile real (scale / shift / residual / ReLU / F16 options), or the two outputs of a concat's data-gradient.
-template <int MB, bool SC, bool SH, int NB>
+template <int MB, bool SC, bool SH, int NB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_c8_wide_sel(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half, int x,
                                                           int y0, const int (&ly)[NB]) {
   const bool relu = a.act == ESS_ACT_RELU, res = a.residual != nullptr;
+  if constexpr (H) {  // half operands: half outputs (plain forms without a residual only: the dispatcher routes nothing else here)
+    if (a.hilo) {
+      if (relu) conv_epilogue_c8_plain<MB, SC, SH, true, true, false, NB, true, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_plain<MB, SC, SH, true, false, false, NB, true, true>(a, acc, ct, n, half, x, y0, ly);
+    } else {
+      if (relu) conv_epilogue_c8_plain<MB, SC, SH, true, true, false, NB, true>(a, acc, ct, n, half, x, y0, ly);
+      else conv_epilogue_c8_plain<MB, SC, SH, true, false, false, NB, true>(a, acc, ct, n, half, x, y0, ly);
+    }
+    return;
+  }
   if constexpr (!SC && !SH) {
     if (a.out_split > 0) { conv_epilogue_c8_dgrad<MB, false>(a, acc, ct, n, half, x, y0, ly); return; }
   }
@@ -1013,17 +1067,17 @@ __device__ __forceinline__ void conv_epilogue_c8_wide_sel(const ConvKArgs& a, f3
     else conv_epilogue_c8_plain<MB, SC, SH, false, false, false>(a, acc, ct, n, half, x, y0, ly);
   }
 }
-template <int MB, int NB>
+template <int MB, int NB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_c8_wide(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half, int x,
                                                       int y0, const int (&ly)[NB], bool biased) {
   if (biased) {  // (uniform; the accumulators started from the shift vector)
-    conv_epilogue_c8_wide_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+    conv_epilogue_c8_wide_sel<MB, false, false, NB, H>(a, acc, ct, n, half, x, y0, ly);
   } else if (a.scale) {
-    if (a.shift) conv_epilogue_c8_wide_sel<MB, true, true>(a, acc, ct, n, half, x, y0, ly);
-    else conv_epilogue_c8_wide_sel<MB, true, false>(a, acc, ct, n, half, x, y0, ly);
+    if (a.shift) conv_epilogue_c8_wide_sel<MB, true, true, NB, H>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_wide_sel<MB, true, false, NB, H>(a, acc, ct, n, half, x, y0, ly);
   } else {
-    if (a.shift) conv_epilogue_c8_wide_sel<MB, false, true>(a, acc, ct, n, half, x, y0, ly);
-    else conv_epilogue_c8_wide_sel<MB, false, false>(a, acc, ct, n, half, x, y0, ly);
+    if (a.shift) conv_epilogue_c8_wide_sel<MB, false, true, NB, H>(a, acc, ct, n, half, x, y0, ly);
+    else conv_epilogue_c8_wide_sel<MB, false, false, NB, H>(a, acc, ct, n, half, x, y0, ly);
   }
 }
 
@@ -1034,17 +1088,17 @@ __device__ __forceinline__ void conv_epilogue_c8_wide(const ConvKArgs& a, f32x16
 // arithmetic per 64 x 256 tile, 15-26 % of a matrix wave's tile.  Here the four activations that do not need c_prev (80 % of
 // the transcendental work) run, in place in the accumulators, while the loads are in flight.  The BF16_C8 copy of h' leaves as
 // whole 16-byte pixel vectors (half-wave swap between the two hidden blocks of a pair, as in conv_epilogue_c8).
-template <int MB, int NB>
+template <int MB, int NB, bool H = false>
 __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16 (&acc)[MB][NB], int ct, int n, int half,
                                                       const int (&pixi)[NB], unsigned HW) {
   typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int nbh = a.hid >> 3;
+  const int ncp = (H && a.hilo) ? 2 : 1;  // (uniform) [hi | lo] copy of h': 2 nbh blocks per sample (ESS_LSTM_H_HILO)
   const size_t state_b = (size_t)nbh * HW * 32;
   const ess_rsrc r_prev = ess_make_rsrc(a.aux0 ? (const char*)(a.aux0 + (size_t)n * nbh * 8 * HW) : (const char*)a.out2, a.aux0 ? state_b : 0);
   const ess_rsrc r_c = ess_make_rsrc(a.out2 + (size_t)n * nbh * 8 * HW, state_b);
   const ess_rsrc r_h = ess_make_rsrc(a.out ? a.out + (size_t)n * nbh * 8 * HW : a.out2, a.out ? state_b : 0);
-  const ess_rsrc r_hb = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.out2, a.out_bf ? (size_t)nbh * HW * 16 : 0);
+  const ess_rsrc r_hb = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * ncp * nbh * HW * 16 : (const char*)a.out2, a.out_bf ? (size_t)ncp * nbh * HW * 16 : 0);
   unsigned vo[MB][NB];
   u32x4c cp[MB][NB];
 #pragma unroll
@@ -1096,12 +1150,7 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
       }
   }
   if (a.out_bf) {  // (uniform)
-    auto pack = [&](int mb, int nb) {
-      bf16x4 b;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) b[i] = (__bf16)hn[mb][nb][i];
-      return __builtin_bit_cast(uint2, b);
-    };
+    auto pack = [&](int mb, int nb) { return ess_cvt4<H>(hn[mb][nb][0], hn[mb][nb][1], hn[mb][nb][2], hn[mb][nb][3]); };
     if constexpr (MB >= 2) {
 #pragma unroll
       for (int mb = 0; mb < MB; mb += 2)
@@ -1113,18 +1162,28 @@ __device__ __forceinline__ void conv_epilogue_lstm_c8(const ConvKArgs& a, f32x16
           const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};  // lanes 0-31: block mb, lanes 32-63: block mb + 1
           const unsigned o = pixi[nb] >= 0 ? ((unsigned)(ct * MB + mb + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
           __builtin_amdgcn_raw_buffer_store_b128(vec, r_hb, (int)o, 0, ESS_EPI_AUX);
+          if constexpr (H) {
+            if (ncp == 2) {  // (uniform) the lo parts, nbh blocks further on
+              const uint2 q0 = ess_cvt4_lo(hn[mb][nb][0], hn[mb][nb][1], hn[mb][nb][2], hn[mb][nb][3]);
+              const uint2 q1 = ess_cvt4_lo(hn[mb + 1][nb][0], hn[mb + 1][nb][1], hn[mb + 1][nb][2], hn[mb + 1][nb][3]);
+              const auto t0 = __builtin_amdgcn_permlane32_swap(q0.x, q1.x, false, false);
+              const auto t1 = __builtin_amdgcn_permlane32_swap(q0.y, q1.y, false, false);
+              const u32x4c vlo = {t0[0], t1[0], t0[1], t1[1]};
+              __builtin_amdgcn_raw_buffer_store_b128(vlo, r_hb, (int)(o == ESS_OOB ? ESS_OOB : o + (unsigned)nbh * HW * 16u), 0, ESS_EPI_AUX);
+            }
+          }
         }
     } else {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        if (pixi[nb] >= 0) ess_store_bf16x4(a.out_bf, (size_t)n * nbh, ct, HW, pixi[nb], half, hn[0][nb][0], hn[0][nb][1], hn[0][nb][2], hn[0][nb][3]);
+        if (pixi[nb] >= 0) ess_store_bf16x4<H>(a.out_bf, (size_t)n * nbh, ct, HW, pixi[nb], half, hn[0][nb][0], hn[0][nb][1], hn[0][nb][2], hn[0][nb][3]);
     }
   }
 }
 
 // ALLOW8 = false: the caller dispatches BF16_C8 outputs to a dedicated kernel instantiation (conv_epilogue_c8 only: a fraction
 // of the code and registers of this function), so the run-time branch to it is left out here.
-template <int MB, int EPI, bool ALLOW8 = true>
+template <int MB, int EPI, bool ALLOW8 = true, bool H = false>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[MB][NBW], int ct, int n, int half, int x,
                                               int y0, const int (&ly)[NBW], bool biased = false) {
   constexpr int COT = MB * 32;
@@ -1142,7 +1201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
   if constexpr (EPI == ESS_EPI_LSTM) {
 #ifndef ESS_LSTM_EPI_GENERAL
     if (biased && a.fmt_out == ESS_FMT_F32_C8 && (!a.aux0 || a.fmt_res == ESS_FMT_F32_C8) && (a.hid % (8 * MB)) == 0) {  // (uniform)
-      conv_epilogue_lstm_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      conv_epilogue_lstm_c8<MB, NBW, H>(a, acc, ct, n, half, pixi, HW);
       return;
     }
 #endif
@@ -1150,36 +1209,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
   if constexpr (EPI == ESS_EPI_GRU_OUT) {
 #ifndef ESS_GRU_EPI_GENERAL
     if (biased && a.fmt_res == ESS_FMT_F32_C8 && a.aux1 && (!a.out || a.fmt_out == ESS_FMT_F32_C8) && (a.hid % (32 * MB)) == 0) {  // (uniform)
-      conv_epilogue_gru_out_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      conv_epilogue_gru_out_c8<MB, NBW, H>(a, acc, ct, n, half, pixi, HW);
       return;
     }
 #endif
-    conv_epilogue_gru_out<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
+    conv_epilogue_gru_out<MB, H>(a, acc, ct, n, half, voff, pixi, HW, biased);
   } else if constexpr (EPI == ESS_EPI_GRU_UR) {
 #ifndef ESS_GRU_EPI_GENERAL
     if (biased && a.out && !a.out2 && a.fmt_out == ESS_FMT_F32_C8 && (!a.aux0 || a.fmt_res == ESS_FMT_F32_C8) && (a.hid % (16 * MB)) == 0) {  // (uniform)
-      conv_epilogue_gru_ur_c8<MB>(a, acc, ct, n, half, pixi, HW);
+      conv_epilogue_gru_ur_c8<MB, NBW, H>(a, acc, ct, n, half, pixi, HW);
       return;
     }
 #endif
-    conv_epilogue_gru_ur<MB>(a, acc, ct, n, half, voff, pixi, HW, biased);
+    conv_epilogue_gru_ur<MB, H>(a, acc, ct, n, half, voff, pixi, HW, biased);
   } else if constexpr (EPI == ESS_EPI_LINEAR) {
     if constexpr (ALLOW8) {
-      if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB>(a, acc, ct, n, half, x, y0, ly); return; }
+      if (a.fmt_out == ESS_FMT_BF16_C8) { conv_epilogue_c8<MB, H>(a, acc, ct, n, half, x, y0, ly); return; }
     }
     const bool bare = a.act == ESS_ACT_NONE && !a.out_bf && a.out;
     if (a.act == ESS_ACT_SUMPOOL2) conv_epilogue_pool<MB>(a, acc, ct, n, half, x, y0, ly, plane_b);
     else if (bare && !a.scale && !a.residual && a.out_split == 0) conv_epilogue_plain<MB>(a, acc, ct, n, half, voff, plane_b);
     else if (bare && !a.scale && a.residual && a.out_split == 0)
-      conv_epilogue_rows<MB, EPI, false, true, 1>(a, acc, ct, n, half, voff, pixi, plane_b);
+      conv_epilogue_rows<MB, EPI, false, true, 1, H>(a, acc, ct, n, half, voff, pixi, plane_b);
     else if (bare && !a.scale && !a.residual && a.out_split > 0)
-      conv_epilogue_rows<MB, EPI, false, false, 3>(a, acc, ct, n, half, voff, pixi, plane_b);
+      conv_epilogue_rows<MB, EPI, false, false, 3, H>(a, acc, ct, n, half, voff, pixi, plane_b);
     else if (a.act == ESS_ACT_RELU && a.scale && !a.residual && a.out_split == 0)
-      conv_epilogue_rows<MB, EPI, true, false, 2>(a, acc, ct, n, half, voff, pixi, plane_b);
-    else if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false>(a, acc, ct, n, half, voff, pixi, plane_b);
-    else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true>(a, acc, ct, n, half, voff, pixi, plane_b);
-    else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false>(a, acc, ct, n, half, voff, pixi, plane_b);
-    else conv_epilogue_rows<MB, EPI, true, true>(a, acc, ct, n, half, voff, pixi, plane_b);
+      conv_epilogue_rows<MB, EPI, true, false, 2, H>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.scale && !a.residual) conv_epilogue_rows<MB, EPI, false, false, 0, H>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.scale) conv_epilogue_rows<MB, EPI, false, true, 0, H>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else if (!a.residual) conv_epilogue_rows<MB, EPI, true, false, 0, H>(a, acc, ct, n, half, voff, pixi, plane_b);
+    else conv_epilogue_rows<MB, EPI, true, true, 0, H>(a, acc, ct, n, half, voff, pixi, plane_b);
   } else {
     const ess_rsrc r_out = ess_make_rsrc(a.out + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
     const ess_rsrc r_out2 = ess_make_rsrc(a.out2 + (size_t)n * a.hid * HW, (size_t)a.hid * plane_b);
@@ -1262,7 +1321,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, f32x16 (&acc)[
             }
           }
           if (a.out_bf && pixi[nb] >= 0 && ct * MB + mb < ((a.hid + 7) >> 3))  // hidden block ct*MB+mb, channels 4*half..+3
-            ess_store_bf16x4(a.out_bf, (size_t)n * ((a.hid + 7) >> 3), ct * MB + mb, HW, pixi[nb], half, hq[0], hq[1], hq[2], hq[3]);
+            ess_store_bf16x4<H>(a.out_bf, (size_t)n * ((a.hid + 7) >> 3), ct * MB + mb, HW, pixi[nb], half, hq[0], hq[1], hq[2], hq[3]);
         }
       }
     }
@@ -1278,7 +1337,10 @@ inline bool is_bf16(const EssConvDesc* d) { return d->compute == ESS_COMPUTE_BF1
 inline bool ws_enabled();
 // ESS_COMPUTE_BF16X3 resolves, per convolution, to the arithmetic that runs: the bf16 3x3 / stride-1 wave-specialised kernel with
 // split operands (`split`), or the exact-fp32 kernels for every other geometry.  The entry points work on the resolved copy.
-struct ResolvedDesc { EssConvDesc d; bool split; };
+// ESS_COMPUTE_F16 resolves to the bf16 kernels' H = true instantiations (`f16`): same geometry, plans and pack layouts, IEEE-half
+// elements in every 16-bit tensor of the call (the resolved copy names them BF16_C8, the kernels' only 16-bit layout);
+// `hilo`: the 16-bit output (LINEAR, ESS_FMT_F16_C8_HILO) / the copy of h' (LSTM, act = ESS_LSTM_H_HILO) leaves as [hi | lo].
+struct ResolvedDesc { EssConvDesc d; bool split; bool f16 = false; bool hilo = false; };
 // ESS_CONV_PAIR=0 switches the tap-paired 5x5 kernel off (tuning); ONE reading of the variable for resolve_compute and is_paired
 inline bool pair_enabled() {
   static const bool on = [] { const char* e = getenv("ESS_CONV_PAIR"); return !(e && e[0] == '0'); }();
@@ -1286,6 +1348,21 @@ inline bool pair_enabled() {
 }
 inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
   ResolvedDesc r{*d, false};
+  if (d->compute == ESS_COMPUTE_F16) {
+    r.f16 = true;
+    r.d.compute = ESS_COMPUTE_BF16;
+    if (r.d.fmt0 == ESS_FMT_F16_C8) r.d.fmt0 = ESS_FMT_BF16_C8;
+    if (r.d.fmt1 == ESS_FMT_F16_C8) r.d.fmt1 = ESS_FMT_BF16_C8;
+    if (r.d.fmt_res == ESS_FMT_F16_C8) r.d.fmt_res = ESS_FMT_BF16_C8;
+    if (d->epilogue == ESS_EPI_LINEAR) {
+      r.hilo = d->fmt_out == ESS_FMT_F16_C8_HILO;
+      if (d->fmt_out == ESS_FMT_F16_C8 || d->fmt_out == ESS_FMT_F16_C8_HILO) r.d.fmt_out = ESS_FMT_BF16_C8;
+    } else if (d->epilogue == ESS_EPI_LSTM) {
+      r.hilo = d->act == ESS_LSTM_H_HILO;
+      r.d.act = ESS_ACT_NONE;
+    }
+    return r;
+  }
   if (d->compute == ESS_COMPUTE_BF16X3) {
     // 3x3 / stride 1 (any epilogue): the wave-specialised kernel; 5x5 LINEAR with at least one 8-channel chunk of input (the
     // frozen E2VID's stride-2 encoder convolutions and upsample-conv decoders): the tap-paired kernel.  The 2-channel 5x5 head
@@ -1411,6 +1488,21 @@ inline Geom choose_geom(const EssConvDesc* d) {
 
 inline int validate(const EssConvDesc* d) {
   ESS_CHECK_ARG(d != nullptr, "conv: null descriptor");
+  if (d->compute == ESS_COMPUTE_F16) {
+    // half operands: the 16-bit tensors are F16_C8 (never BF16_C8); fp32 NCHW sources only where a kernel rounds them to half itself
+    // (the 5x5 head); forward forms only
+    ESS_CHECK_ARG(d->fmt0 != ESS_FMT_BF16_C8 && d->fmt1 != ESS_FMT_BF16_C8 && d->fmt_out != ESS_FMT_BF16_C8 && d->fmt_res != ESS_FMT_BF16_C8,
+                  "conv(f16): 16-bit tensors of a half-operand convolution are ESS_FMT_F16_C8");
+    ESS_CHECK_ARG(d->act != ESS_ACT_SUMPOOL2 || d->epilogue != ESS_EPI_LINEAR, "conv(f16): no pooled (data-gradient) form");
+    ESS_CHECK_ARG(d->mode0 != ESS_SRC_ZERO_UP2 && d->mode1 != ESS_SRC_ZERO_UP2, "conv(f16): no zero-inserted sources");
+    if (d->epilogue == ESS_EPI_LINEAR && d->fmt_out == ESS_FMT_F16_C8_HILO)
+      ESS_CHECK_ARG(d->out_split == 0 && (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU) && (d->C_out % 64) == 0,
+                    "conv(f16): a [hi | lo] output needs act in {none, relu}, no out_split, C_out %% 64 == 0");
+    if (d->epilogue == ESS_EPI_LSTM) ESS_CHECK_ARG(d->act == 0 || d->act == ESS_LSTM_H_HILO, "conv(f16, LSTM): act is 0 or ESS_LSTM_H_HILO");
+    const ResolvedDesc r = resolve_compute(d);
+    return validate(&r.d);
+  }
+  ESS_CHECK_ARG(d->fmt_out != ESS_FMT_F16_C8_HILO, "conv: ESS_FMT_F16_C8_HILO is an output format of ESS_COMPUTE_F16");
   ESS_CHECK_ARG(d->N > 0 && d->H_in > 0 && d->W_in > 0 && d->C0 > 0 && d->C1 >= 0 && d->C_out > 0, "conv: bad extents");
   ESS_CHECK_ARG(d->ksize == 1 || d->ksize == 3 || d->ksize == 5 || d->ksize == 7, "conv: ksize %d unsupported", d->ksize);
   ESS_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported", d->stride);
@@ -1572,7 +1664,7 @@ static __global__ void pack_rows_kernel(const float* v, const float* v2, float f
 // bf16-MFMA variant (conv_bf16.hip)
 int conv_bf16_launch(const EssConvDesc* d, const EssConvPlan& pl, const Geom& g, const ConvKArgs& a, hipStream_t st);
 int conv_bf16_pack_weights(const EssConvDesc* d, const EssConvPlan& pl, int w_kind, const float* w, const float* w2, void* packed,
-                           hipStream_t st, bool split = false);
+                           hipStream_t st, bool split = false, bool f16 = false);
 int conv_bf16_pack_weights_multi(const EssConvDesc* descs, const int32_t* kinds, const float* const* w, void* const* packed, int count,
                                  hipStream_t st);
 void conv_bf16_s2d_pick(const EssConvDesc* d, int* cw, int* tiles, int* tiles_x, int* tiles_y);

@@ -205,7 +205,7 @@ extern "C" int ess_conv2d_pack_weights(const EssConvDesc* d, int w_kind, const f
   d = &rd.d;
   EssConvPlan pl;
   make_plan(d, &pl, rd.split);
-  if (is_bf16(d)) return conv_bf16_pack_weights(d, pl, w_kind, w, w2, packed, (hipStream_t)stream, rd.split);
+  if (is_bf16(d)) return conv_bf16_pack_weights(d, pl, w_kind, w, w2, packed, (hipStream_t)stream, rd.split, rd.f16);
   const int64_t total = pl.packed_elems;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, w2,
                      (float*)packed, total, pl.cout_tile, pl.ck, pl.n_chunks, d->ksize, d->C0 + d->C1, d->C_out, d->epilogue,
@@ -240,7 +240,7 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   // ESS_FMT_F16_C8 output: the BF16_C8-output path with half elements (LINEAR epilogue; no pooled output, no out_split)
   EssConvDesc dcopy;
   bool out_f16 = false;
-  if (d && d->fmt_out == ESS_FMT_F16_C8) {
+  if (d && d->fmt_out == ESS_FMT_F16_C8 && d->compute != ESS_COMPUTE_F16) {
     ESS_CHECK_ARG(d->act != ESS_ACT_SUMPOOL2 && d->out_split == 0 && (d->fmt_res == ESS_FMT_F32_NCHW || d->fmt_res == ESS_FMT_BF16_C8),
                   "conv: an F16_C8 output takes no SUMPOOL2 / out_split; a residual comes as BF16_C8");
     dcopy = *d;
@@ -292,6 +292,13 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
 #endif
   a.out_f16 = out_f16 ? 1 : 0;
   a.split = rd.split ? 1 : 0;
+  a.f16 = rd.f16 ? 1 : 0;
+  a.hilo = rd.hilo ? 1 : 0;
+  if (rd.hilo && d->epilogue == ESS_EPI_LINEAR)
+    ESS_CHECK_ARG(!residual && (d->C_out % pl.cout_tile) == 0 && d->fmt_out == ESS_FMT_BF16_C8, "conv(f16): a [hi | lo] output takes no residual and whole channel tiles");
+  if (rd.hilo && d->epilogue == ESS_EPI_LSTM)
+    ESS_CHECK_ARG(out_bf16 && shift && d->fmt_out == ESS_FMT_F32_C8 && (!aux0 || d->fmt_res == ESS_FMT_F32_C8) && (d->hidden % (8 * (pl.cout_tile / 32))) == 0 && pl.cout_tile >= 64,
+                  "conv(f16, LSTM): a [hi | lo] copy of h' exists in the lean form only (channel-blocked cell states, whole hidden blocks per tile)");
   a.N = d->N; a.Hin = d->H_in; a.Win = d->W_in; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.mode1 = d->mode1;
   a.Cout = d->C_out; a.Hout = d->H_out; a.Wout = d->W_out; a.pad = d->pad;
   a.bwl = g.bwl; a.wxl = g.wxl; a.tiles_x = g.tiles_x; a.n_tiles = g.tiles_x * g.tiles_y; a.n_cout_tiles = pl.n_cout_tiles;

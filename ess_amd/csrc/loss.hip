@@ -369,8 +369,9 @@ extern "C" size_t ess_task_loss_workspace(int32_t K) { (void)K; return (size_t)T
 
 extern "C" int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
                              int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
-                             void* workspace, ess_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(logits && labels && loss && workspace && N > 0 && hw > 0, "task_loss: bad arguments");
+  ESS_CHECK_ARG(workspace_bytes >= ess_task_loss_workspace(K), "task_loss: workspace of %zu bytes, ess_task_loss_workspace(K) = %zu needed", workspace_bytes, ess_task_loss_workspace(K));
   ESS_CHECK_ARG(K > 0 && K <= KMAX, "task_loss: K=%d unsupported (max %d)", K, KMAX);
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * hw;
@@ -392,8 +393,9 @@ extern "C" int ess_task_loss(const float* logits, const int64_t* labels, float* 
 }
 
 extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int32_t N, int32_t K,
-                               int32_t hw, void* workspace, ess_stream_t stream) {
+                               int32_t hw, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(a && b && loss && workspace && N > 0 && hw > 0, "sym_js_loss: bad arguments");
+  ESS_CHECK_ARG(workspace_bytes >= (size_t)ESS_LOSS_WORKSPACE_BYTES, "sym_js_loss: workspace of %zu bytes, ESS_LOSS_WORKSPACE_BYTES = %zu needed", workspace_bytes, (size_t)ESS_LOSS_WORKSPACE_BYTES);
   ESS_CHECK_ARG(K > 0 && K <= KMAX, "sym_js_loss: K=%d unsupported (max %d)", K, KMAX);
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * hw;
@@ -409,8 +411,9 @@ extern "C" int ess_sym_js_loss(const float* a, const float* b, float* loss, floa
 }
 
 extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n, void* workspace,
-                           ess_stream_t stream) {
+                           size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(a && b && loss && workspace && n > 0, "l1_loss: bad arguments");
+  ESS_CHECK_ARG(workspace_bytes >= (size_t)ESS_LOSS_WORKSPACE_BYTES, "l1_loss: workspace of %zu bytes, ESS_LOSS_WORKSPACE_BYTES = %zu needed", workspace_bytes, (size_t)ESS_LOSS_WORKSPACE_BYTES);
   hipStream_t st = (hipStream_t)stream;
   unsigned grid;
   if ((n & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0) {
@@ -426,8 +429,9 @@ extern "C" int ess_l1_loss(const float* a, const float* b, float* loss, float* d
 }
 
 extern "C" int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* da, float loss_scale, int64_t n_vectors, int64_t n,
-                              void* workspace, ess_stream_t stream) {
+                              void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(a && b && loss && workspace && n_vectors > 0 && n > 0 && n <= 8 * n_vectors, "l1_loss_c8: bad arguments");
+  ESS_CHECK_ARG(workspace_bytes >= (size_t)ESS_LOSS_WORKSPACE_BYTES, "l1_loss_c8: workspace of %zu bytes, ESS_LOSS_WORKSPACE_BYTES = %zu needed", workspace_bytes, (size_t)ESS_LOSS_WORKSPACE_BYTES);
   ESS_CHECK_ARG(((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0, "l1_loss_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = wave_uniform_grid((size_t)n_vectors, LOSS_MAX_BLOCKS);

@@ -51,6 +51,17 @@ __device__ __forceinline__ u32x4n pack8n(const float (&f)[8]) {
   return __builtin_bit_cast(u32x4n, b);
 }
 
+__device__ __forceinline__ u32x4n pack8hn(const float (&f)[8]) {  // IEEE half, saturating at +-65504 (NaN kept)
+  typedef _Float16 f16x8n __attribute__((ext_vector_type(8)));
+  f16x8n b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float c = __builtin_amdgcn_fmed3f(f[j], -65504.f, 65504.f);
+    b[j] = (_Float16)(f[j] != f[j] ? f[j] : c);
+  }
+  return __builtin_bit_cast(u32x4n, b);
+}
+
 // block-wide sums of 8 floats (blockDim.x a multiple of 64, <= 1024); red: 16 x 8 floats of LDS.  Fixed order.
 __device__ __forceinline__ void block_sum8(float (&v)[8], float* red) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -170,16 +181,122 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_kernel(const u32x4n* __rest
   }
 }
 
+// ---- InstanceNorm forward of the "mixed" configuration (round 6; ESS_COMPUTE_F16 consumers): the fused kernel above with
+//   * a second output y16 = the result as an F16_C8 tensor (what the next convolution's half matrix cores read: 11 significant bits;
+//     y, the BF16_C8 form every other consumer keeps reading -- weight gradient, skip add, losses --, may be NULL);
+//   * a residual that may be an F16_C8 tensor (flag bit 9);
+//   * HILO: x is a [hi | lo] half pair, [N][2 CB][hw][8] (ESS_FMT_F16_C8_HILO): x = hi + lo, ~22 significant bits -- the first decoder
+//     layer's pre-norm tensor, whose channel means are 6-17 standard deviations (the event latents' means): rounding IT to half was the
+//     largest single term of the logit error once the operands were half (tools/hybrid_rounding_ablation.py).
+template <int THREADS, int MV, bool HILO>
+__global__ __launch_bounds__(THREADS) void in_fwd_c8_mix_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
+                                                                u32x4n* __restrict__ y, u32x4n* __restrict__ y16, float* __restrict__ stats,
+                                                                int CB, int C, int hw, float eps, int flags) {
+  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1;
+  __shared__ float red[16 * 8];
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  const size_t base = (size_t)g * hw;
+  const size_t xbase = HILO ? ((size_t)n * 2 * CB + cb) * hw : base, xlo = xbase + (size_t)CB * hw;
+  u32x4n xv[MV], xl[HILO ? MV : 1];
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    xv[k] = x[xbase + (i < hw ? i : hw - 1)];
+    if constexpr (HILO) xl[k] = x[xlo + (i < hw ? i : hw - 1)];
+  }
+  auto value = [&](int k, float (&f)[8]) {
+    if constexpr (HILO) {
+      float l[8];
+      unpack8h(opaque(xv[k]), f);
+      unpack8h(opaque(xl[k]), l);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += l[j];
+    } else {
+      unpack8x(opaque(xv[k]), f, xf16);
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    if (i < hw) {
+      float f[8];
+      value(k, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+  }
+  block_sum8(s, red);
+  float mean[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { mean[j] = s[j] / hw; q[j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < MV; ++k) {
+    const int i = threadIdx.x + k * THREADS;
+    if (i < hw) {
+      float f[8];
+      value(k, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = f[j] - mean[j]; q[j] += d * d; }
+    }
+  }
+  block_sum8(q, red);
+  float rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(q[j] / hw + eps);
+  if (threadIdx.x < 8 && cb * 8 + (int)threadIdx.x < C) {
+    float m = 0.f, r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j == (int)threadIdx.x) { m = mean[j]; r = rstd[j]; }
+    stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x)] = m;
+    stats[2 * ((size_t)n * C + cb * 8 + threadIdx.x) + 1] = r;
+  }
+  constexpr int RB = 5;
+#pragma unroll
+  for (int k0 = 0; k0 < MV; k0 += RB) {
+    u32x4n rv[RB];
+    if (res) {  // (uniform)
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int i = threadIdx.x + (k0 + u) * THREADS;
+        if (k0 + u < MV) rv[u] = res[base + (i < hw ? i : hw - 1)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int k = k0 + u, i = threadIdx.x + k * THREADS;
+      if (k < MV && i < hw) {
+        float f[8], rf[8];
+        value(k, f);
+        if (res) unpack8x(rv[u], rf, rf16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = (f[j] - mean[j]) * rstd[j];
+          if (relu) t = fmaxf(t, 0.f);
+          if (res) t += rf[j];
+          f[j] = cb * 8 + j < C ? t : 0.f;
+        }
+        if (y) y[base + i] = pack8n(f);
+        y16[base + i] = pack8hn(f);
+      }
+    }
+  }
+}
+
 // ---- InstanceNorm backward, fused (256 threads: x and dy of a 60x80 block stay in registers)
 template <int THREADS = 256, int MV = MAXV>
 __global__ __launch_bounds__(THREADS) void in_bwd_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
                                                             const float* __restrict__ stats, u32x4n* __restrict__ dx, int CB, int C,
-                                                            int hw, int relu) {
-  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+                                                            int hw, int relu, int xcb = 0) {
+  const int xf16 = (relu >> 8) & 1;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
   relu &= 0xff;
   __shared__ float red[16 * 8];
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   const size_t base = (size_t)g * hw;
+  // xcb > 0: x keeps xcb blocks per sample of which the first CB are read (the hi parts of a [hi | lo] pre-norm tensor)
+  const size_t xbase = xcb > 0 ? ((size_t)n * xcb + cb) * hw : base;
   float mean[8], rstd[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -194,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void in_bwd_c8_kernel(const u32x4n* __rest
 #pragma unroll
   for (int k = 0; k < MV; ++k) {  // (unconditional loads from clamped addresses: see in_fwd_c8_kernel)
     const int i = threadIdx.x + k * THREADS;
-    xv[k] = x[base + (i < hw ? i : hw - 1)];
+    xv[k] = x[xbase + (i < hw ? i : hw - 1)];
     gv[k] = dy[base + (i < hw ? i : hw - 1)];
   }
 #pragma unroll
@@ -400,6 +517,59 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
         f[j] = cb * 8 + j < C ? t : 0.f;
       }
       y[base + ii] = pack8n(f);
+    }
+  }
+}
+
+// the split path's forward map with the second (F16_C8) output and an optionally half residual (see in_fwd_c8_mix_kernel; no [hi | lo] x here)
+__global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
+                                                              u32x4n* __restrict__ y, u32x4n* __restrict__ y16, float* __restrict__ stats,
+                                                              const double* sums, int nsl, int CB, int C, int hw, float eps, int flags) {
+  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1;
+  const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
+  double t0[8], t1[8];
+  group_total8(sums, g, nsl, t0, t1);
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double m = t0[j] / hw;
+    double var = t1[j] / hw - m * m;
+    if (var < 0) var = 0;
+    mean[j] = (float)m;
+    rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) { stats[2 * ((size_t)n * C + cb * 8 + j)] = mean[j]; stats[2 * ((size_t)n * C + cb * 8 + j) + 1] = rstd[j]; }
+  }
+  const size_t base = (size_t)g * hw;
+  constexpr int U = 4;
+  const int stride = gridDim.y * 256;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
+    u32x4n xv[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
+      xv[u] = x[base + ic];
+      if (res) rv[u] = res[base + ic];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ii = i + u * stride;
+      if (ii >= hw) continue;
+      float f[8], rf[8];
+      unpack8x(xv[u], f, xf16);
+      if (res) unpack8x(rv[u], rf, rf16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (f[j] - mean[j]) * rstd[j];
+        if (relu) t = fmaxf(t, 0.f);
+        if (res) t += rf[j];
+        f[j] = cb * 8 + j < C ? t : 0.f;
+      }
+      if (y) y[base + ii] = pack8n(f);
+      y16[base + ii] = pack8hn(f);
     }
   }
 }
@@ -659,20 +829,55 @@ extern "C" int ess_instnorm_forward_c8(const void* x, const void* residual, void
   return ess_launch_status("instnorm_forward_c8(split)");
 }
 
+extern "C" int ess_instnorm_forward_c8_mixed(const void* x, const void* residual, void* y, void* y16, float* stats, int32_t N, int32_t C,
+                                             int32_t hw, float eps, int32_t relu, int32_t x_fmt, int32_t res_f16, void* workspace,
+                                             size_t workspace_bytes, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y16 && stats && N > 0 && C > 0 && hw > 0, "instnorm_forward_c8_mixed: bad arguments");
+  ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_forward_c8_mixed: relu must be 0 or 1");
+  ESS_CHECK_ARG(x_fmt >= 0 && x_fmt <= 2, "instnorm_forward_c8_mixed: x_fmt is 0 (BF16_C8), 1 (F16_C8) or 2 (F16_C8 [hi | lo])");
+  ESS_CHECK_ARG(al16(x, residual, y, y16), "instnorm_forward_c8_mixed: C8 tensors must be 16-byte aligned");
+  ESS_CHECK_ARG(x_fmt != 2 || hw <= 256 * MAXV, "instnorm_forward_c8_mixed: a [hi | lo] input exists for planes of at most %d pixels", 256 * MAXV);
+  hipStream_t st = (hipStream_t)stream;
+  const int flags = (relu & 1) | (x_fmt ? 0x100 : 0) | (res_f16 ? 0x200 : 0);
+  const int CB = (C + 7) / 8, groups = N * CB;
+  const u32x4n* xs = (const u32x4n*)x; const u32x4n* rs = (const u32x4n*)residual; u32x4n* ys = (u32x4n*)y; u32x4n* hs = (u32x4n*)y16;
+  if (hw <= 256 * MAXV) {
+    if (x_fmt == 2) {
+      if (hw <= 512 * 10) hipLaunchKernelGGL((in_fwd_c8_mix_kernel<512, 10, true>), dim3(groups), dim3(512), 0, st, xs, rs, ys, hs, stats, CB, C, hw, eps, flags);
+      else hipLaunchKernelGGL((in_fwd_c8_mix_kernel<256, MAXV, true>), dim3(groups), dim3(256), 0, st, xs, rs, ys, hs, stats, CB, C, hw, eps, flags);
+    } else {
+      if (hw <= 512 * 10) hipLaunchKernelGGL((in_fwd_c8_mix_kernel<512, 10, false>), dim3(groups), dim3(512), 0, st, xs, rs, ys, hs, stats, CB, C, hw, eps, flags);
+      else hipLaunchKernelGGL((in_fwd_c8_mix_kernel<256, MAXV, false>), dim3(groups), dim3(256), 0, st, xs, rs, ys, hs, stats, CB, C, hw, eps, flags);
+    }
+    return ess_launch_status("instnorm_forward_c8_mixed");
+  }
+  int rc = need_ws(workspace, ess_norm_workspace_c8(groups), workspace_bytes, "instnorm_forward_c8_mixed");
+  if (rc) return rc;
+  const int nsl = split_for8(groups, hw);
+  hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, nullptr, nullptr, (double*)workspace, hw, 1,
+                     0, CB, C, 1, flags & 0x100, 0);
+  hipLaunchKernelGGL(in_apply_c8_mix_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, rs, ys, hs, stats,
+                     (const double*)workspace, nsl, CB, C, hw, eps, flags);
+  return ess_launch_status("instnorm_forward_c8_mixed(split)");
+}
+
 extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C,
                                         int32_t hw, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream) {
   ESS_CHECK_ARG(x && dy && stats && dx && N > 0 && C > 0 && hw > 0, "instnorm_backward_c8: bad arguments");
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_backward_c8: relu must be 0 or 1");
   ESS_CHECK_ARG(al16(x, dy, dx), "instnorm_backward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  // x_f16 = 2: x is a [hi | lo] half pair ([N][2 CB][hw][8], the mixed configuration's first decoder layer): the hi parts are read
+  ESS_CHECK_ARG(x_f16 >= 0 && x_f16 <= 2 && (x_f16 != 2 || hw <= 256 * MAXV), "instnorm_backward_c8: x_f16 is 0, 1 or (planes of at most %d pixels) 2", 256 * MAXV);
+  const int xcb = x_f16 == 2 ? 2 * ((C + 7) / 8) : 0;
   relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* gs = (const u32x4n*)dy; u32x4n* ds = (u32x4n*)dx;
   if (hw <= 256 * MAXV) {
     const int th = in_small_threads();
-    if (th == 1024 && hw <= 1024 * 5) hipLaunchKernelGGL((in_bwd_c8_kernel<1024, 5>), dim3(groups), dim3(1024), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
-    else if (th == 512 && hw <= 512 * 10) hipLaunchKernelGGL((in_bwd_c8_kernel<512, 10>), dim3(groups), dim3(512), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
-    else hipLaunchKernelGGL((in_bwd_c8_kernel<256, MAXV>), dim3(groups), dim3(256), 0, st, xs, gs, stats, ds, CB, C, hw, relu);
+    if (th == 1024 && hw <= 1024 * 5) hipLaunchKernelGGL((in_bwd_c8_kernel<1024, 5>), dim3(groups), dim3(1024), 0, st, xs, gs, stats, ds, CB, C, hw, relu, xcb);
+    else if (th == 512 && hw <= 512 * 10) hipLaunchKernelGGL((in_bwd_c8_kernel<512, 10>), dim3(groups), dim3(512), 0, st, xs, gs, stats, ds, CB, C, hw, relu, xcb);
+    else hipLaunchKernelGGL((in_bwd_c8_kernel<256, MAXV>), dim3(groups), dim3(256), 0, st, xs, gs, stats, ds, CB, C, hw, relu, xcb);
     return ess_launch_status("instnorm_backward_c8");
   }
   int rc = need_ws(workspace, ess_norm_workspace_c8(groups), workspace_bytes, "instnorm_backward_c8");

@@ -601,3 +601,99 @@ extern "C" int ess_from_bf16_c8(const void* x, float* y, int N, int C, int H, in
   hipLaunchKernelGGL(from_bf16_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, y, C, hw, total);
   return ess_launch_status("from_bf16_c8");
 }
+
+// ---- the "mixed" configuration's format bridges (round 6; ESS_COMPUTE_F16 consumers read F16_C8 tensors) ----
+namespace {
+__device__ __forceinline__ _Float16 half_sat(float v) {  // (saturating at +-65504, NaN kept: conv_common.h ess_f16_sat)
+  const float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  return (_Float16)(v != v ? v : c);
+}
+// fp32 NCHW -> F16_C8, or (hilo) the [hi | lo] pair [N][2 nblk][hw][8]: hi = half(v), lo = half(v - hi)
+__global__ __launch_bounds__(256) void to_f16_c8_kernel(const float* __restrict__ x, uint4* __restrict__ y, int C, int64_t hw,
+                                                        int64_t total, int hilo) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  const int nblk = (C + 7) >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % hw, nb = i / hw;
+    const int blk = (int)(nb % nblk);
+    const int64_t n = nb / nblk;
+    const float* p = x + ((size_t)n * C + (size_t)blk * 8) * hw + pix;
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = blk * 8 + j < C ? p[(size_t)j * hw] : 0.f;
+      h[j] = half_sat(v);
+      l[j] = (_Float16)(v - (float)h[j]);
+    }
+    if (hilo) {
+      y[((size_t)n * 2 * nblk + blk) * hw + pix] = __builtin_bit_cast(uint4, h);
+      y[((size_t)n * 2 * nblk + nblk + blk) * hw + pix] = __builtin_bit_cast(uint4, l);
+    } else {
+      y[i] = __builtin_bit_cast(uint4, h);
+    }
+  }
+}
+// BF16_C8 -> F16_C8 (bfloat16's 8 significant bits fit a half; |v| > 65504 saturates, |v| < 6e-8 flushes)
+__global__ __launch_bounds__(256) void bf16_to_f16_c8_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int64_t total) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8 b = __builtin_bit_cast(bf16x8, x[i]);
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = half_sat((float)b[j]);
+    y[i] = __builtin_bit_cast(uint4, h);
+  }
+}
+// F16_C8 (src_blocks = nblk) or a [hi | lo] pair (src_blocks = 2 nblk: hi + lo) -> BF16_C8 (round to nearest even)
+__global__ __launch_bounds__(256) void f16_to_bf16_c8_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int nblk, int src_blocks,
+                                                             int64_t hw, int64_t total) {
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i % hw, nb = i / hw;
+    const int blk = (int)(nb % nblk);
+    const int64_t n = nb / nblk;
+    const f16x8 h = __builtin_bit_cast(f16x8, x[((size_t)n * src_blocks + blk) * hw + pix]);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    if (src_blocks == 2 * nblk) {
+      const f16x8 l = __builtin_bit_cast(f16x8, x[((size_t)n * src_blocks + nblk + blk) * hw + pix]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+    }
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+    y[i] = __builtin_bit_cast(uint4, b);
+  }
+}
+inline unsigned bridge_grid(int64_t total) {
+  int64_t blocks = ceil_div64(total, 256);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  return (unsigned)blocks;
+}
+}  // namespace
+
+extern "C" int ess_to_f16_c8(const float* x, void* y, int N, int C, int H, int W, int32_t hilo, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "to_f16_c8: bad arguments");
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * ((C + 7) / 8) * hw;
+  hipLaunchKernelGGL(to_f16_c8_kernel, dim3(bridge_grid(total)), dim3(256), 0, (hipStream_t)stream, x, (uint4*)y, C, hw, total, hilo ? 1 : 0);
+  return ess_launch_status("to_f16_c8");
+}
+
+extern "C" int ess_bf16_c8_to_f16_c8(const void* x, void* y, int64_t n_vec, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && n_vec > 0, "bf16_c8_to_f16_c8: bad arguments");
+  hipLaunchKernelGGL(bf16_to_f16_c8_kernel, dim3(bridge_grid(n_vec)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, n_vec);
+  return ess_launch_status("bf16_c8_to_f16_c8");
+}
+
+extern "C" int ess_f16_c8_to_bf16_c8(const void* x, void* y, int N, int C, int H, int W, int32_t hilo, ess_stream_t stream) {
+  ESS_CHECK_ARG(x && y && N > 0 && C > 0 && H > 0 && W > 0, "f16_c8_to_bf16_c8: bad arguments");
+  const int nblk = (C + 7) / 8;
+  const int64_t hw = (int64_t)H * W, total = (int64_t)N * nblk * hw;
+  hipLaunchKernelGGL(f16_to_bf16_c8_kernel, dim3(bridge_grid(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (uint4*)y, nblk,
+                     hilo ? 2 * nblk : nblk, hw, total);
+  return ess_launch_status("f16_c8_to_bf16_c8");
+}

@@ -216,6 +216,127 @@ class ConvLayer(nn.Module):
         return out
 
 
+# ---- 'mixed' configuration (hip.set_compute('mixed'), round 6): the recurrent part of the frozen encoder -- head, the stride-2
+# convolutions, the ConvLSTM gates -- on IEEE-half operands (ESS_COMPUTE_F16).  Activations travel as F16_C8 copies (`.ess_h16` =
+# (tensor, version, hilo)); the convolution in front of a recurrent block writes a [hi | lo] half pair (its post-ReLU values carry
+# means far above their spread: rounding THEM to 11 bits was the largest term of the encoder's error, tools/hybrid_rounding_ablation.py),
+# and so does the last time step's ConvLSTM for h' -- the event latents.  A [hi | lo] source enters a convolution as 2 C channels
+# against a weight whose input columns are repeated.
+_dupw_cache = {}
+
+
+def _dup_weight(key, base, cols):
+    """torch.cat([base[:, a:b] for (a, b) in cols], dim=1) of a frozen weight, cached by (key, the weight's identity and version)"""
+    ver = (id(base), base._version, base.data_ptr(), tuple(cols))
+    ent = _dupw_cache.get(key)
+    if ent is None or ent[0] != ver:
+        if len(_dupw_cache) >= 64:
+            _dupw_cache.clear()
+        with torch.no_grad():
+            ent = _dupw_cache[key] = (ver, torch.cat([base.detach()[:, a:b] for (a, b) in cols], dim=1).contiguous())
+    return ent[1]
+
+
+def _half_source(t):
+    """(F16_C8 tensor, hilo) of an activation inside the mixed encoder: the producer's copy, else its fp32 values converted"""
+    h = hip.h16_of(t)
+    if h is not None:
+        return h
+    return hip.to_f16_c8(_fp32(t).contiguous()), False
+
+
+def _convlayer_forward_mixed(self, x, hilo_out=False, want_fp32=False):
+    """ConvLayer on half operands.  x: the fp32 NCHW voxel grid (the 5x5 head: rounded to half inside the kernel) or an activation
+    carrying a half copy.  -> fp32 tensor (a placeholder unless want_fp32) carrying the output's half copy ([hi | lo] with hilo_out)."""
+    _inference_only(x)
+    _check_eval(self, self.norm)
+    c = self.conv2d
+    k, s, p = c.kernel_size[0], c.stride[0], c.padding[0]
+    act = _ACT[self.activation]
+    N, C0, H, W = x.shape
+    is_head = hip.h16_of(x) is None and k == 5 and s == 1 and C0 <= 5 and not getattr(x, 'ess_fp32_unwritten', False)
+    if is_head:
+        spec = hip.conv_spec(N, H, W, C0, 0, c.out_channels, k, s, p, act=act, compute=hip.COMPUTE_F16)
+        scale, shift = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
+        h16 = hip.f16_blocks_empty(N, c.out_channels, spec.H_out, spec.W_out, x.device)
+        if want_fp32:
+            out = torch.empty(N, c.out_channels, spec.H_out, spec.W_out, dtype=torch.float32, device=x.device)
+            hip.conv_forward_h16(spec, x.contiguous(), None, packed_weight(spec, c.weight), scale, shift, out=out, out_h16=h16, src_fp32=True)
+        else:
+            hip.conv_forward_h16(spec, x.contiguous(), None, packed_weight(spec, c.weight), scale, shift, out=h16, out_fmt=hip.FMT_F16_C8,
+                                 src_fp32=True)
+            out = _c8_placeholder(N, c.out_channels, spec.H_out, spec.W_out, x.device, None)
+            del out.ess_c8
+        return hip.attach_h16(out, h16, False)
+    if want_fp32:
+        raise hip.EssHipError('ConvLayer(mixed): fp32 outputs exist for the head only')
+    s16, hl = _half_source(x)
+    Ce = C0 * (2 if hl else 1)
+    w = _dup_weight((id(self), 'dup'), c.weight, [(0, C0), (0, C0)]) if hl else c.weight
+    out_fmt = hip.FMT_F16_C8_HILO if hilo_out else hip.FMT_F16_C8
+    h16 = hip.f16_blocks_empty(N, c.out_channels, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, x.device, hilo=hilo_out)
+    s2 = None
+    if (k, s, p) == (5, 2, 2) and Ce % 32 == 0 and c.out_channels % 64 == 0 and not (H % 2 or W % 2) and os.environ.get('ESS_CONV5_S2D', '1')[:1] != '0':
+        s2 = hip.conv_spec(N, H // 2, W // 2, 4 * Ce, 0, c.out_channels, 3, 1, 1, mode0=hip.SRC_S2D, act=act, compute=hip.COMPUTE_F16)
+        if not hip.s2d_preferred(s2):
+            s2 = None
+    if s2 is not None:
+        sc, sh = self._fold.get(s2, c.bias, self.norm, getattr(self, 'norm_layer', None))
+        hip.conv_forward_h16(s2, s16, None, packed_weight(s2, w, kind=hip.W_CONV5_S2D), sc, sh, out=h16, out_fmt=out_fmt)
+    else:
+        spec = hip.conv_spec(N, H, W, Ce, 0, c.out_channels, k, s, p, act=act, compute=hip.COMPUTE_F16)
+        sc, sh = self._fold.get(spec, c.bias, self.norm, getattr(self, 'norm_layer', None))
+        hip.conv_forward_h16(spec, s16, None, packed_weight(spec, w), sc, sh, out=h16, out_fmt=out_fmt)
+    out = _c8_placeholder(N, c.out_channels, h16.shape[2], h16.shape[3], x.device, None)
+    del out.ess_c8
+    return hip.attach_h16(out, h16, hilo_out)
+
+
+def _convlstm_forward_mixed(self, input_, prev_state, lean, hilo_out):
+    """ConvLSTM step on half operands: x (a [hi | lo] pair from the encoder convolution) and h_prev from their half copies; fp32 cell
+    state as in the bf16 configuration.  lean: no fp32 hidden tensor (placeholder + half copy + channel-blocked cell); hilo_out (lean
+    only): the half copy of h' as a [hi | lo] pair -- the latents of the sequence's last step."""
+    _inference_only(input_)
+    N, C, H, W = input_.shape
+    hid = self.hidden_size
+    xs, xhl = _half_source(input_)
+    Cx = C * (2 if xhl else 1)
+    W_ = self.Gates.weight
+    if prev_state is None:
+        hs, hhl, C1, prev_cell = None, False, 0, None
+        cols = [(0, C)] * (2 if xhl else 1)
+    else:
+        prev_hidden, prev_cell = prev_state
+        hs, hhl = _half_source(prev_hidden)
+        C1 = hid * (2 if hhl else 1)
+        cols = [(0, C)] * (2 if xhl else 1) + [(C, C + hid)] * (2 if hhl else 1)
+    w = W_ if cols == [(0, C), (C, C + hid)] else _dup_weight((id(self), xhl, hhl, prev_state is None), W_, cols)
+    hilo = bool(hilo_out and lean)
+    spec = hip.conv_spec(N, H, W, Cx, C1, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, act=hip.LSTM_H_HILO if hilo else 0,
+                         compute=hip.COMPUTE_F16)
+    if hilo and (hid % (8 * (spec.plan.cout_tile // 32)) or spec.plan.cout_tile < 64):
+        hilo = False
+        spec = hip.conv_spec(N, H, W, Cx, C1, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, compute=hip.COMPUTE_F16)
+    b = self.Gates.bias
+    bkey = ('mixed', spec.plan.rows_padded, b._version, b.data_ptr())
+    if getattr(self, '_bias_mixed_ver', None) != bkey:
+        self._bias_mixed_ver, self._bias_mixed = bkey, hip.pack_rows(spec, b.detach())
+    new16 = hip.f16_blocks_empty(N, hid, H, W, input_.device, hilo=hilo)
+    cell, sfmt = _new_cell(N, hid, H, W, input_.device, lean)
+    cfmt = hip.FMT_F32_C8 if prev_cell is not None and prev_cell.dim() == 5 else hip.FMT_F32_NCHW
+    if lean and sfmt == hip.FMT_F32_C8:
+        hidden = _c8_placeholder(N, hid, H, W, input_.device, None)
+        del hidden.ess_c8
+        hip.conv_forward_h16(spec, xs, hs, packed_weight(spec, w), None, self._bias_mixed, aux0=prev_cell, out=None, out2=cell, out_h16=new16,
+                             out_fmt=sfmt, aux_fmt=cfmt)
+    else:
+        hidden = torch.empty(N, hid, H, W, dtype=torch.float32, device=input_.device)
+        hip.conv_forward_h16(spec, xs, hs, packed_weight(spec, w), None, self._bias_mixed, aux0=prev_cell, out=hidden, out2=cell, out_h16=new16,
+                             out_fmt=sfmt, aux_fmt=cfmt)
+    hip.attach_h16(hidden, new16, hilo)
+    return hidden, cell
+
+
 class TransposedConvLayer(nn.Module):
     """ConvTranspose2d(k, stride 2, output_padding 1) (+norm) (+activation): the zero-insertion is done
     while staging the LDS tile.  Reference: submodules.py:34-62."""
@@ -425,6 +546,7 @@ def _convlstm_first_step(self, input_, hidden, cell, lean):
 
 
 ConvLSTM._first_step = _convlstm_first_step
+ConvLSTM.forward_mixed = _convlstm_forward_mixed
 
 
 class ConvGRU(nn.Module):
@@ -578,6 +700,19 @@ def _rcl_prev_has_c8(self, prev_state):
 RecurrentConvLayer._prev_has_c8 = _rcl_prev_has_c8
 
 
+def _rcl_forward_mixed(self, x, prev_state, lean=False, hilo_out=False):
+    """the mixed configuration's step (see _convlayer_forward_mixed): conv -> [hi | lo] half pair -> ConvLSTM on half operands"""
+    if self.recurrent_block_type != 'convlstm':
+        raise NotImplementedError("the 'mixed' configuration covers the ConvLSTM encoder (the recurrent block of the E2VID checkpoint's default); "
+                                  "ConvGRU runs in 'bf16' / 'bf16x3' / 'fp32'")
+    xc = self.conv.forward_mixed(x, hilo_out=True)
+    state = self.recurrent_block.forward_mixed(xc, prev_state, lean, hilo_out)
+    return state[0], state
+
+
+RecurrentConvLayer.forward_mixed = _rcl_forward_mixed
+
+
 class ResidualBlock(nn.Module):
     """conv3x3 -norm-ReLU- conv3x3 -norm- (+x) -ReLU as two fused kernels (BN/no norm), or with the
     InstanceNorm plane kernel in between (norm='IN').  Reference: submodules.py:140-172."""
@@ -641,3 +776,6 @@ class ResidualBlock(nn.Module):
         if not fused:
             out, _ = hip.instnorm_forward(out, x, 2, EPS)
         return out
+
+
+ConvLayer.forward_mixed = _convlayer_forward_mixed

@@ -136,7 +136,7 @@ class UNetRecurrent(BaseUNet):
         the lean BF16_C8 path is not available (exact-fp32 arithmetic, diagnostic switches).  forward(..., prefix=(head_t, conv_t))
         then starts at the first recurrent block.  Two launches for S slices instead of 2 S."""
         from .submodules import _c8_of
-        ok = hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2) and \
+        ok = hip.get_compute() == 'bf16' and not hip.mixed() and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2) and \
             self.encoder_output_sizes[0] % 8 == 0 and self.base_num_channels % 8 == 0
         if not ok:
             return None
@@ -155,6 +155,10 @@ class UNetRecurrent(BaseUNet):
         losses), so the outputs are bit-identical; a caller that wants fp32 hidden states keeps lean_state off."""
         if lean and not encoder_only:
             raise ValueError('lean needs encoder_only')
+        if hip.mixed():
+            if prefix is not None:
+                raise ValueError("the time-batched prefix does not exist in the 'mixed' configuration")
+            return self._forward_mixed(x, prev_states, encoder_only, lean, lean_state)
         # every consumer of the unwritten fp32 tensors must be able to stage their BF16_C8 copies (diagnostic switches may forbid it)
         c8_ok = hip.get_compute() == 'bf16' and hip.c8_stageable(3, 1, 1) and hip.c8_stageable(5, 2, 2)
         lean = lean and c8_ok
@@ -192,6 +196,41 @@ class UNetRecurrent(BaseUNet):
         if encoder_only:
             return None, states, latent
         return self._tail(x, blocks, head), states, latent
+
+
+def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean_state):
+    """One time step of the 'mixed' configuration (hip.set_compute('mixed')): head, stride-2 convolutions and ConvLSTM gates on IEEE-half
+    operands (submodules._convlayer_forward_mixed / _convlstm_forward_mixed), the tail that only feeds the reconstruction (residual
+    blocks, upsample-conv decoders, prediction layer: reference unet.py:165-181) on the bf16 kernels from BF16_C8 copies of the hidden
+    states.  lean: the step only advances the state; lean_state: its hidden states need no fp32 form (then the last step's copies of h'
+    -- the event latents -- leave as [hi | lo] half pairs)."""
+    from .submodules import _c8_of, _attach_c8
+    final = not lean
+    no_fp32 = lean or (lean_state and self.use_upsample_conv and self.norm != 'IN')
+    head = self.head.forward_mixed(x, want_fp32=final)
+    if prev_states is None:
+        prev_states = [None] * self.num_encoders
+    blocks, states = [], []
+    x = head
+    for i, encoder in enumerate(self.encoders):
+        x, state = encoder.forward_mixed(x, prev_states[i], lean=no_fp32, hilo_out=final)
+        blocks.append(x)
+        states.append(state)
+    if lean:
+        return None, states, None
+    latent = {1: head}
+    for i, b in enumerate(blocks):
+        latent[2 ** (i + 1)] = b
+    if encoder_only:
+        return None, states, latent
+    for b in blocks:  # the tail stages BF16_C8 copies
+        h = hip.h16_of(b)
+        if h is not None and _c8_of(b) is None:
+            _attach_c8(b, hip.f16_c8_to_bf16_c8(h[0], hilo=h[1]))
+    return self._tail(x, blocks, head), states, latent
+
+
+UNetRecurrent._forward_mixed = _unet_recurrent_forward_mixed
 
 
 class UNetDecoder(BaseUNet):

@@ -114,6 +114,8 @@ def invalidate_packed(params):
     for p in params:
         _pack_cache.pop(id(p), None)
         _first_cache.pop(id(p), None)
+        for key in [k for k in _dup_cache if k[0] == id(p)]:
+            _dup_cache.pop(key, None)
 
 
 _first_cache = {}
@@ -139,6 +141,8 @@ def repack(params):
     jobs = []
     for p in params:
         _first_cache.pop(id(p), None)  # derived copies: rebuilt on next use
+        for dk in [k for k in _dup_cache if k[0] == id(p)]:
+            _dup_cache.pop(dk, None)
         ent = _pack_cache.get(id(p))
         if ent is None or ent[0]() is not p:
             continue
@@ -150,7 +154,7 @@ def repack(params):
                 # bias rows of a plain bf16 convolution ride in the same launch (round 5: 21 pack_rows launches per step otherwise);
                 # any other row layout is dropped and re-packed lazily
                 sp = getattr(ent[2][key], 'ess_spec', None)
-                if sp is not None and p.dim() == 1 and sp.key[11] == hip.EPI_LINEAR and sp.key[15] == hip.COMPUTE_BF16 and \
+                if sp is not None and p.dim() == 1 and sp.key[11] == hip.EPI_LINEAR and sp.key[15] in (hip.COMPUTE_BF16, hip.COMPUTE_F16) and \
                         os.environ.get('ESS_REPACK_ROWS', '1')[:1] != '0':
                     jobs.append((sp, hip.W_ROWS, p.detach(), ent[2][key]))
                 else:
@@ -158,7 +162,7 @@ def repack(params):
                 continue
             skey, kind = key
             k, epi, compute = skey[8], skey[11], skey[15]
-            if compute == hip.COMPUTE_BF16 and epi == hip.EPI_LINEAR and k != 5 and p.dim() == 4:
+            if compute in (hip.COMPUTE_BF16, hip.COMPUTE_F16) and epi == hip.EPI_LINEAR and k != 5 and p.dim() == 4:
                 jobs.append((hip.spec_of(skey), kind, p.detach(), ent[2][key]))
             else:
                 del ent[2][key]
@@ -186,6 +190,51 @@ def _fmt(x):
 
 
 PRE_NORM = 'f16'  # out_c8 value of a convolution whose output goes straight into an InstanceNorm / train-mode BatchNorm
+PRE_NORM_HILO = 'f16hilo'  # (mixed configuration) ... as a [hi | lo] half pair: the first decoder layer, whose channel means are 6-17 sigma
+
+
+def mixed():
+    """'mixed' configuration (hip.set_compute('mixed')): BF16_C8 storage and bf16 backward like the bf16 configuration, every forward
+    contraction of the decoder on IEEE-half operands read from the half copies the norm kernels leave next to their BF16_C8 outputs."""
+    return hip.mixed()
+
+
+def half_of(x):
+    """(F16_C8 tensor, hilo) holding the values of the BF16_C8 activation `x` for a half-operand convolution: the copy its producer
+    left (`.ess_h16`: 11 or, [hi | lo], ~22 significant bits), else the BF16_C8 values themselves converted (exact)."""
+    c = hip.h16_of(x)
+    if c is not None:
+        return c
+    return hip.bf16_c8_to_f16_c8(x.detach().contiguous()), False
+
+
+_dup_cache = {}
+
+
+def _dup_columns(weight, c0, dup0, c1, dup1):
+    """weight [Cout, c0 + c1, k, k] with the input columns of a [hi | lo] source repeated: [w0 | w0 | w1 | w1] as needed -- w (hi + lo)
+    on the matrix cores is the plain convolution over the 2 C-channel source against this weight.  Cached like the packed layouts."""
+    if not (dup0 or dup1):
+        return weight
+    key = (id(weight), c0, dup0, c1, dup1)
+    ver = (weight._version, weight.data_ptr())
+    ent = _dup_cache.get(key)
+    if ent is None or ent[0]() is not weight or ent[1] != ver:
+        with torch.no_grad():
+            w = weight.detach()
+            parts = [w[:, :c0]] * (2 if dup0 else 1) + ([w[:, c0:]] * (2 if dup1 else 1) if c1 else [])
+            d = torch.cat(parts, dim=1).contiguous()
+        ent = (weakref.ref(weight, lambda _, k=key: _dup_cache.pop(k, None)), ver, d)
+        _dup_cache[key] = ent
+    return ent[2]
+
+
+def _hilo_placeholder(N, C, H, W, device, buf):
+    """The autograd-visible tensor of a [hi | lo] pre-norm output: shape and dtype of the BF16_C8 tensor its gradient has, no memory
+    behind it (stride 0); the half pair travels as `.ess_hilo` -- only the norm kernels read it."""
+    t = torch.empty((), dtype=torch.bfloat16, device=device).expand(N, C // 8, H, W, 8)
+    t.ess_hilo = buf
+    return t
 
 
 def _empty_act(N, C, H, W, device, c8):
@@ -240,6 +289,21 @@ def as_c8(x):
         return x
     if x.shape[1] % 8:
         raise hip.EssHipError(f'as_c8: {x.shape[1]} channels are not a whole number of 8-channel blocks')
+    if hip.mixed() and not x.requires_grad:
+        # mixed configuration, an event latent (fp32 NCHW, possibly an unwritten placeholder carrying only its half copy): the
+        # BF16_C8 tensor the backward / skip / loss consumers read, with the [hi | lo] half pair the forward convolutions read
+        cached = getattr(x, 'ess_mixed_c8', None)
+        if cached is not None and cached[1] == x._version:
+            return cached[0]
+        h = hip.h16_of(x)
+        if h is None:
+            if getattr(x, 'ess_fp32_unwritten', False):
+                raise hip.EssHipError('as_c8(mixed): the tensor has neither fp32 values nor a half copy')
+            h = (hip.to_f16_c8(x.contiguous(), hilo=True), True)
+        c8t = hip.f16_c8_to_bf16_c8(h[0], hilo=h[1])
+        hip.attach_h16(c8t, h[0], h[1])
+        x.ess_mixed_c8 = (c8t, x._version)
+        return c8t
     c8 = getattr(x, 'ess_c8', None)
     if c8 is not None and c8[1] == x._version and not x.requires_grad:
         return c8[0]
@@ -258,6 +322,9 @@ def detach_keep_c8(x):
         d.ess_c8 = (c8[0], d._version)
     if getattr(x, 'ess_fp32_unwritten', False):
         d.ess_fp32_unwritten = True
+    h = getattr(x, 'ess_h16', None)
+    if h is not None and h[1] == x._version:
+        d.ess_h16 = (h[0], d._version, h[2])
     return d
 
 
@@ -271,7 +338,12 @@ class ForkFn(torch.autograd.Function):
         # unused aliases (e.g. the image task backward consumes pred[1] only) must arrive as None in backward, not as
         # materialised zero tensors: a zero fill plus an add pass per unused fork otherwise
         ctx.set_materialize_grads(False)
-        return tuple(x.detach() for _ in range(n))
+        outs = tuple(x.detach() for _ in range(n))
+        h = hip.h16_of(x)
+        if h is not None:  # (mixed configuration: the aliases keep the producer's half copy)
+            for o in outs:
+                hip.attach_h16(o, h[0], h[1])
+        return outs
 
     @staticmethod
     def backward(ctx, *gs):
@@ -304,7 +376,7 @@ class Conv2dFn(torch.autograd.Function):
     transposed weights) + weight gradient kernel, each only when needed."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1, passthrough=False, out_c8=None):
+    def forward(ctx, x0, x1, weight, bias, stride, pad, mode0, mode1, passthrough=False, out_c8=None, half=False):
         """passthrough=True additionally returns x0 itself as a second output.  A residual block uses THAT as its
         skip operand (y = f(conv(x)) + x_passthrough), so the gradient of the skip branch arrives in this function's
         backward next to the conv's own and is added inside the data-gradient kernel's epilogue (`residual`), instead
@@ -324,10 +396,34 @@ class Conv2dFn(torch.autograd.Function):
         if weight.shape[1] != C0 + C1:
             raise hip.EssHipError(f'Conv2dFn: weight expects {weight.shape[1]} input channels, got {C0}+{C1}')
         spec = hip.conv_spec(N, Hv, Wv, C0, C1, Cout, k, stride, pad, mode0, mode1)
-        out = _empty_act(N, Cout, spec.H_out, spec.W_out, x0.device, out_c8)
         shift = packed_rows(spec, bias) if bias is not None else None
-        hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out, src_fmt=_fmt(x0),
-                         out_fmt=hip.FMT_F16_C8 if out_c8 == PRE_NORM else _fmt(out))
+        if half and c8in and hip.mixed():
+            # mixed configuration (decoder convolutions): the FORWARD contraction on IEEE-half operands -- the sources' half copies
+            # (the norm kernels / the frozen encoder leave them; a [hi | lo] pair enters as 2 C channels against repeated weight
+            # columns), half weights; `spec`, the saved BF16_C8 tensors and the whole backward stay those of the bf16 configuration
+            h0, hl0 = half_of(x0)
+            h1, hl1 = half_of(x1) if x1 is not None else (None, False)
+            fspec = hip.conv_spec(N, Hv, Wv, C0 * (2 if hl0 else 1), C1 * (2 if hl1 else 1), Cout, k, stride, pad, mode0, mode1,
+                                  compute=hip.COMPUTE_F16)
+            pw = packed_weight(fspec, _dup_columns(weight, C0, hl0, C1, hl1))
+            if out_c8 == PRE_NORM_HILO:
+                buf = hip.f16_blocks_empty(N, Cout, spec.H_out, spec.W_out, x0.device, hilo=True)
+                hip.conv_forward_h16(fspec, h0, h1, pw, None, shift, out=buf, out_fmt=hip.FMT_F16_C8_HILO)
+                out = _hilo_placeholder(N, Cout, spec.H_out, spec.W_out, x0.device, buf)
+            elif out_c8 == PRE_NORM:
+                out = hip.f16_c8_empty(N, Cout, spec.H_out, spec.W_out, x0.device)
+                hip.conv_forward_h16(fspec, h0, h1, pw, None, shift, out=out.view(torch.float16), out_fmt=hip.FMT_F16_C8)
+            elif not out_c8:
+                out = torch.empty(N, Cout, spec.H_out, spec.W_out, dtype=torch.float32, device=x0.device)
+                hip.conv_forward_h16(fspec, h0, h1, pw, None, shift, out=out, out_fmt=hip.FMT_F32_NCHW)
+            else:
+                raise hip.EssHipError('Conv2dFn(mixed): a half-operand convolution writes a pre-norm tensor or fp32 NCHW')
+        else:
+            if out_c8 == PRE_NORM_HILO:
+                out_c8 = PRE_NORM
+            out = _empty_act(N, Cout, spec.H_out, spec.W_out, x0.device, out_c8)
+            hip.conv_forward(spec, x0, x1, packed_weight(spec, weight), None, shift, out=out, src_fmt=_fmt(x0),
+                             out_fmt=hip.FMT_F16_C8 if out_c8 == PRE_NORM else _fmt(out))
         ctx.spec = spec
         ctx.has_x1, ctx.has_bias = x1 is not None, bias is not None
         ctx.bias_ref = weakref.ref(bias) if bias is not None else None
@@ -434,7 +530,7 @@ class Conv2dFn(torch.autograd.Function):
                     GRAD_READY_HOOK(weight)
         if d_skip is not None and need0:  # not fusable (or no data-gradient was computed): plain sum
             d0 = d_skip if d0 is None else (hip.add_bf16(d0, d_skip.contiguous()) if c8in else hip.add(d0, d_skip.contiguous()))
-        return d0, d1, dw, db, None, None, None, None, None, None
+        return d0, d1, dw, db, None, None, None, None, None, None, None
 
 
 def _wgrad_stride2_by_phases(x, dy, dw, db, k):
@@ -461,13 +557,14 @@ def _wgrad_stride2_by_phases(x, dy, dw, db, k):
                     dw[:, :, ky, kx] = tmp[:, :, 0 if ky == 0 else 1, 0 if kx == 0 else 1]
 
 
-def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT, out_c8=None):
-    return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1, False, out_c8)
+def conv2d(x0, weight, bias=None, stride=1, pad=0, x1=None, mode0=hip.SRC_DIRECT, mode1=hip.SRC_DIRECT, out_c8=None, half=False):
+    """half: (mixed configuration only; ignored otherwise) run the forward contraction on IEEE-half operands -- the decoder's convolutions"""
+    return Conv2dFn.apply(x0, x1, weight, bias, stride, pad, mode0, mode1, False, out_c8, half)
 
 
-def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0, out_c8=None):
+def conv2d_passthrough(x0, weight, bias=None, stride=1, pad=0, out_c8=None, half=False):
     """-> (conv2d(x0), x0): use the second value as the skip operand of a residual block (see Conv2dFn.forward)."""
-    return Conv2dFn.apply(x0, None, weight, bias, stride, pad, hip.SRC_DIRECT, hip.SRC_DIRECT, True, out_c8)
+    return Conv2dFn.apply(x0, None, weight, bias, stride, pad, hip.SRC_DIRECT, hip.SRC_DIRECT, True, out_c8, half)
 
 
 class InstanceNormFn(torch.autograd.Function):
@@ -477,6 +574,21 @@ class InstanceNormFn(torch.autograd.Function):
     def forward(ctx, x, residual, relu, eps, x_f16=False):
         """x_f16: x is an F16_C8 tensor (the producing convolution was asked for PRE_NORM storage; the tensor's own tag decides)"""
         x_f16 = bool(x_f16) or hip.is_f16_c8(x)
+        if _blocked(x) and hip.mixed():
+            # mixed configuration: the result leaves twice -- BF16_C8 (the tensor autograd sees: weight gradient, skip, losses) and
+            # F16_C8 (`.ess_h16`: what the next half-operand convolution reads); a [hi | lo] pre-norm input comes as x.ess_hilo
+            buf = getattr(x, 'ess_hilo', None)
+            xin, x_fmt = (buf, 2) if buf is not None else (x, 1 if x_f16 else 0)
+            res = residual
+            if residual is not None:
+                h = hip.h16_of(residual)
+                if h is not None:  # the skip operand's half values (a [hi | lo] latent: its hi parts, a plain copy of CB blocks per sample)
+                    res = h[0][:, :h[0].shape[1] // 2].contiguous() if h[1] else h[0]
+            y, y16, stats = hip.instnorm_forward_c8_mixed(xin, _channels(x), res, relu, eps, x_fmt)
+            hip.attach_h16(y, y16, False)
+            ctx.relu, ctx.x_f16 = relu, x_fmt
+            ctx.save_for_backward(xin, stats)
+            return y
         if _blocked(x):
             y, stats = hip.instnorm_forward_c8(x, _channels(x), residual, relu, eps, x_f16)
         else:
@@ -491,8 +603,10 @@ class InstanceNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = hip.instnorm_backward_c8(x, _channels(x), dy, stats, ctx.relu, ctx.x_f16) if _blocked(x) else \
-                hip.instnorm_backward(x, dy, stats, ctx.relu)
+            if _blocked(dy):  # (x may be a [hi | lo] half pair with twice the blocks: the channel count is the gradient's)
+                dx = hip.instnorm_backward_c8(x, _channels(dy), dy, stats, ctx.relu, ctx.x_f16)
+            else:
+                dx = hip.instnorm_backward(x, dy, stats, ctx.relu)
         dres = dy if ctx.needs_input_grad[1] else None
         return dx, dres, None, None, None
 

@@ -19,10 +19,12 @@ EPI_LINEAR, EPI_LSTM, EPI_GRU_UR, EPI_GRU_OUT = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_SUMPOOL2 = 0, 1, 2, 3, 4
 W_CONV, W_TRANSPOSED, W_ROWS, W_CONV5_S2D = 0, 1, 2, 3
 GRU_U_F32, GRU_U_F16 = 0, 1
-COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
-FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8 = 0, 1, 2, 3
+COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_F16 = 0, 1, 2, 3
+FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8, FMT_F16_C8_HILO = 0, 1, 2, 3, 4
+LSTM_H_HILO = 1
 
 _default_compute = COMPUTE_FP32
+_mixed = False
 
 
 def set_compute(kind):
@@ -32,13 +34,31 @@ def set_compute(kind):
     configuration, every 3x3 / stride-1 contraction -- forward, data-gradient, recurrent gates, weight gradient -- as
     w_hi x_hi + w_hi x_lo + w_lo x_hi on the bf16 matrix cores with fp32 accumulators, ~2^-16 relative operand error; every other
     convolution on the exact-fp32 kernels: the parity-grade configuration at a matrix-core-rate step)."""
-    global _default_compute
+    global _default_compute, _mixed
+    # 'mixed' (round 6): the bf16 configuration's storage and BACKWARD arithmetic (BF16_C8 tensors, bf16 data- and weight-gradients),
+    # every FORWARD contraction of the frozen encoder's recurrent part and of the decoder on IEEE-half operands (ESS_COMPUTE_F16, the
+    # same matrix-core rate, 11 instead of 8 significant bits), [hi | lo] half pairs where an operand's mean is large against its
+    # spread (the encoder convolution feeding a recurrent block, the event latents, the first decoder layer's pre-norm tensor):
+    # per-pixel argmax / mIoU parity with the fp32 reference at the bf16 step's cost + ~15 % (DESIGN.md section 5, round 6)
+    _mixed = kind == 'mixed'
+    if _mixed:
+        kind = 'bf16'
     _default_compute = {'fp32': COMPUTE_FP32, 'bf16': COMPUTE_BF16, 'bf16x3': COMPUTE_BF16X3, COMPUTE_FP32: COMPUTE_FP32,
                         COMPUTE_BF16: COMPUTE_BF16, COMPUTE_BF16X3: COMPUTE_BF16X3}[kind]
 
 
 def get_compute():
+    """'fp32' | 'bf16' | 'bf16x3' -- storage / backward arithmetic; the 'mixed' configuration reports 'bf16' here and True from mixed()"""
     return {COMPUTE_FP32: 'fp32', COMPUTE_BF16: 'bf16', COMPUTE_BF16X3: 'bf16x3'}[_default_compute]
+
+
+def mixed():
+    return _mixed
+
+
+def compute_name():
+    """the name set_compute() was given"""
+    return 'mixed' if _mixed else get_compute()
 
 EXPORTS = [
     'ess_last_error', 'ess_version', 'ess_conv2d_plan', 'ess_conv2d_pack_weights', 'ess_conv2d_pack_rows',
@@ -51,6 +71,7 @@ EXPORTS = [
     'ess_batchnorm_train_backward_c8', 'ess_l1_loss_c8', 'ess_augment_image_label', 'ess_radam_step_dev', 'ess_upsample_bilinear2x_add_c8',
     'ess_upsample_bilinear2x_add_c8_from_c8', 'ess_add_bf16', 'ess_event_normalize_slices', 'ess_sum_scalars',
     'ess_label_confusion', 'ess_augment_perspective_filter', 'ess_tuning_set', 'ess_tuning_get', 'ess_conv2d_s2d_preferred',
+    'ess_to_f16_c8', 'ess_bf16_c8_to_f16_c8', 'ess_f16_c8_to_bf16_c8', 'ess_instnorm_forward_c8_mixed',
 ]
 
 
@@ -115,9 +136,9 @@ def lib():
             'ess_sum_scalars': [P, I, P, P],
             'ess_event_normalize': [P, P, I64, P, P],
             'ess_event_normalize_slices': [P, P, I, I, I64, P, P],
-            'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, P],
-            'ess_sym_js_loss': [P, P, P, P, F, I, I, I, P, P],
-            'ess_l1_loss': [P, P, P, P, F, I64, P, P],
+            'ess_task_loss': [P, P, P, P, F, I, I, I, I, I, I, P, c_size_t, P],
+            'ess_sym_js_loss': [P, P, P, P, F, I, I, I, P, c_size_t, P],
+            'ess_l1_loss': [P, P, P, P, F, I64, P, c_size_t, P],
             'ess_radam_step': [P, P, P, P, I64, F, F, F, F, F, I, P],
             'ess_argmax_confusion': [P, P, P, P, I, I, I, I, P],
             'ess_resize_nearest': [P, P, I, I, I, I, I, P],
@@ -130,7 +151,11 @@ def lib():
             'ess_instnorm_backward_c8': [P, P, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_batchnorm_train_forward_c8': [P, P, P, P, P, P, F, F, P, P, I, I, I, I, I, P, c_size_t, P],
             'ess_batchnorm_train_backward_c8': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, c_size_t, P],
-            'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, P],
+            'ess_l1_loss_c8': [P, P, P, P, F, I64, I64, P, c_size_t, P],
+            'ess_to_f16_c8': [P, P, I, I, I, I, I, P],
+            'ess_bf16_c8_to_f16_c8': [P, P, I64, P],
+            'ess_f16_c8_to_bf16_c8': [P, P, I, I, I, I, I, P],
+            'ess_instnorm_forward_c8_mixed': [P, P, P, P, P, I, I, I, F, I, I, I, P, c_size_t, P],
             'ess_augment_image_label': [P, P, P, P, P, P, I, I, I, I, I, P],
             'ess_radam_step_dev': [P, P, P, P, I64, F, F, F, P, P],
             'ess_upsample_bilinear2x_add_c8': [P, P, P, I, I, I, I, P],
@@ -478,10 +503,13 @@ def instnorm_forward_c8(x, C, residual, relu, eps=1e-5, x_f16=False):
 
 
 def instnorm_backward_c8(x, C, dy, stats, relu, x_f16=False):
+    """x_f16: False / 0 BF16_C8, True / 1 F16_C8, 2 a [hi | lo] half pair [N][2 CB][H][W][8] (its hi parts are read)"""
     N, CB, H, W, _ = x.shape
-    dx = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    if int(x_f16) == 2:
+        CB //= 2
+    dx = torch.empty(N, CB, H, W, 8, dtype=torch.bfloat16, device=x.device)
     L = lib()
-    xdt, xf = torch.bfloat16, int(bool(x_f16))
+    xdt, xf = x.dtype, int(x_f16)
     ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
     _check(L.ess_instnorm_backward_c8(ptr(x, xdt), ptr(dy, torch.bfloat16), ptr(stats), ptr(dx, torch.bfloat16), N, C, H * W,
                                       int(relu), xf, c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_instnorm_backward_c8')
@@ -667,7 +695,7 @@ def task_loss(logits, labels, want_grad, scale=1.0, ignore_index=255, use_dice=T
     dz = torch.empty_like(logits) if want_grad else None
     ws = workspace(lib().ess_task_loss_workspace(K), logits.device, 'loss')
     _check(lib().ess_task_loss(ptr(logits), ptr(labels, torch.int64), ptr(loss), ptr(dz), c_float(scale), N, K, H * W,
-                               int(ignore_index), int(use_dice), int(use_ce), c_void_p(ws.data_ptr()), stream()),
+                               int(ignore_index), int(use_dice), int(use_ce), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
            'ess_task_loss')
     return loss, dz
 
@@ -678,7 +706,7 @@ def sym_js_loss(a, b, want_grad, scale=1.0):
     da = torch.empty_like(a) if want_grad else None
     ws = _mean_loss_ws(a.device)
     _check(lib().ess_sym_js_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), N, K, H * W, c_void_p(ws.data_ptr()),
-                                 stream()), 'ess_sym_js_loss')
+                                 c_size_t(ws.numel()), stream()), 'ess_sym_js_loss')
     return loss, da
 
 
@@ -687,7 +715,7 @@ def l1_loss(a, b, want_grad, scale=1.0):
     da = torch.empty_like(a) if want_grad else None
     ws = _mean_loss_ws(a.device)
     _check(lib().ess_l1_loss(ptr(a), ptr(b), ptr(loss), ptr(da), c_float(scale), a.numel(), c_void_p(ws.data_ptr()),
-                             stream()), 'ess_l1_loss')
+                             c_size_t(ws.numel()), stream()), 'ess_l1_loss')
     return loss, da
 
 
@@ -699,7 +727,7 @@ def l1_loss_c8(a, b, n_real, want_grad, scale=1.0):
     da = torch.empty_like(a) if want_grad else None
     ws = _mean_loss_ws(a.device)
     _check(lib().ess_l1_loss_c8(ptr(a, torch.bfloat16), ptr(b, torch.bfloat16), ptr(loss), ptr(da, torch.bfloat16), c_float(scale),
-                                a.numel() // 8, int(n_real), c_void_p(ws.data_ptr()), stream()), 'ess_l1_loss_c8')
+                                a.numel() // 8, int(n_real), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()), 'ess_l1_loss_c8')
     return loss, da
 
 
@@ -785,3 +813,87 @@ def argmax_confusion(logits, labels=None, conf=None, ignore_index=255, want_pred
     _check(lib().ess_argmax_confusion(ptr(logits), ptr(labels, torch.int64), ptr(pred, torch.int64), ptr(conf, torch.int64),
                                       N, K, H * W, int(ignore_index), stream()), 'ess_argmax_confusion')
     return pred
+
+
+# ------------------------------------------------------------------------------------------ 'mixed' configuration (ESS_COMPUTE_F16)
+def f16_blocks_empty(N, C, H, W, device, hilo=False):
+    """Uninitialised F16_C8 tensor of a logical [N, C, H, W] activation: float16 [N][ceil(C/8)][H][W][8]; hilo: the [hi | lo] pair
+    [N][2 ceil(C/8)][H][W][8] (ESS_FMT_F16_C8_HILO)."""
+    return torch.empty(N, ((C + 7) // 8) * (2 if hilo else 1), H, W, 8, dtype=torch.float16, device=device)
+
+
+def h16_of(t):
+    """(half copy, hilo) a producer left next to `t` (`.ess_h16`, valid while `t` is unmodified), or None."""
+    c = getattr(t, 'ess_h16', None)
+    return (c[0], c[2]) if c is not None and c[1] == t._version else None
+
+
+def attach_h16(t, h16, hilo=False):
+    t.ess_h16 = (h16, t._version, bool(hilo))
+    return t
+
+
+def to_f16_c8(x, hilo=False):
+    """fp32 NCHW -> F16_C8 (hilo: the [hi | lo] pair) on the device."""
+    N, C, H, W = x.shape
+    y = f16_blocks_empty(N, C, H, W, x.device, hilo)
+    _check(lib().ess_to_f16_c8(ptr(x), ptr(y, torch.float16), N, C, H, W, int(bool(hilo)), stream()), 'ess_to_f16_c8')
+    return y
+
+
+def bf16_c8_to_f16_c8(x):
+    """BF16_C8 -> F16_C8 (exact inside half's range)."""
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _check(lib().ess_bf16_c8_to_f16_c8(ptr(x, torch.bfloat16), ptr(y, torch.float16), x.numel() // 8, stream()), 'ess_bf16_c8_to_f16_c8')
+    return y
+
+
+def f16_c8_to_bf16_c8(x, hilo=False):
+    """F16_C8 (or, hilo, a [hi | lo] pair: hi + lo) -> BF16_C8, round to nearest even."""
+    N, nb, H, W, _ = x.shape
+    CB = nb // 2 if hilo else nb
+    y = torch.empty(N, CB, H, W, 8, dtype=torch.bfloat16, device=x.device)
+    _check(lib().ess_f16_c8_to_bf16_c8(ptr(x, torch.float16), ptr(y, torch.bfloat16), N, CB * 8, H, W, int(bool(hilo)), stream()),
+           'ess_f16_c8_to_bf16_c8')
+    return y
+
+
+def conv_forward_h16(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None, out2=None,
+                     out_h16=None, out_fmt=FMT_F32_NCHW, aux_fmt=FMT_F32_NCHW, src_fp32=False):
+    """ess_conv2d_forward of an ESS_COMPUTE_F16 spec: src0 / src1 / residual are F16_C8 tensors (float16 [N][C/8][H][W][8]; src_fp32:
+    the fp32 NCHW image of the 5x5 head), out_fmt FMT_F16_C8 / FMT_F16_C8_HILO: `out` is a float16 tensor from f16_blocks_empty;
+    FMT_F32_NCHW: fp32 (+ out_h16, the half copy); LSTM / GRU: out_fmt / aux_fmt describe the fp32 states, out_h16 the half copy."""
+    if spec.desc.compute != COMPUTE_F16:
+        raise EssHipError('conv_forward_h16: the spec was not created with compute=COMPUTE_F16')
+    sdt = torch.float32 if src_fp32 else torch.float16
+    sfmt = FMT_F32_NCHW if src_fp32 else FMT_F16_C8
+    half_out = out_fmt in (FMT_F16_C8, FMT_F16_C8_HILO)
+    odt = torch.float16 if half_out else torch.float32
+    res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else ((FMT_F16_C8 if half_out else out_fmt) if residual is not None else FMT_F32_NCHW)
+    desc = spec.desc_fmt(sfmt, out_fmt, res_fmt)
+    u16 = spec.desc.act == GRU_U_F16 and spec.desc.epilogue in (EPI_GRU_UR, EPI_GRU_OUT)
+    udt_out = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_UR and out_fmt == FMT_F32_C8) else odt
+    udt_aux = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_OUT and res_fmt == FMT_F32_C8) else torch.float32
+    _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt), ptr(packed_w, torch.uint8), ptr(scale), ptr(shift),
+                                    ptr(residual, torch.float16 if half_out else torch.float32), ptr(aux0), ptr(aux1, udt_aux),
+                                    ptr(out, udt_out), ptr(out2, odt), ptr(out_h16, torch.float16), stream()), 'ess_conv2d_forward(f16)')
+    return out
+
+
+def instnorm_forward_c8_mixed(x, C, residual, relu, eps=1e-5, x_fmt=1, want_bf16=True):
+    """InstanceNorm of the mixed configuration -> (y BF16_C8 or None, y16 F16_C8, stats).  x: the pre-norm tensor (x_fmt 0 BF16_C8,
+    1 F16_C8, 2 the [hi | lo] pair [N][2 CB][H][W][8]) in a bfloat16- or float16-typed container; residual: BF16_C8 (bfloat16) or
+    F16_C8 (float16) by its dtype."""
+    N, nb, H, W, _ = x.shape
+    CB = nb // 2 if x_fmt == 2 else nb
+    y = torch.empty(N, CB, H, W, 8, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    y16 = torch.empty(N, CB, H, W, 8, dtype=torch.float16, device=x.device)
+    stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
+    L = lib()
+    ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
+    res_f16 = residual is not None and residual.dtype == torch.float16
+    _check(L.ess_instnorm_forward_c8_mixed(ptr(x, x.dtype), ptr(residual, residual.dtype if residual is not None else torch.float16),
+                                           ptr(y, torch.bfloat16), ptr(y16, torch.float16), ptr(stats), N, C, H * W, c_float(eps),
+                                           int(relu), int(x_fmt), int(res_f16), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),
+           'ess_instnorm_forward_c8_mixed')
+    return y, y16, stats

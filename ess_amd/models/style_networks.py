@@ -34,7 +34,7 @@ class ReLUINSConv2d(nn.Module):
         c = self.model[0]
         pre = Fn.pre_norm_fmt() if hip.is_c8(x) else None  # (the conv output is a pre-norm tensor: F16_C8 in the bf16 configuration)
         y = Fn.conv2d(x, c.weight, c.bias, c.stride[0], c.padding[0], x1=skip,
-                      mode0=hip.SRC_NEAREST_UP2 if up else hip.SRC_DIRECT, out_c8=pre)
+                      mode0=hip.SRC_NEAREST_UP2 if up else hip.SRC_DIRECT, out_c8=pre, half=True)  # (half: the mixed configuration's forward)
         return Fn.instance_norm(y, None, True, self.model[1].eps, x_f16=pre == Fn.PRE_NORM)
 
     def forward(self, x):
@@ -56,14 +56,22 @@ class INSResBlock(nn.Module):
         self.model = nn.Sequential(*layers)
         self.model.apply(gaussian_weights_init)
 
-    def forward(self, x):
+    def forward(self, x, first=False):
+        """first (mixed configuration): the block reads the event latents -- its first pre-norm tensor has channel means of 6-17 standard
+        deviations and leaves the convolution as a [hi | lo] half pair (planes of at most 5120 pixels: the fused norm kernels)"""
         c1, c2 = self.model[0], self.model[3]
         # x enters the graph ONCE: conv1 hands it through as the skip operand, so the skip gradient is added inside
         # conv1's data-gradient kernel instead of by a separate elementwise pass (functional.Conv2dFn.forward)
         pre = Fn.pre_norm_fmt() if hip.is_c8(x) else None  # (the conv outputs are pre-norm tensors: F16_C8 in the bf16 configuration)
-        y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1, out_c8=pre)
+        pre1 = pre
+        if first and pre == Fn.PRE_NORM and Fn.mixed() and x.shape[2] * x.shape[3] <= 5120 and c1.out_channels % 64 == 0:
+            pre1 = Fn.PRE_NORM_HILO
+        y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1, out_c8=pre1, half=True)
+        hx = hip.h16_of(x)
+        if hx is not None and hip.h16_of(skip) is None:  # (an input handed through an autograd.Function comes back as a new alias: keep its half copy)
+            hip.attach_h16(skip, hx[0], hx[1])
         y = Fn.instance_norm(y, None, True, self.model[1].eps, x_f16=pre == Fn.PRE_NORM)
-        y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1, out_c8=pre)
+        y = Fn.conv2d(y, c2.weight, c2.bias, 1, 1, out_c8=pre, half=True)
         return Fn.instance_norm(y, skip, False, self.model[4].eps, x_f16=pre == Fn.PRE_NORM)  # IN(.) + residual in one pass
 
 
@@ -117,7 +125,9 @@ class SemSegE2VID(nn.Module):
         lat = (lambda t: Fn.as_c8(t).contiguous()) if c8 else (lambda t: t.contiguous())
         x = lat(x)
         if self.skip_connect:
-            x = self.decoder_scale_1(x)
+            x = self.decoder_scale_1[0](x, first=True)
+            for blk in list(self.decoder_scale_1)[1:]:
+                x = blk(x)
             x = self.decoder_scale_2[0].forward_fused(x, lat(input_dict[4]), up=True)
             # out[4] / out[2] feed the next stage AND (through the returned dict) the cycle losses: Fn.fork sums the two
             # gradients in one library launch instead of autograd's accumulation add
@@ -128,14 +138,16 @@ class SemSegE2VID(nn.Module):
             self.update_skip_dict(out, xo, sz_in)
             x = self.decoder_scale_4[0].forward_fused(x, None, up=True)
         else:
-            x = self.decoder_scale_1(x)
+            x = self.decoder_scale_1[0](x, first=True)
+            for blk in list(self.decoder_scale_1)[1:]:
+                x = blk(x)
             x, xo = Fn.fork(self.decoder_scale_2[1].forward_fused(x, None, up=True))
             self.update_skip_dict(out, xo, sz_in)
             x, xo = Fn.fork(self.decoder_scale_3[1].forward_fused(x, None, up=True))
             self.update_skip_dict(out, xo, sz_in)
             x = self.decoder_scale_4[1].forward_fused(x, None, up=True)
         c5 = self.decoder_scale_5[0]
-        x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0, out_c8=False)  # the logits: fp32 NCHW for the loss / metric kernels
+        x = Fn.conv2d(x, c5.weight, c5.bias, 1, 0, out_c8=False, half=True)  # the logits: fp32 NCHW for the loss / metric kernels
         self.update_skip_dict(out, x, sz_in)
         return out
 

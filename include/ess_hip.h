@@ -61,14 +61,26 @@ enum { ESS_COMPUTE_FP32 = 0, ESS_COMPUTE_BF16 = 1,
         * w_hi x_hi + w_hi x_lo + w_lo x_hi in fp32 accumulators: ~2^-16 relative operand error against bf16's 2^-8, at three bf16
         * MFMAs per product (the exact fp32 MFMA costs sixteen).  Every other convolution of such a descriptor runs the exact-fp32
         * kernels.  The parity-grade configuration with a matrix-core-rate step.                                          */
-       ESS_COMPUTE_BF16X3 = 2 };
+       ESS_COMPUTE_BF16X3 = 2,
+       /* IEEE-half operands (round 6; the forward arithmetic of the "mixed" configuration): the matrix cores run
+        * v_mfma_f32_32x32x16_f16 at the bf16 rate with 11 instead of 8 significant operand bits; fp32 accumulators.  Every 16-bit
+        * tensor of such a call is an ESS_FMT_F16_C8 tensor (sources, residual, LINEAR output, the recurrent epilogues' copies), the
+        * weights are rounded to half at pack time, conversions saturate at +-65504 (NaN kept).  Forward forms only (no SUMPOOL2, no
+        * zero-inserted source, no weight gradient): gradients stay bfloat16 -- their magnitudes (1e-7 for a mean loss over 2.5 M
+        * pixels) are below half's normal range.  fp32 NCHW sources only for the 2-channel 5x5 head.                         */
+       ESS_COMPUTE_F16 = 3 };
 /* storage format of a convolution source.  BF16_C8 = the "staging copy" a producing kernel can emit next to its
  * fp32 NCHW output (out_bf16 of ess_conv2d_forward, or ess_to_bf16_c8): bfloat16 [N][ceil(C/8)][H][W][8], i.e. the
  * 8 channels of a pixel are one 16-byte vector = one MFMA K-fragment; channels past C are zero.  A consumer conv
  * stages it with plain 16-byte copies: 4x fewer cache-line touches and half the bytes of the fp32 NCHW path.      */
 /* ESS_FMT_F16_C8: the BF16_C8 layout with IEEE half elements.  ONLY as a convolution OUTPUT (fmt_out, LINEAR epilogue) that a norm
  * kernel reads (x of ess_instnorm_* / ess_batchnorm_train_*_c8 with x_f16 = 1): pre-normalisation tensors keep 11 significant bits. */
-enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3,
+/* ESS_COMPUTE_F16 convolutions read and write F16_C8 tensors throughout.  ESS_FMT_F16_C8_HILO (fmt_out of such a LINEAR convolution; act in
+ * {none, relu}, no residual, no out_split, C_out % 64 == 0): the output is [N][2 ceil(C/8)][H][W][8] halfs -- blocks [0, CB) hold
+ * hi = half(v), blocks [CB, 2 CB) lo = half(v - hi), ~22 significant bits in the pair.  A consumer reads it as a plain F16_C8 source of 2 C
+ * channels against a weight whose input columns are repeated ([w | w]): w (hi + lo) on the half matrix cores.  Used where an
+ * activation's mean is large against its spread: the encoder convolution in front of a recurrent block, the event latents.   */
+enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3, ESS_FMT_F16_C8_HILO = 4,
        ESS_FMT_F32_C8 = 2 /* fp32 [N][ceil(C/8)][H][W][8]: ConvLSTM cell / ConvGRU hidden states between time steps (recurrent epilogues only) */ };
 /* ConvGRU: the update gate u between the (update, reset) kernel and the candidate kernel (EssConvDesc.act of the two GRU epilogues).
  * ESS_GRU_U_F16: u is rounded to IEEE half (11 significant bits of a value in (0, 1); the gates come from bf16 operands) -- with
@@ -76,6 +88,10 @@ enum { ESS_FMT_F32_NCHW = 0, ESS_FMT_BF16_C8 = 1, ESS_FMT_F16_C8 = 3,
  * pair's most bandwidth-bound operand), with fp32 NCHW states the fp32 tensor carries the rounded value, so that a sequence gives the
  * same bits whichever storage its steps use.  bf16 compute only.  Reference: e2vid/model/submodules.py:255-273 (`update`).          */
 enum { ESS_GRU_U_F32 = 0, ESS_GRU_U_F16 = 1 };
+/* ConvLSTM with ESS_COMPUTE_F16 (EssConvDesc.act of the LSTM epilogue; 0 otherwise): the half copy of h' (out_bf16) leaves as a
+ * [hi | lo] pair, [N][2 hid/8][H][W][8] (see ESS_FMT_F16_C8_HILO) -- the event latents the semantic decoder reads.  Lean form only
+ * (channel-blocked cell states, hidden % 16 == 0).                                                                       */
+enum { ESS_LSTM_H_HILO = 1 };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */
@@ -183,6 +199,15 @@ int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const void* src1,
 int ess_to_bf16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
 /* BF16_C8 -> fp32 NCHW (exact).                                                                                  */
 int ess_from_bf16_c8(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, ess_stream_t stream);
+/* Format bridges of the "mixed" configuration (ESS_COMPUTE_F16 convolutions read F16_C8 tensors):
+ *   ess_to_f16_c8          fp32 NCHW -> F16_C8 [N][ceil(C/8)][H][W][8] halfs, or (hilo != 0) the [hi | lo] pair of ESS_FMT_F16_C8_HILO,
+ *                          [N][2 ceil(C/8)][H][W][8] (event latents handed over as fp32 tensors: models/style_networks.py:69-88);
+ *   ess_bf16_c8_to_f16_c8  BF16_C8 -> F16_C8, n_vec 16-byte vectors (exact but for |v| > 65504 / < 6e-8; the image encoder's latents);
+ *   ess_f16_c8_to_bf16_c8  F16_C8, or (hilo != 0) a [hi | lo] pair summed, -> BF16_C8 (round to nearest even): the form the weight
+ *                          gradient, the skip connection and the L1 terms of the trainable decoder keep reading.                    */
+int ess_to_f16_c8(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t hilo, ess_stream_t stream);
+int ess_bf16_c8_to_f16_c8(const void* x, void* y, int64_t n_vec, ess_stream_t stream);
+int ess_f16_c8_to_bf16_c8(const void* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t hilo, ess_stream_t stream);
 
 /* Weight gradient of the same convolution (replaces cuDNN wgrad under autograd for
  * models/style_networks.py:158-193 and the ResNet prefix :116-121).
@@ -224,6 +249,13 @@ int ess_instnorm_backward(const float* x, const float* dy, const float* stats, f
 size_t ess_norm_workspace_c8(int32_t groups);
 int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float* stats, int32_t N, int32_t C, int32_t hw,
                             float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream);
+/* InstanceNorm forward of the "mixed" configuration: as ess_instnorm_forward_c8, plus y16 = the result as an F16_C8 tensor (required;
+ * what the next ESS_COMPUTE_F16 convolution reads), y (BF16_C8) optional; x_fmt: 0 BF16_C8, 1 F16_C8, 2 the [hi | lo] pair of
+ * ESS_FMT_F16_C8_HILO (x = hi + lo; planes of at most 5120 pixels); res_f16: the residual is an F16_C8 tensor.  The statistics
+ * are those of the values read.  ess_instnorm_backward_c8 takes the same x with x_f16 = x_fmt (2: the hi parts are read).     */
+int ess_instnorm_forward_c8_mixed(const void* x, const void* residual, void* y, void* y16, float* stats, int32_t N, int32_t C, int32_t hw,
+                                  float eps, int32_t relu, int32_t x_fmt, int32_t res_f16, void* workspace, size_t workspace_bytes,
+                                  ess_stream_t stream);
 int ess_instnorm_backward_c8(const void* x, const void* dy, const float* stats, void* dx, int32_t N, int32_t C, int32_t hw,
                              int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 int ess_batchnorm_train_forward_c8(const void* x, const void* residual, const float* gamma, const float* beta,
@@ -349,25 +381,26 @@ int ess_augment_perspective_filter(const float* img, const int64_t* label, const
 size_t ess_task_loss_workspace(int32_t K);
 int ess_task_loss(const float* logits, const int64_t* labels, float* loss, float* dlogits, float loss_scale,
                   int32_t N, int32_t K, int32_t hw, int32_t ignore_index, int32_t use_dice, int32_t use_ce,
-                  void* workspace, ess_stream_t stream);
+                  void* workspace, size_t workspace_bytes, ess_stream_t stream);
 /* Workspace of the mean-type losses below (ess_sym_js_loss, ess_l1_loss, ess_l1_loss_c8): one partial sum per workgroup.  Each loss is
  * TWO launches: the kernel proper (every workgroup stores its partial: no atomics, no memset in front) and a one-workgroup finalize
  * that adds the partials in workgroup order -- the value does not depend on scheduling.  Nothing to initialise.  Do not share the
- * buffer between streams.                                                                                                     */
+ * buffer between streams.  ABI 110 (round 6): every loss entry point takes workspace_bytes and returns ESS_EINVAL when the buffer is
+ * smaller than it needs (ABI 100 callers passed 8 bytes here until round 5 made it one partial per workgroup).                  */
 #define ESS_LOSS_WORKSPACE_BYTES (8 * (1 + 2048))
 /* symJSDivLoss (utils/loss_functions.py:27-37): loss (1 float) and gradient w.r.t. `a` only
  * (the other argument is always computed under no_grad by the trainers).  workspace: ESS_LOSS_WORKSPACE_BYTES (see above). */
 int ess_sym_js_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int32_t N,
-                    int32_t K, int32_t hw, void* workspace, ess_stream_t stream);
+                    int32_t K, int32_t hw, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 /* L1Loss mean (training/ess_trainer.py:217-229): loss and gradient w.r.t. a.  workspace: ESS_LOSS_WORKSPACE_BYTES.  */
 int ess_l1_loss(const float* a, const float* b, float* loss, float* da, float loss_scale, int64_t n,
-                void* workspace, ess_stream_t stream);
+                void* workspace, size_t workspace_bytes, ess_stream_t stream);
 
 /* L1Loss mean over BF16_C8 operands (bf16 configuration: the latents / intermediate predictions the cycle losses compare are
  * stored as BF16_C8); da (nullable): BF16_C8 gradient.  n_vectors 16-byte pixel vectors, n REAL elements (the mean's
  * denominator; padded tail channels are zero in both operands).  workspace: ESS_LOSS_WORKSPACE_BYTES.               */
 int ess_l1_loss_c8(const void* a, const void* b, float* loss, void* da, float loss_scale, int64_t n_vectors, int64_t n,
-                   void* workspace, ess_stream_t stream);
+                   void* workspace, size_t workspace_bytes, ess_stream_t stream);
 
 /* RAdam.step over ONE flat parameter buffer (utils/radam.py:15-80, weight_decay = 0).
  * step_size / n_sma_ge5 are computed by the host exactly as radam.py:49-64.                         */
