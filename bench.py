@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--recurrent', default='convlstm', choices=['convlstm', 'convgru'],
                     help='recurrent block of the frozen E2VID encoder (reference e2vid/model/submodules.py:175-273); BASELINE config 5 '
                          'names the ConvGRU variant')
-    ap.add_argument('--compute', default='bf16', choices=['bf16', 'fp32', 'bf16x3', 'mixed'],
+    ap.add_argument('--compute', default='mixed', choices=['bf16', 'fp32', 'bf16x3', 'mixed'],
                     help='conv contraction arithmetic: bf16 MFMA operands + fp32 accumulate (config 3), exact fp32 MFMA, or '
                          'split-operand bf16 (fp32 tensors, three bf16 MFMAs per product: the parity-grade configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -57,6 +57,16 @@ def parse():
     ap.add_argument('--no-t20-extra', action='store_true', help='skip the T = 20 steps of the parity-grade configuration')
     ap.add_argument('--quick-cpu-baseline', action='store_true', help='1 warm-up + 2 timed oracle steps instead of 2 + 5')
     return ap.parse_args()
+
+
+# argmax agreement / mIoU of each arithmetic against the fp32 CPU oracle on the trained-decoder fixture at 480x640 (tests/test_hip_bf16_separated.py,
+# asserted there; the numbers of the GPU suite's last run are in profiles/r6_parity.txt)
+PARITY_NOTE = {
+    'mixed': 'trained decoder 480x640: argmax agreement >= 99.99 % (11 of 307200 flips), |dmIoU| <= 1e-4 (98.8978 vs 98.8998 %): tests assert both; profiles/r6_parity.txt',
+    'bf16': 'trained decoder 480x640: argmax agreement 99.84 % (476 flips), mIoU 98.786 vs 98.900 %: misses the 1e-4 clause; profiles/r6_parity.txt',
+    'bf16x3': 'trained decoder 480x640: 2 flips, mIoU 98.8984 vs 98.8998 %; logits within 1e-3; profiles/r6_parity.txt',
+    'fp32': 'logits within 1e-3, argmax exact outside the oracle tie band (11 of 307200 at the DSEC size), mIoU equal; profiles/r6_parity.txt',
+}
 
 
 class HipEvents:
@@ -104,35 +114,53 @@ def in_step_conv_rate(trainer, batch):
     -> {launches, ms (sum of their durations), achieved TFLOP/s = their algorithmic FLOPs / that time}.  This is the rate the rocprofv3
     summary of the eager step gives for the kernel (profiles/r3_uda_bf16_eager_kernel_stats.txt: average duration x launches)."""
     from ess_amd import hip
-    spans = []
-    orig = hip.conv_forward
+    spans, gate_spans = [], []
+    orig, orig_h = hip.conv_forward, hip.conv_forward_h16
+
+    def timed(call, spec, half):
+        (N, Hv, Wv, C0, C1, _, _, Cout, k, st, pad, epi, _, _, _, compute) = spec.key
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = call()
+        e1.record()
+        # (FLOPs of the launch AS ISSUED: a [hi | lo] source of the mixed configuration is 2 C stored channels)
+        (gate_spans if epi == hip.EPI_LSTM else spans).append((e0, e1, 2.0 * N * spec.H_out * spec.W_out * 9 * (C0 + C1) * Cout, half))
+        return r
 
     def wrapped(spec, src0, src1, packed_w, scale=None, shift=None, residual=None, aux0=None, aux1=None, out=None, out2=None,
                 out_bf=None, src_fmt=hip.FMT_F32_NCHW, out_fmt=hip.FMT_F32_NCHW, aux_fmt=hip.FMT_F32_NCHW):
-        (N, Hv, Wv, C0, C1, _, _, Cout, k, st, pad, epi, _, _, _, compute) = spec.key
-        hot = (k == 3 and st == 1 and epi == hip.EPI_LINEAR and compute == hip.COMPUTE_BF16 and src_fmt == hip.FMT_BF16_C8 and
-               out_fmt in (hip.FMT_BF16_C8, hip.FMT_F16_C8))
-        if not hot:
-            return orig(spec, src0, src1, packed_w, scale, shift, residual, aux0, aux1, out, out2, out_bf, src_fmt, out_fmt, aux_fmt)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(spec, src0, src1, packed_w, scale, shift, residual, aux0, aux1, out, out2, out_bf, src_fmt, out_fmt, aux_fmt)
-        e1.record()
-        spans.append((e0, e1, 2.0 * N * spec.H_out * spec.W_out * 9 * (C0 + C1) * Cout))
-        return r
+        k, st, epi, compute = spec.key[8], spec.key[9], spec.key[11], spec.key[15]
+        hot = (k == 3 and st == 1 and compute == hip.COMPUTE_BF16 and src_fmt == hip.FMT_BF16_C8 and
+               ((epi == hip.EPI_LINEAR and out_fmt in (hip.FMT_BF16_C8, hip.FMT_F16_C8)) or epi == hip.EPI_LSTM))
+        call = lambda: orig(spec, src0, src1, packed_w, scale, shift, residual, aux0, aux1, out, out2, out_bf, src_fmt, out_fmt, aux_fmt)  # noqa: E731
+        return timed(call, spec, False) if hot else call()
+
+    def wrapped_h(spec, src0, src1, packed_w, *a, **kw):
+        k, st, epi = spec.key[8], spec.key[9], spec.key[11]
+        fmt = kw.get('out_fmt', hip.FMT_F32_NCHW)
+        hot = k == 3 and st == 1 and not kw.get('src_fp32', False) and \
+            ((epi == hip.EPI_LINEAR and fmt in (hip.FMT_F16_C8, hip.FMT_F16_C8_HILO)) or epi == hip.EPI_LSTM)
+        call = lambda: orig_h(spec, src0, src1, packed_w, *a, **kw)  # noqa: E731
+        return timed(call, spec, True) if hot else call()
 
     g_saved = (getattr(trainer, '_g', None), getattr(trainer, '_g_mid', None), getattr(trainer, '_g_tail', None))
-    hip.conv_forward = wrapped
+    hip.conv_forward, hip.conv_forward_h16 = wrapped, wrapped_h
     try:
         trainer._g = None  # (issue this step eagerly; the captured graph is restored below)
         trainer.train_step(batch)
         torch.cuda.synchronize()
     finally:
-        hip.conv_forward = orig
+        hip.conv_forward, hip.conv_forward_h16 = orig, orig_h
         trainer._g = g_saved[0]
-    ms = sum(a.elapsed_time(b) for a, b, _ in spans)
-    fl = sum(f for _, _, f in spans)
+    ms = sum(a.elapsed_time(b) for a, b, _, _ in spans)
+    fl = sum(f for _, _, f, _ in spans)
+    gms = sum(a.elapsed_time(b) for a, b, _, _ in gate_spans)
+    gfl = sum(f for _, _, f, _ in gate_spans)
     return {'launches': len(spans), 'ms': round(ms, 4), 'achieved': round(fl / ms / 1e9, 1) if ms > 0 else None,
+            'half_operand_launches': sum(1 for s in spans if s[3]),
+            'dominant_in_step': {'kernel': 'conv_bf16_wide_kernel<2,2,LSTM> (the fused ConvLSTM gate launches: the largest single kernel of the step by time)',
+                                 'launches': len(gate_spans), 'ms': round(gms, 4), 'executed_tflops': round(gfl / gms / 1e9, 1) if gms > 0 else None,
+                                 'note': 'FLOPs of the launches as issued (the mixed configuration contracts the [hi | lo] x operand as 2 C channels: executed, not algorithmic, work)'},
             'note': 'HIP event pair around every launch of the kernel inside one eager train step issued after the timed region; population = EVERY '
                     '3x3 / stride-1 LINEAR launch with BF16_C8 sources and a BF16_C8 / F16_C8 output (forward and data-gradient forms of the decoder '
                     'and the image encoder, 64^ -> 32 @ full resolution included), i.e. a superset of the 16 decoder-forward layers `frac` is measured on'}
@@ -339,7 +367,44 @@ def roofline_blocks(args, device):
         fl = 2.0 * B * H * W * 9 * (2 * hid) * (3 * hid)
         gru_levels.append({'level': lvl, 'hidden': hid, 'ms_ur': round(ms1, 4), 'ms_out': round(ms2, 4), 'tflops': round(fl / (ms1 + ms2) / 1e9, 1)})
         gru_ms += ms1 + ms2; gru_fl += fl
-    tag = f'{args.compute}/{B}/{args.height}x{args.width}'
+    # ---- mixed configuration: the half-operand (ESS_COMPUTE_F16) instantiations of the same kernels, as the step's FORWARD launches them
+    mixed_fwd = None
+    if args.compute == 'mixed':
+        h_ms = h_fl = 0.0
+        for (C0, C1, Cout, Hv, Wv, m0, cnt) in decoder_conv3x3_layers(args):
+            spec = hip.conv_spec(B, Hv, Wv, C0, C1, Cout, 3, 1, 1, hip.SRC_NEAREST_UP2 if m0 else hip.SRC_DIRECT, hip.SRC_DIRECT, compute=hip.COMPUTE_F16)
+            x0 = hip.to_f16_c8(torch.randn(B, C0, Hv // (2 if m0 else 1), Wv // (2 if m0 else 1), generator=g).to(device))
+            x1 = hip.to_f16_c8(torch.randn(B, C1, Hv, Wv, generator=g).to(device)) if C1 else None
+            w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5).to(device)
+            pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(Cout, generator=g).to(device))
+            out = hip.f16_blocks_empty(B, Cout, Hv, Wv, device)
+            ms = _timed(ev, stream, lambda: hip.conv_forward_h16(spec, x0, x1, pw, None, pb, out=out, out_fmt=hip.FMT_F16_C8))
+            h_ms += cnt * ms; h_fl += cnt * 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout
+            del x0, x1, out
+        hg_ms = hg_fl = 0.0
+        hg_levels = []
+        for lvl, hid in enumerate((64, 128, 256)):
+            H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
+            # the product launch of a lean time step: x as a [hi | lo] half pair (2 hid stored channels), h as a half copy, channel-blocked cells
+            spec = hip.conv_spec(B, H, W, 2 * hid, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, compute=hip.COMPUTE_F16)
+            w = (torch.randn(4 * hid, 3 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device)
+            pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(4 * hid, generator=g).to(device))
+            x = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(device), hilo=True)
+            h = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(device))
+            c, co = hip.f32_c8_empty(B, hid, H, W, device).normal_(), hip.f32_c8_empty(B, hid, H, W, device)
+            h16 = hip.f16_blocks_empty(B, hid, H, W, device)
+            ms = _timed(ev, stream, lambda: hip.conv_forward_h16(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_h16=h16,
+                                                                 out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8))
+            fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)  # ALGORITHMIC: the reference's cat(x, h) contraction; the launch contracts 3 hid stored channels
+            hg_levels.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'algorithmic_tflops': round(fl / ms / 1e9, 1), 'executed_tflops': round(1.5 * fl / ms / 1e9, 1)})
+            hg_ms += ms; hg_fl += fl
+            del x, h, c, co, h16
+        mixed_fwd = {'decoder_forward_launch_set': {'kernel': 'the 16 launches above on IEEE-half operands (H = true instantiations: v_mfma_f32_32x32x16_f16)',
+                                                    'ms_per_launch_set': round(h_ms, 4), 'achieved': round(h_fl / h_ms / 1e9, 1), 'frac': round(h_fl / h_ms / 1e9 / peak, 4)},
+                     'convlstm_gate': {'kernel': 'conv_bf16_wide_kernel<2, 2, LSTM, H>: x as a [hi | lo] half pair (1.5x the stored K of the bf16 launch)',
+                                       'ms_per_launch_set': round(hg_ms, 4), 'algorithmic_tflops': round(hg_fl / hg_ms / 1e9, 1),
+                                       'executed_tflops': round(1.5 * hg_fl / hg_ms / 1e9, 1), 'executed_frac': round(1.5 * hg_fl / hg_ms / 1e9 / peak, 4), 'per_level': hg_levels}}
+    tag = f'{"bf16" if bf16 else args.compute}/{B}/{args.height}x{args.width}'  # (the PMC passes cover the bf16 instantiations; the half-operand flavour is the same code with v_mfma_f32_32x32x16_f16)
     conv_t = conv_fl / conv_ms / 1e9
     t_conv, t_gate, t_gru, t_wg, t_enc = [_traffic_from_profiles(g_ + '/' + tag) for g_ in ('conv3x3', 'gate', 'gru', 'wgrad', 'enc5x5s2')]
     return {'bound': 'mfma', **_pmc_summary(t_conv),
@@ -348,16 +413,17 @@ def roofline_blocks(args, device):
             'achieved': round(conv_t, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(conv_t / peak, 4),
             'traffic': t_conv, 'ms_per_launch_set': round(conv_ms, 4), 'per_layer': per_layer,
             'others': {
-                'convlstm_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
+                'convlstm_gate': {'kernel': 'conv_bf16_wide_kernel<2, 2, LSTM> (every lean gate launch of the step since round 4; conv_bf16_ws_k3s1_kernel<MB, LSTM, BF16_C8 sources> below its round-count threshold)' if bf16 else 'conv_f32_kernel<3,1,2,LSTM,8>',
                                   'achieved': round(gate_fl / gate_ms / 1e9, 1), 'frac': round(gate_fl / gate_ms / 1e9 / peak, 4),
                                   **_pmc_summary(t_gate), 'per_level': gate_levels, 'traffic': t_gate},
-                'convgru_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, GRU_UR | GRU_OUT, BF16_C8 sources>' if bf16 else 'conv_f32_kernel<3,1,2,GRU_UR | GRU_OUT,8>',
+                'convgru_gate': {'kernel': 'conv_bf16_ws_k3s1_kernel<MB, GRU_UR | GRU_OUT, BF16_C8 sources> (levels 0 / 1) | conv_bf16_wide_kernel<2, 2, GRU_UR | GRU_OUT> (level 2)' if bf16 else 'conv_f32_kernel<3,1,2,GRU_UR | GRU_OUT,8>',
                                  'achieved': round(gru_fl / gru_ms / 1e9, 1), 'frac': round(gru_fl / gru_ms / 1e9 / peak, 4),
                                  **_pmc_summary(t_gru), 'per_level': gru_levels, 'traffic': t_gru},
                 **({'encoder_conv5x5_s2': {'kernel': 'conv_bf16_wide_kernel<2, CW, LINEAR, S2D> (the 5x5 / stride-2 convolutions of the frozen encoder as a 3x3 over '
                                                      'the space-to-depth view of the BF16_C8 source) | conv_bf16_ws_pair_kernel<5, 2, 1>',
                                            'achieved': round(enc_fl / enc_ms / 1e9, 1), 'frac': round(enc_fl / enc_ms / 1e9 / peak, 4),
                                            **_pmc_summary(t_enc), 'ms_per_launch_set': round(enc_ms, 4), 'per_level': enc_levels, 'traffic': t_enc}} if enc_ms else {}),
+                **({'mixed_forward': mixed_fwd} if mixed_fwd else {}),
                 'wgrad': {'kernel': 'wgrad_c8_ws_kernel (LDS-DMA loader waves + MFMA waves) + wgrad_reduce_kernel' if bf16 else 'wgrad_f32_kernel<3,1> + reduce',
                           'achieved': round(wg_fl / wg_ms / 1e9, 1), 'frac': round(wg_fl / wg_ms / 1e9 / peak, 4),
                           **_pmc_summary(t_wg), 'ms_per_launch_set': round(wg_ms, 4), 'traffic': t_wg,
@@ -367,8 +433,9 @@ def roofline_blocks(args, device):
                                                           'in one launch (functional.WGRAD_DEFER); `achieved` / `frac` above stay the one-set launch of the earlier rounds'}}},
             'note': ('bf16 MFMA operands, fp32 accumulate' if bf16 else 'fp32-input MFMA (exact fp32)') +
                     '; HIP events on the launch stream, inside this process after the timed steps; launch sets repeated back to back, i.e. '
-                    'at the sustained-matrix-load clock (the same kernels inside the step, between HBM-bound launches, run 5-20 % faster: '
-                    'rocprofv3 averages in profiles/r5b_uda_bf16_eager_kernel_stats.txt, DESIGN.md 7d / 7e)'}
+                    'at the sustained-matrix-load clock.  `in_step` is the rate of the same kernel class inside one eager step (a superset of '
+                    'these 16 layers: data-gradient forms and the image encoder included; cold caches between unlike launches) and '
+                    '`in_step.dominant_in_step` that of the ConvLSTM gate launches, the largest kernel of the step by time'}
 
 
 def executed_flops_per_step(args):
@@ -489,8 +556,14 @@ def main():
     # data-parallel code paths: more than one rank -- or ONE rank under ESS_DP_FORCE=1 (the RCCL side of the step executed on a
     # single-GPU box: communicator bound to the device, ncclAllReduce(AVG) between / under the graph replays)
     dp = world > 1 or os.environ.get('ESS_DP_FORCE', '0') not in ('', '0')
+    rccl_ranks = None
     if dp:
         D.init_for_device(device)  # backend 'nccl' = RCCL over xGMI, bound to this rank's GPU (ESS_DIST_BACKEND=gloo overrides)
+        # how many ranks the collective backend actually joined: a SUM all-reduce of ones, read back AFTER the collective (a record with
+        # n_gpus = 8 and rccl_ranks = 8 says RCCL saw eight ranks; dist.get_world_size() alone repeats the launcher's environment)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        rccl_ranks = {'all_reduce_sum_of_ones': int(ones.item()), 'world_size': dist.get_world_size(), 'backend': dist.get_backend()}
 
     torch.manual_seed(6)
     st = synthetic_settings(args.trainer, 'DSEC_events', (args.height, args.width), args.classes, args.batch, args.T, args.C,
@@ -584,17 +657,43 @@ def main():
             D.force_dp(True)
 
     in_step = None
-    if rank == 0 and world == 1 and args.compute == 'bf16' and not args.no_roofline:
+    if rank == 0 and world == 1 and args.compute in ('bf16', 'mixed') and not args.no_roofline:
         try:
             in_step = in_step_conv_rate(trainer, batch)
         except Exception as e:  # (the launch-set loops below still report)
             in_step = {'error': f'{type(e).__name__}: {e}'}
 
     extra = {}
-    if world == 1 and args.compute == 'bf16' and not args.no_fp32_extra:
+    if world == 1 and args.compute == 'mixed' and not args.no_fp32_extra:
+        # the bf16 configuration (BASELINE config 3's dtype, the headline of rounds 1-5) next to the mixed one: the SAME step, captured
+        # the same way, same box, same run
+        try:
+            del trainer
+            torch.cuda.empty_cache()
+            hip.set_compute('bf16')
+            torch.manual_seed(6)
+            trb = ESSModel(st) if args.trainer == 'ess' else ESSSupervisedModel(st)
+            if not args.no_graph:
+                trb.enable_step_graph(batch, warmup=2)
+            for _ in range(2):
+                trb.train_step(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                trb.train_step(batch)
+            torch.cuda.synchronize()
+            msb = (time.perf_counter() - t1) / args.steps * 1e3
+            extra['bf16_ms_per_step'] = round(msb, 3)
+            extra['bf16_voxel_grids_per_s'] = round(args.batch * args.T / msb * 1e3, 2)
+            del trb
+        except Exception as e:  # noqa: BLE001
+            extra['bf16_error'] = f'{type(e).__name__}: {e}'
+        trainer = None
+        torch.cuda.empty_cache()
+    if world == 1 and args.compute in ('bf16', 'mixed') and not args.no_fp32_extra:
         # the parity-grade configuration next to the headline one: the SAME step in exact-fp32 arithmetic (fp32 MFMA, fp32 NCHW
         # tensors; logits within 1e-3 / argmax-exact / mIoU within 1e-4 of the oracle: tests/test_hip_modules.py), 1 warm-up + 3 steps
-        del trainer
+        trainer = None
         torch.cuda.empty_cache()
         hip.set_compute('fp32')
         torch.manual_seed(6)
@@ -666,15 +765,19 @@ def main():
             'metric': 'UDA train-step throughput (voxel grids/s = N*B*T/step_time)' if args.trainer == 'ess'
             else 'supervised train-step throughput (voxel grids/s)',
             'value': round(grids, 2), 'unit': 'voxel_grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16 forward / bf16 backward' if args.compute == 'mixed' else ('bf16' if bf16 else 'f32'),
             'data': 'synthetic', 'sequences_per_s': round(world * args.batch * args.steps / elapsed, 3),
             'final_loss': final_loss,
             'config': {'workload': f'ESS {"UDA (DSEC branch)" if args.trainer == "ess" else "supervised"} train step, '
                                    f'{"DSEC" if args.width == 640 else "DDD17" if args.width == 352 else "custom"}-shape B={args.batch}/GPU T={args.T} C={args.C} {args.height}x{args.width} K={args.classes}, '
                                    f'E2VID {args.recurrent}+BN (frozen) + ResNet18-prefix image encoder + SemSegE2VID decoder, 2xRAdam; '
-                                   f'conv contractions {args.compute} MFMA operands, fp32 accumulate; {storage}',
+                                   + ('forward contractions of the frozen recurrent encoder and of the decoder on IEEE-half MFMA operands (v_mfma_f32_32x32x16_f16; [hi | lo] half pairs for the '
+                                      'encoder convolutions feeding the ConvLSTMs, the event latents and the first decoder pre-norm tensor), every backward contraction, the image encoder and the '
+                                      'reconstruction tail on bf16 operands, fp32 accumulate' if args.compute == 'mixed' else f'conv contractions {args.compute} MFMA operands, fp32 accumulate')
+                                   + f'; {storage}',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world}', 'ranks': world, 'step_issue': graph_note,
-                       'collective_backend': (dist.get_backend() if dp else None)},
+                       'collective_backend': (dist.get_backend() if dp else None), 'rccl_ranks': rccl_ranks},
             # whole step against the matrix-core peak: FLOPs of the launches the step issues (executed_flops_per_step) / step time
             'step': {'flops_per_gpu': step_flops, 'tflops_per_gpu': round(step_flops / ms / 1e9, 1),
                      'step_frac': round(step_flops / ms / 1e9 / peak, 4)},
@@ -694,7 +797,7 @@ def main():
             result['extra'] = extra
         if not args.no_roofline:
             result['roofline'] = roofline_blocks(args, device)
-            if args.compute == 'bf16':
+            if args.compute in ('bf16', 'mixed'):
                 pc = part_mfma_ceiling()
                 result['roofline']['part_ceiling'] = pc
                 if pc and 'registers_only' in pc:
@@ -705,6 +808,10 @@ def main():
                     in_step['frac'] = round(in_step['achieved'] / peak, 4)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args)
+        # LAST key of the line (the driver keeps its tail): which arithmetic the headline belongs to and what it was checked against
+        result['parity'] = {'compute': args.compute, 'ms_per_step': round(ms, 3), 'bf16_ms_per_step': extra.get('bf16_ms_per_step'),
+                            'bf16x3_ms_per_step': extra.get('bf16x3_ms_per_step'), 'fp32_ms_per_step': extra.get('fp32_ms_per_step'),
+                            'vs_fp32_oracle': PARITY_NOTE.get(args.compute)}
         print(json.dumps(result), flush=True)
     if dp:
         dist.barrier()

@@ -121,10 +121,16 @@ def _check_eval(mod, norm):
                                   'training/ess_trainer.py:54); call .eval() on the encoder')
 
 
+_S2D_MODE = os.environ.get('ESS_CONV5_S2D', '1')[:1]  # (read once: 0 = never, 1 = where faster, 2 = wherever the form exists)
+
+
 def _s2d_spec(N, k, stride, pad, cin, cout, H, W, act):
     """The ESS_SRC_S2D spec of a 5x5 / stride-2 / pad-2 convolution where that form exists AND is the faster one for this launch
-    (hip.s2d_preferred: it needs a launch that fills the chip), else None.  Switch ESS_CONV5_S2D: 0 = never, 2 = wherever it exists."""
-    mode = os.environ.get('ESS_CONV5_S2D', '1')[:1]
+    (hip.s2d_preferred: it needs a launch that fills the chip), else None.  Switch ESS_CONV5_S2D: 0 = never, 2 = wherever it exists.
+    The two forms add the same products in different orders: the choice depends on the batch size and on the device's compute-unit
+    count, so the encoder's output for one sample may differ in the last bf16 bit between a B >= 4 training batch and a B < 4
+    validation / streaming call (include/ess_hip.h, ess_conv2d_s2d_preferred); ESS_CONV5_S2D=0 / 2 pins one form."""
+    mode = _S2D_MODE
     if (k, stride, pad) != (5, 2, 2) or cin % 32 or cout % 64 or H % 2 or W % 2 or mode == '0':
         return None
     s2 = hip.conv_spec(N, H // 2, W // 2, 4 * cin, 0, cout, 3, 1, 1, mode0=hip.SRC_S2D, act=act)
@@ -276,7 +282,7 @@ def _convlayer_forward_mixed(self, x, hilo_out=False, want_fp32=False):
     out_fmt = hip.FMT_F16_C8_HILO if hilo_out else hip.FMT_F16_C8
     h16 = hip.f16_blocks_empty(N, c.out_channels, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, x.device, hilo=hilo_out)
     s2 = None
-    if (k, s, p) == (5, 2, 2) and Ce % 32 == 0 and c.out_channels % 64 == 0 and not (H % 2 or W % 2) and os.environ.get('ESS_CONV5_S2D', '1')[:1] != '0':
+    if (k, s, p) == (5, 2, 2) and Ce % 32 == 0 and c.out_channels % 64 == 0 and not (H % 2 or W % 2) and _S2D_MODE != '0':
         s2 = hip.conv_spec(N, H // 2, W // 2, 4 * Ce, 0, c.out_channels, 3, 1, 1, mode0=hip.SRC_S2D, act=act, compute=hip.COMPUTE_F16)
         if not hip.s2d_preferred(s2):
             s2 = None

@@ -73,6 +73,16 @@ def flush_deferred_wgrads(close=True):
     pend.clear()
 
 
+def discard_deferred_wgrads():
+    """Close the window WITHOUT launching what is stashed (an exception unwound the step between begin_deferred_wgrads and the flush:
+    the step's other gradients are incomplete anyway; what must not happen is that the stash -- and the activations it keeps alive --
+    survives into the next step, or that the next step's first pass finds WGRAD_STASHING still set)."""
+    global WGRAD_DEFER, WGRAD_STASHING
+    if WGRAD_DEFER:
+        WGRAD_DEFER.clear()
+    WGRAD_DEFER, WGRAD_STASHING = None, False
+
+
 # Set by training.distributed.GradAllReducer.arm(): called with a parameter as soon as the launch that completes its gradient
 # in the running backward pass has been issued (bucketed gradient all-reduce overlapped with the rest of the backward).
 GRAD_READY_HOOK = None
@@ -307,6 +317,9 @@ def as_c8(x):
     c8 = getattr(x, 'ess_c8', None)
     if c8 is not None and c8[1] == x._version and not x.requires_grad:
         return c8[0]
+    if getattr(x, 'ess_fp32_unwritten', False):
+        raise hip.EssHipError('as_c8: the tensor was produced as a staging copy only and the copy is gone (modified / detached without '
+                              'detach_keep_c8): its fp32 values were never written')
     return ToC8Fn.apply(x)
 
 
@@ -753,4 +766,7 @@ def l1_loss(a, b, weight=1.0):
         raise hip.EssHipError('l1_loss: the second argument must not require grad')
     if hip.is_c8(a) != hip.is_c8(b):  # one side already lives in the bf16 configuration's stored form: compare there
         a, b = as_c8(a), as_c8(b)
+    for t in (a, b):  # (a lean latent whose fp32 values were never written must have gone through as_c8 above)
+        if getattr(t, 'ess_fp32_unwritten', False):
+            raise hip.EssHipError('l1_loss: the tensor exists as a staging copy only (lean recurrent state); its fp32 values were never written')
     return L1Fn.apply(a.contiguous(), b.contiguous(), weight)

@@ -32,12 +32,19 @@ def init_for_device(device, backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     extra = {}
-    if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:  # no launcher: a one-rank group (ESS_DP_FORCE on a single-GPU box)
-        import socket
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        extra = {'rank': 0, 'world_size': 1, 'init_method': f'tcp://127.0.0.1:{port}'}
+    if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
+        # no launcher environment.  ONLY under ESS_DP_FORCE / force_dp (a single-GPU box executing the RCCL side on purpose) does this
+        # become a one-rank group; a launcher that set half of the variables (LOCAL_RANK alone, say) must fail loudly -- N processes that
+        # each train as an independent one-rank group average nothing and report no error
+        if not _FORCE:
+            raise RuntimeError('init_for_device: RANK / WORLD_SIZE are not set (launch through torch.distributed.run, or set ESS_DP_FORCE=1 '
+                               'for a one-rank group on a single-GPU box)')
+        import tempfile
+        # file:// rendezvous: no port to probe (a bind-then-close probe races with every other process on the host)
+        fd, path = tempfile.mkstemp(prefix='ess_dp1_')
+        os.close(fd)
+        os.unlink(path)  # (the store creates it)
+        extra = {'rank': 0, 'world_size': 1, 'init_method': f'file://{path}'}
     if backend is None:
         backend = os.environ.get('ESS_DIST_BACKEND', 'nccl')
     if backend == 'nccl':

@@ -122,6 +122,13 @@ class ESSModel(base_trainer.BaseTrainer):
         return self._train_step_eager(input_batch)
 
     def _train_step_eager(self, input_batch, optimise=True, defer_task_backward=False):
+        try:
+            return self._train_step_body(input_batch, optimise, defer_task_backward)
+        except BaseException:
+            Fn.discard_deferred_wgrads()  # (the deferred weight-gradient window must not outlive a failed step)
+            raise
+
+    def _train_step_body(self, input_batch, optimise=True, defer_task_backward=False):
         """optimise=False (recording the data-parallel step: BaseTrainer.enable_step_graph): stop behind the backward passes.
         defer_task_backward (with optimise=False): stop behind the backward of the image-encoder terms -- the image encoder's
         gradients are complete -- and leave the decoder's task backward to `_finish_deferred_backward()`, which the captured
@@ -225,7 +232,7 @@ class ESSModel(base_trainer.BaseTrainer):
     def trainTaskStep(self, sensor_name, latent_fake, labels, losses, pred=None):
         if pred is None:
             if self.settings.dataset_name_b == 'DSEC_events':
-                latent_fake = {k: v.detach() for k, v in latent_fake.items()}
+                latent_fake = {k: Fn.detach_keep_c8(v) for k, v in latent_fake.items()}  # (keeps staging copies / the unwritten-fp32 mark)
             pred = self.models_dict['back_end'](latent_fake)
         loss_pred = self.task_loss(pred[1], labels, weight=self.settings.weight_task_loss)  # weight folded into the kernel
         losses['semseg_' + sensor_name + '_loss'] = loss_pred.detach()

@@ -160,7 +160,9 @@ int ess_conv2d_plan(const EssConvDesc* d, EssConvPlan* plan);
 /* 1 when `d` is a valid ESS_SRC_S2D descriptor AND the space-to-depth form is the faster way to run that 5x5 / stride-2 convolution
  * on this device (its one-workgroup-per-CU tiles need a launch of at least 3/4 of the compute units' worth of tiles: B >= 4 at the
  * DSEC shape; below that the tap-paired 5x5 kernel wins), else 0.  The caller picks the descriptor (and the weight pack) by it:
- * ConvLayer.forward of the frozen encoder, e2vid/model/submodules.py:7-31,176-186.                                          */
+ * ConvLayer.forward of the frozen encoder, e2vid/model/submodules.py:7-31,176-186.  NOTE: the two forms add the same products in
+ * different orders, so a caller that follows this answer gets results that depend on N and on the device's compute-unit count in
+ * the last bf16 / half bit (training batch vs a B < 4 validation or streaming call); pin one form per model where that matters.  */
 int ess_conv2d_s2d_preferred(const EssConvDesc* d);
 
 /* Re-layout a weight tensor for ess_conv2d_forward (tile-major, epilogue row permutation applied).

@@ -474,13 +474,19 @@ def test_rccl_process_group_construction_mocked(monkeypatch):
     monkeypatch.delenv('MASTER_ADDR', raising=False)
     monkeypatch.setattr(dist, 'init_process_group', lambda **kw: calls.update(init=kw))
     dev = torch.device('cuda', 3)
-    # without a launcher (no RANK / WORLD_SIZE): a one-rank group on a private tcp:// rendezvous (ESS_DP_FORCE on a single-GPU box)
+    # without a launcher (no RANK / WORLD_SIZE): refused -- a half-configured launcher must not turn into N independent one-rank groups --
+    # unless ESS_DP_FORCE / force_dp asks for the one-rank group (single-GPU box), which rendezvouses through a private file:// store
     monkeypatch.delenv('RANK', raising=False)
     monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(D, '_FORCE', False)
+    with pytest.raises(RuntimeError, match='RANK / WORLD_SIZE'):
+        D.init_for_device(dev)
+    monkeypatch.setattr(D, '_FORCE', True)
     assert D.init_for_device(dev) == 'nccl'
     one = calls['init']
     assert one['backend'] == 'nccl' and one['device_id'] == dev and one['rank'] == 0 and one['world_size'] == 1
-    assert one['init_method'].startswith('tcp://127.0.0.1:')
+    assert one['init_method'].startswith('file://')
+    monkeypatch.setattr(D, '_FORCE', False)
     monkeypatch.setenv('RANK', '3')
     monkeypatch.setenv('WORLD_SIZE', '8')
     assert D.init_for_device(dev) == 'nccl'
@@ -536,3 +542,99 @@ def test_forced_dp_one_rank_gloo(monkeypatch):
     finally:
         D.force_dp(False)
         dist.destroy_process_group()
+
+
+def _dp8_worker(rank, world, port, ret):
+    """One of EIGHT ranks (BASELINE config 4's world size) over gloo on CPU: (1) GradAllReducer.arm over the REAL decoder's parameter
+    list (models/style_networks.py SemSegE2VID: 37 conv weights + biases) -- bucket boundaries never separate a weight from its bias,
+    the buckets tile the flat buffer exactly, the averaged gradient equals the mean over the ranks; (2) reduce_validation_sums with an
+    EMPTY shard on one rank and a key only some ranks report; (3) broadcast_module from rank 0 with differing initial weights."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from ess_amd import functional as Fn
+    from ess_amd.models.style_networks import SemSegE2VID
+    from ess_amd.training import distributed as D
+    torch.manual_seed(100 + rank)
+    dec = SemSegE2VID(256, 11, skip_connect=True, skip_type='concat')
+    w0 = next(dec.parameters()).detach().clone()
+    D.broadcast_module(dec, 0)
+    wb = next(dec.parameters()).detach().clone()
+    params = [p for p in dec.parameters() if p.requires_grad]
+    sizes = [p.numel() for p in params]
+    total = sum(sizes)
+    flat = torch.empty(total)
+    off = 0
+    for i, k in enumerate(sizes):  # rank r's "gradient" of parameter i: the constant (r + 1) * (i + 1)
+        flat[off:off + k] = float((rank + 1) * (i + 1))
+        off += k
+    opt = SimpleNamespace(param_groups=[{'params': params}], flat_grad=flat)
+    red = D.GradAllReducer()
+    red.arm(opt, n_buckets=3)
+    bk = red._armed['buckets']
+    tiles = [(b['lo'], b['hi']) for b in bk]
+    ok_tiling = tiles[0][0] == 0 and tiles[-1][1] == total and all(tiles[i][1] == tiles[i + 1][0] for i in range(len(tiles) - 1))
+    # a boundary may only sit in front of a conv weight (4-D): never between a weight and its bias
+    starts = {0}
+    o = 0
+    for p, k in zip(params, sizes):
+        if p.dim() == 4:
+            starts.add(o)
+        o += k
+    ok_bounds = all(lo in starts for lo, _ in tiles)
+    fired = []
+    for p in reversed(params):  # backward order; only conv weights report (their launch completes the bias too)
+        if p.dim() == 4:
+            Fn.GRAD_READY_HOOK(p)
+        fired.append(len(red.pending))
+    red.wait()
+    mean_rank = sum(range(1, world + 1)) / world
+    off, err = 0, 0.0
+    for i, k in enumerate(sizes):
+        err = max(err, (flat[off:off + k] - mean_rank * (i + 1)).abs().max().item())
+        off += k
+    # (2) validation sums: rank 3's shard is empty; 'only_some' is reported by the even ranks
+    D.force_dp(False)
+    losses = {}
+    n = 0
+    if rank != 3:
+        losses = {'semseg_sensor_b_loss': torch.tensor(float(rank + 1))}
+        if rank % 2 == 0:
+            losses['only_some'] = torch.tensor(10.0)
+        n = 2
+    tot, n_tot = D.reduce_validation_sums(losses, n)
+    exp_loss = float(sum(r + 1 for r in range(world) if r != 3))
+    exp_some = 10.0 * sum(1 for r in range(world) if r % 2 == 0 and r != 3)
+    ok_val = abs(float(tot['semseg_sensor_b_loss']) - exp_loss) < 1e-6 and abs(float(tot['only_some']) - exp_some) < 1e-6 and n_tot == 2.0 * (world - 1)
+    out = torch.tensor([float(ok_tiling), float(ok_bounds), err, float(ok_val), float((wb - w0).abs().max() > 0 if rank else 1.0),
+                        float(len(bk)), float(max(fired))])
+    gathered = [torch.zeros_like(out) for _ in range(world)]
+    dist.all_gather(gathered, out)
+    wsum = [torch.zeros_like(wb.flatten()[:8]) for _ in range(world)]
+    dist.all_gather(wsum, wb.flatten()[:8].contiguous())
+    if rank == 0:
+        ret.put(([t.tolist() for t in gathered], [t.tolist() for t in wsum]))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world8_gloo_buckets_validation_broadcast():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    world = 8
+    procs = [ctx.Process(target=_dp8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, ws = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r, row in enumerate(res):
+        ok_tiling, ok_bounds, err, ok_val, changed, n_b, max_fired = row
+        assert ok_tiling == 1.0 and ok_bounds == 1.0, (r, row)
+        assert err < 1e-5 and ok_val == 1.0, (r, row)
+        assert changed == 1.0, (r, row)  # every non-zero rank's weights were replaced by rank 0's
+        assert n_b == 3.0 and max_fired == 3.0, (r, row)  # all three buckets were issued from inside the (simulated) backward
+    assert all(w == ws[0] for w in ws)
