@@ -706,12 +706,12 @@ def _rcl_prev_has_c8(self, prev_state):
 RecurrentConvLayer._prev_has_c8 = _rcl_prev_has_c8
 
 
-def _rcl_forward_mixed(self, x, prev_state, lean=False, hilo_out=False):
-    """the mixed configuration's step (see _convlayer_forward_mixed): conv -> [hi | lo] half pair -> ConvLSTM on half operands"""
+def _rcl_forward_mixed(self, x, prev_state, lean=False, hilo_out=False, x_hilo=True):
+    """the mixed configuration's step (see _convlayer_forward_mixed): conv -> half copy ([hi | lo] pair with x_hilo) -> ConvLSTM on half operands"""
     if self.recurrent_block_type != 'convlstm':
         raise NotImplementedError("the 'mixed' configuration covers the ConvLSTM encoder (the recurrent block of the E2VID checkpoint's default); "
                                   "ConvGRU runs in 'bf16' / 'bf16x3' / 'fp32'")
-    xc = self.conv.forward_mixed(x, hilo_out=True)
+    xc = self.conv.forward_mixed(x, hilo_out=x_hilo)
     state = self.recurrent_block.forward_mixed(xc, prev_state, lean, hilo_out)
     return state[0], state
 

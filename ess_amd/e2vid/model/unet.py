@@ -205,6 +205,12 @@ def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean
     states.  lean: the step only advances the state; lean_state: its hidden states need no fp32 form (then the last step's copies of h'
     -- the event latents -- leave as [hi | lo] half pairs)."""
     from .submodules import _c8_of, _attach_c8
+    import os
+    # WHERE the [hi | lo] pairs are used: by default at the DEEPEST level only -- the convolution feeding its ConvLSTM and, on the last
+    # step, its h' (the 1/8-resolution latent).  tools/hybrid_rounding_ablation.py (levels / latents sections): on the trained fixture
+    # that level alone carries the effect (10 flips of 307200 against 13 with pairs at all three levels, 37 with none; latents: 11 with
+    # the 1/8 latent alone, 13 with all, 40 with none); ESS_MIXED_HILO=all puts pairs at every level (+ 0.3 ms per time step at B = 8)
+    hilo_all = os.environ.get('ESS_MIXED_HILO', 'deepest') == 'all'
     final = not lean
     no_fp32 = lean or (lean_state and self.use_upsample_conv and self.norm != 'IN')
     head = self.head.forward_mixed(x, want_fp32=final)
@@ -213,7 +219,8 @@ def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean
     blocks, states = [], []
     x = head
     for i, encoder in enumerate(self.encoders):
-        x, state = encoder.forward_mixed(x, prev_states[i], lean=no_fp32, hilo_out=final)
+        deep = hilo_all or i == self.num_encoders - 1
+        x, state = encoder.forward_mixed(x, prev_states[i], lean=no_fp32, hilo_out=final and deep, x_hilo=deep)
         blocks.append(x)
         states.append(state)
     if lean:

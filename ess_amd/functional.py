@@ -292,7 +292,7 @@ class FromC8Fn(torch.autograd.Function):
         return hip.to_bf16_c8(dy.contiguous()), None
 
 
-def as_c8(x):
+def as_c8(x, want_hilo=False):
     """`x` as a BF16_C8 tensor: itself, the staging copy its producer left next to an fp32 tensor (frozen encoder latents:
     `.ess_c8`, valid while the tensor is unmodified and needs no gradient), or a converted copy (autograd-aware)."""
     if hip.is_c8(x):
@@ -302,17 +302,20 @@ def as_c8(x):
     if hip.mixed() and not x.requires_grad:
         # mixed configuration, an event latent (fp32 NCHW, possibly an unwritten placeholder carrying only its half copy): the
         # BF16_C8 tensor the backward / skip / loss consumers read, with the [hi | lo] half pair the forward convolutions read
-        cached = getattr(x, 'ess_mixed_c8', None)
-        if cached is not None and cached[1] == x._version:
-            return cached[0]
+        # want_hilo: the consumer's operand should be a [hi | lo] pair (the 1/8-resolution latent: channel means far above the spread)
         h = hip.h16_of(x)
-        if h is None:
-            if getattr(x, 'ess_fp32_unwritten', False):
+        want_hilo = bool(want_hilo) or (h is not None and h[1])  # (a producer's [hi | lo] copy serves every consumer)
+        cached = getattr(x, 'ess_mixed_c8', None)
+        if cached is not None and cached[1] == (x._version, want_hilo):
+            return cached[0]
+        unwritten = getattr(x, 'ess_fp32_unwritten', False)
+        if h is None or (want_hilo and not h[1] and not unwritten):
+            if unwritten:
                 raise hip.EssHipError('as_c8(mixed): the tensor has neither fp32 values nor a half copy')
-            h = (hip.to_f16_c8(x.contiguous(), hilo=True), True)
+            h = (hip.to_f16_c8(x.contiguous(), hilo=bool(want_hilo)), bool(want_hilo))
         c8t = hip.f16_c8_to_bf16_c8(h[0], hilo=h[1])
         hip.attach_h16(c8t, h[0], h[1])
-        x.ess_mixed_c8 = (c8t, x._version)
+        x.ess_mixed_c8 = (c8t, (x._version, bool(want_hilo)))
         return c8t
     c8 = getattr(x, 'ess_c8', None)
     if c8 is not None and c8[1] == x._version and not x.requires_grad:

@@ -122,8 +122,8 @@ class SemSegE2VID(nn.Module):
         x = input_dict[8]
         out = {8: x}
         c8 = Fn.c8_mode()
-        lat = (lambda t: Fn.as_c8(t).contiguous()) if c8 else (lambda t: t.contiguous())
-        x = lat(x)
+        lat = (lambda t, deep=False: Fn.as_c8(t, want_hilo=deep).contiguous()) if c8 else (lambda t, deep=False: t.contiguous())
+        x = lat(x, True)  # (mixed configuration: the 1/8 latent enters as a [hi | lo] half pair)
         if self.skip_connect:
             x = self.decoder_scale_1[0](x, first=True)
             for blk in list(self.decoder_scale_1)[1:]:
