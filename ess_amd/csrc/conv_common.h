@@ -538,7 +538,8 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
   const ess_rsrc r_u = u16 ? ess_make_rsrc((const char*)a.aux1 + (size_t)n * nbh * HW * 16, (size_t)nbh * HW * 16)
                            : ess_make_rsrc(a.aux1 + (size_t)n * nbh * 8 * HW, state_b);
   const ess_rsrc r_o = ess_make_rsrc(a.out ? (const char*)(a.out + (size_t)n * nbh * 8 * HW) : (const char*)a.aux1, a.out ? state_b : 0);
-  const ess_rsrc r_ob = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * nbh * HW * 16 : (const char*)a.aux1, a.out_bf ? (size_t)nbh * HW * 16 : 0);
+  const int ncp = (H && a.hilo) ? 2 : 1;  // (uniform) [hi | lo] copy of h': 2 nbh blocks per sample (ESS_GRU_H_HILO)
+  const ess_rsrc r_ob = ess_make_rsrc(a.out_bf ? (const char*)a.out_bf + (size_t)n * ncp * nbh * HW * 16 : (const char*)a.aux1, a.out_bf ? (size_t)ncp * nbh * HW * 16 : 0);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -580,7 +581,7 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
           uv[j][2] = __builtin_bit_cast(unsigned, (float)hi[0]); uv[j][3] = __builtin_bit_cast(unsigned, (float)hi[1]);
         }
       }
-      uint2 pk[4];
+      uint2 pk[4], pl[H ? 4 : 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         u32x4c ov;
@@ -595,6 +596,7 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
         }
         if (a.out) __builtin_amdgcn_raw_buffer_store_b128(ov, r_o, (int)vo[j], 0, ESS_GRU_AUX);  // (uniform)
         pk[j] = ess_cvt4<H>(of[0], of[1], of[2], of[3]);
+        if constexpr (H) pl[j] = ess_cvt4_lo(of[0], of[1], of[2], of[3]);
       }
       if (a.out_bf) {  // (uniform)
 #pragma unroll
@@ -604,6 +606,14 @@ __device__ __forceinline__ void conv_epilogue_gru_out_c8(const ConvKArgs& a, f32
           const u32x4c vec = {s0[0], s1[0], s0[1], s1[1]};
           const unsigned o = pixi[nb] >= 0 ? ((unsigned)((ct * MB + mb) * 4 + j + half) * HW + (unsigned)pixi[nb]) * 16u : ESS_OOB;
           __builtin_amdgcn_raw_buffer_store_b128(vec, r_ob, (int)o, 0, ESS_GRU_AUX);
+          if constexpr (H) {
+            if (ncp == 2) {  // (uniform) the lo parts, nbh blocks further on
+              const auto t0 = __builtin_amdgcn_permlane32_swap(pl[j].x, pl[j + 1].x, false, false);
+              const auto t1 = __builtin_amdgcn_permlane32_swap(pl[j].y, pl[j + 1].y, false, false);
+              const u32x4c vlo = {t0[0], t1[0], t0[1], t1[1]};
+              __builtin_amdgcn_raw_buffer_store_b128(vlo, r_ob, (int)(o == ESS_OOB ? ESS_OOB : o + (unsigned)nbh * HW * 16u), 0, ESS_GRU_AUX);
+            }
+          }
         }
       }
     }
@@ -1360,6 +1370,9 @@ inline ResolvedDesc resolve_compute(const EssConvDesc* d) {
     } else if (d->epilogue == ESS_EPI_LSTM) {
       r.hilo = d->act == ESS_LSTM_H_HILO;
       r.d.act = ESS_ACT_NONE;
+    } else if (d->epilogue == ESS_EPI_GRU_OUT) {
+      r.hilo = (d->act & ESS_GRU_H_HILO) != 0;
+      r.d.act = d->act & ~ESS_GRU_H_HILO;
     }
     return r;
   }
@@ -1499,6 +1512,7 @@ inline int validate(const EssConvDesc* d) {
       ESS_CHECK_ARG(d->out_split == 0 && (d->act == ESS_ACT_NONE || d->act == ESS_ACT_RELU) && (d->C_out % 64) == 0,
                     "conv(f16): a [hi | lo] output needs act in {none, relu}, no out_split, C_out %% 64 == 0");
     if (d->epilogue == ESS_EPI_LSTM) ESS_CHECK_ARG(d->act == 0 || d->act == ESS_LSTM_H_HILO, "conv(f16, LSTM): act is 0 or ESS_LSTM_H_HILO");
+    if (d->epilogue == ESS_EPI_GRU_UR) ESS_CHECK_ARG(d->act == ESS_GRU_U_F32 || d->act == ESS_GRU_U_F16, "conv(f16, GRU_UR): act is ESS_GRU_U_F32 or ESS_GRU_U_F16");
     const ResolvedDesc r = resolve_compute(d);
     return validate(&r.d);
   }

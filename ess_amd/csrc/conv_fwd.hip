@@ -296,6 +296,9 @@ extern "C" int ess_conv2d_forward(const EssConvDesc* d, const void* src0, const 
   a.hilo = rd.hilo ? 1 : 0;
   if (rd.hilo && d->epilogue == ESS_EPI_LINEAR)
     ESS_CHECK_ARG(!residual && (d->C_out % pl.cout_tile) == 0 && d->fmt_out == ESS_FMT_BF16_C8, "conv(f16): a [hi | lo] output takes no residual and whole channel tiles");
+  if (rd.hilo && d->epilogue == ESS_EPI_GRU_OUT)
+    ESS_CHECK_ARG(out_bf16 && shift && d->fmt_res == ESS_FMT_F32_C8 && aux1 && (!out || d->fmt_out == ESS_FMT_F32_C8) && (d->hidden % pl.cout_tile) == 0,
+                  "conv(f16, GRU_OUT): a [hi | lo] copy of h' exists in the straight-line form only (channel-blocked states, whole tiles of hidden channels)");
   if (rd.hilo && d->epilogue == ESS_EPI_LSTM)
     ESS_CHECK_ARG(out_bf16 && shift && d->fmt_out == ESS_FMT_F32_C8 && (!aux0 || d->fmt_res == ESS_FMT_F32_C8) && (d->hidden % (8 * (pl.cout_tile / 32))) == 0 && pl.cout_tile >= 64,
                   "conv(f16, LSTM): a [hi | lo] copy of h' exists in the lean form only (channel-blocked cell states, whole hidden blocks per tile)");

@@ -343,6 +343,63 @@ def _convlstm_forward_mixed(self, input_, prev_state, lean, hilo_out):
     return hidden, cell
 
 
+def _convgru_forward_mixed(self, input_, prev_state, lean, hilo_out):
+    """ConvGRU step on half operands (the two fused launches of ConvGRU.forward): x from its half copy (a [hi | lo] pair at the deepest
+    level: repeated weight columns in both launches), h and r*h as half copies, the fp32 recurrence h' = h (1 - u) + o u on channel-
+    blocked fp32 states between lean steps, u between the launches as IEEE half.  hilo_out (lean only): the copy of h' as a [hi | lo] pair."""
+    _inference_only(input_)
+    N, C, H, W = input_.shape
+    hid = self.hidden_size
+    dev = input_.device
+    first = prev_state is None
+    xs, xhl = _half_source(input_)
+    Cx = C * (2 if xhl else 1)
+    C1 = 0 if first else hid
+    cols = [(0, C)] * (2 if xhl else 1) + ([] if first else [(C, C + hid)])
+    plain = cols == [(0, C), (C, C + hid)]
+    ws = []
+    for nm, g in (('u', self.update_gate), ('r', self.reset_gate), ('o', self.out_gate)):
+        ws.append(g.weight if plain else _dup_weight((id(self), nm, xhl, first), g.weight, cols))
+    wu, wr, wo = ws
+    hs = None if first else _half_source(prev_state)[0]
+    if not first and _half_source(prev_state)[1]:
+        raise hip.EssHipError('ConvGRU(mixed): a [hi | lo] hidden state feeds the decoder, not the next time step')
+    hb = None if first else getattr(prev_state, 'ess_f32c8', None)
+    blocked = first or hb is not None
+    afmt = hip.FMT_F32_C8 if blocked else hip.FMT_F32_NCHW
+    h32 = hb if blocked else _fp32(prev_state)
+    uact = hip.GRU_U_F16
+    s1 = hip.conv_spec(N, H, W, Cx, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=uact, hidden=hid, compute=hip.COMPUTE_F16)
+    if hid % (s1.plan.cout_tile // 2):
+        uact = hip.GRU_U_F32
+        s1 = hip.conv_spec(N, H, W, Cx, C1, 2 * hid, 3, 1, 1, epi=hip.EPI_GRU_UR, act=uact, hidden=hid, compute=hip.COMPUTE_F16)
+    hilo = bool(hilo_out and lean and blocked)
+    s2 = hip.conv_spec(N, H, W, Cx, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=uact | (hip.GRU_H_HILO if hilo else 0), hidden=hid, compute=hip.COMPUTE_F16)
+    if hilo and hid % s2.plan.cout_tile:
+        hilo = False
+        s2 = hip.conv_spec(N, H, W, Cx, C1, hid, 3, 1, 1, epi=hip.EPI_GRU_OUT, act=uact, hidden=hid, compute=hip.COMPUTE_F16)
+    b1, b2 = self._biases(s1, s2)
+    pw1, pw2 = packed_weight(s1, wu, wr), packed_weight(s2, wo)
+    if afmt == hip.FMT_F32_C8:
+        u = hip.f16_c8_raw_empty(N, hid, H, W, dev) if uact == hip.GRU_U_F16 else hip.f32_c8_empty(N, hid, H, W, dev)
+    else:
+        u = torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+    rh16 = None if first else hip.f16_blocks_empty(N, hid, H, W, dev)
+    hip.conv_forward_h16(s1, xs, hs, pw1, None, b1, aux0=h32, out=u, out2=None, out_h16=rh16, out_fmt=afmt, aux_fmt=afmt)
+    new16 = hip.f16_blocks_empty(N, hid, H, W, dev, hilo=hilo)
+    if lean and blocked:
+        nb = hip.f32_c8_empty(N, hid, H, W, dev)
+        hip.conv_forward_h16(s2, xs, rh16, pw2, None, b2, aux0=h32, aux1=u, out=nb, out_h16=new16, out_fmt=hip.FMT_F32_C8, aux_fmt=afmt)
+        new_state = _c8_placeholder(N, hid, H, W, dev, None)
+        del new_state.ess_c8
+        new_state.ess_f32c8 = nb
+    else:
+        new_state = torch.empty(N, hid, H, W, dtype=torch.float32, device=dev)
+        hip.conv_forward_h16(s2, xs, rh16, pw2, None, b2, aux0=h32, aux1=u, out=new_state, out_h16=new16, out_fmt=hip.FMT_F32_NCHW, aux_fmt=afmt)
+    hip.attach_h16(new_state, new16, hilo)
+    return new_state
+
+
 class TransposedConvLayer(nn.Module):
     """ConvTranspose2d(k, stride 2, output_padding 1) (+norm) (+activation): the zero-insertion is done
     while staging the LDS tile.  Reference: submodules.py:34-62."""
@@ -708,12 +765,9 @@ RecurrentConvLayer._prev_has_c8 = _rcl_prev_has_c8
 
 def _rcl_forward_mixed(self, x, prev_state, lean=False, hilo_out=False, x_hilo=True):
     """the mixed configuration's step (see _convlayer_forward_mixed): conv -> half copy ([hi | lo] pair with x_hilo) -> ConvLSTM on half operands"""
-    if self.recurrent_block_type != 'convlstm':
-        raise NotImplementedError("the 'mixed' configuration covers the ConvLSTM encoder (the recurrent block of the E2VID checkpoint's default); "
-                                  "ConvGRU runs in 'bf16' / 'bf16x3' / 'fp32'")
     xc = self.conv.forward_mixed(x, hilo_out=x_hilo)
     state = self.recurrent_block.forward_mixed(xc, prev_state, lean, hilo_out)
-    return state[0], state
+    return (state[0] if self.recurrent_block_type == 'convlstm' else state), state
 
 
 RecurrentConvLayer.forward_mixed = _rcl_forward_mixed
@@ -785,3 +839,4 @@ class ResidualBlock(nn.Module):
 
 
 ConvLayer.forward_mixed = _convlayer_forward_mixed
+ConvGRU.forward_mixed = _convgru_forward_mixed

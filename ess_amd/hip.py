@@ -22,6 +22,7 @@ GRU_U_F32, GRU_U_F16 = 0, 1
 COMPUTE_FP32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_F16 = 0, 1, 2, 3
 FMT_F32_NCHW, FMT_BF16_C8, FMT_F32_C8, FMT_F16_C8, FMT_F16_C8_HILO = 0, 1, 2, 3, 4
 LSTM_H_HILO = 1
+GRU_H_HILO = 2
 
 _default_compute = COMPUTE_FP32
 _mixed = False
@@ -871,7 +872,7 @@ def conv_forward_h16(spec, src0, src1, packed_w, scale=None, shift=None, residua
     odt = torch.float16 if half_out else torch.float32
     res_fmt = aux_fmt if aux_fmt != FMT_F32_NCHW else ((FMT_F16_C8 if half_out else out_fmt) if residual is not None else FMT_F32_NCHW)
     desc = spec.desc_fmt(sfmt, out_fmt, res_fmt)
-    u16 = spec.desc.act == GRU_U_F16 and spec.desc.epilogue in (EPI_GRU_UR, EPI_GRU_OUT)
+    u16 = (spec.desc.act & 1) == GRU_U_F16 and spec.desc.epilogue in (EPI_GRU_UR, EPI_GRU_OUT)
     udt_out = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_UR and out_fmt == FMT_F32_C8) else odt
     udt_aux = torch.float16 if (u16 and spec.desc.epilogue == EPI_GRU_OUT and res_fmt == FMT_F32_C8) else torch.float32
     _check(lib().ess_conv2d_forward(byref(desc), ptr(src0, sdt), ptr(src1, sdt), ptr(packed_w, torch.uint8), ptr(scale), ptr(shift),

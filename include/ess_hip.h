@@ -92,6 +92,9 @@ enum { ESS_GRU_U_F32 = 0, ESS_GRU_U_F16 = 1 };
  * [hi | lo] pair, [N][2 hid/8][H][W][8] (see ESS_FMT_F16_C8_HILO) -- the event latents the semantic decoder reads.  Lean form only
  * (channel-blocked cell states, hidden % 16 == 0).                                                                       */
 enum { ESS_LSTM_H_HILO = 1 };
+/* ... and the ConvGRU candidate launch (ESS_EPI_GRU_OUT, ESS_COMPUTE_F16): OR'ed into act next to ESS_GRU_U_*; straight-line form only
+ * (channel-blocked states, hidden % 64 == 0).                                                                                     */
+enum { ESS_GRU_H_HILO = 2 };
 /* weight sources for ess_conv2d_pack_weights */
 enum {
   ESS_W_CONV = 0,        /* nn.Conv2d weight [C_out][C_in][k][k]                                     */

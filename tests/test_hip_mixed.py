@@ -225,3 +225,47 @@ def test_instance_norm_mixed(H, case):
     got = H.from_bf16_c8(dx, C).cpu().double()
     scale = xr.grad.abs().max().item()
     assert (got - xr.grad).abs().max().item() < 2e-2 * scale
+
+
+@pytest.mark.parametrize('rec_type', ['convlstm', 'convgru'])
+def test_mixed_sequence_latents_vs_oracle(H, rec_type):
+    """T recurrent steps of the frozen encoder in the mixed configuration (half operands, [hi | lo] pairs at the deepest level) against
+    the fp32 oracle: latents within 1e-3 (the bf16 configuration: ~3e-3), both through the lean sequence call (the trainers' path: the
+    1/8 latent arrives as a [hi | lo] half pair) and through per-slice calls that keep fp32 states.  Reference training/ess_trainer.py:268-301."""
+    from oracle import ess_oracle as O
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.model.model import E2VIDRecurrent
+    from ess_amd.e2vid.options.inference_options import default_options
+    from ess_amd import functional as Fn
+    B, T, C, Hh, W = 2, 4, 2, 96, 128
+    cfg = O.e2vid_config(num_bins=C, recurrent_block_type=rec_type)
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 77)
+    ev, _, _, _ = O.synth_batch(B, T, C, Hh, W, 11, seed=5)
+    ref_img, _, ref_lat = O.reconstruct_sequence(sd_e, cfg, ev, T)
+    H.set_compute('mixed')
+    try:
+        model = E2VIDRecurrent(dict(cfg))
+        model.load_state_dict(sd_e)
+        model = model.cuda().eval()
+        rec = ImageReconstructor(model, Hh, W, C, torch.device('cuda:0'), default_options())
+        rec.last_states_for_each_channel = {'grayscale': None}
+        with torch.no_grad():
+            img, _, lat = rec.update_reconstruction_sequence(ev.cuda(), T, need_image=True, final_lean=True)
+            # the latents as the decoder takes them: BF16_C8 tensors carrying half copies; the 1/8 latent as a [hi | lo] pair
+            l8 = Fn.as_c8(lat[8], want_hilo=True)
+            h8 = H.h16_of(l8)
+            assert h8 is not None and h8[1], 'the 1/8 latent must arrive as a [hi | lo] half pair'
+            e8 = (unblock_hilo(h8[0], 256).float() - ref_lat[8]).abs().max().item()
+            l4 = Fn.as_c8(lat[4])
+            h4 = H.h16_of(l4)
+            e4 = (unblock(h4[0], 128) - ref_lat[4]).abs().max().item()
+        e_img = (img.cpu() - ref_img).abs().max().item()
+        rec.last_states_for_each_channel = {'grayscale': None}
+        with torch.no_grad():
+            for t in range(T):
+                img2, _, lat2 = rec.update_reconstruction(ev.cuda()[:, t * C:(t + 1) * C], need_image=t == T - 1)
+        e8b = (lat2[8].cpu() - ref_lat[8]).abs().max().item()
+        print(f'mixed {rec_type}: 1/8 latent {e8:.2e} (lean, [hi | lo]) / {e8b:.2e} (fp32 states), 1/4 latent {e4:.2e}, img_fake {e_img:.2e}')
+        assert e8 < 1e-3 and e8b < 1e-3 and e4 < 1.5e-3 and e_img < 3e-2, (e8, e8b, e4, e_img)
+    finally:
+        H.set_compute('fp32')
