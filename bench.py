@@ -812,10 +812,17 @@ def main():
         result['parity'] = {'compute': args.compute, 'ms_per_step': round(ms, 3), 'bf16_ms_per_step': extra.get('bf16_ms_per_step'),
                             'bf16x3_ms_per_step': extra.get('bf16x3_ms_per_step'), 'fp32_ms_per_step': extra.get('fp32_ms_per_step'),
                             'vs_fp32_oracle': PARITY_NOTE.get(args.compute)}
-        print(json.dumps(result), flush=True)
     if dp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing this process writes: RCCL prints a version banner through C stdio (flushed at exit, i.e. behind
+        # anything Python printed earlier) -- push it out first
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(result), flush=True)
     return result
 
 

@@ -309,11 +309,16 @@ def as_c8(x, want_hilo=False):
         if cached is not None and cached[1] == (x._version, want_hilo):
             return cached[0]
         unwritten = getattr(x, 'ess_fp32_unwritten', False)
-        if h is None or (want_hilo and not h[1] and not unwritten):
+        fresh = h is None or (want_hilo and not h[1] and not unwritten)
+        if fresh:
             if unwritten:
                 raise hip.EssHipError('as_c8(mixed): the tensor has neither fp32 values nor a half copy')
             h = (hip.to_f16_c8(x.contiguous(), hilo=bool(want_hilo)), bool(want_hilo))
-        c8t = hip.f16_c8_to_bf16_c8(h[0], hilo=h[1])
+        c8 = getattr(x, 'ess_c8', None)
+        if c8 is not None and c8[1] == x._version and not fresh:
+            c8t = c8[0]  # (the BF16_C8 copy the encoder's reconstruction tail already made of this very half copy: no second conversion)
+        else:
+            c8t = hip.f16_c8_to_bf16_c8(h[0], hilo=h[1])
         hip.attach_h16(c8t, h[0], h[1])
         x.ess_mixed_c8 = (c8t, (x._version, bool(want_hilo)))
         return c8t

@@ -34,7 +34,7 @@ def _batch(kind, shape, seed):
     return [[img.cuda(), lab_a.cuda()], [ev.cuda(), lab_b.cuda()]] if kind == 'ess' else [ev.cuda(), lab_b.cuda()]
 
 
-@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16')])
+@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16'), ('ess', 'mixed'), ('ess_supervised', 'mixed')])
 def test_captured_step_is_bit_identical_to_eager(kind, mode):
     from ess_amd import hip
     shape = (2, 3, 2, 96, 128, 11)
@@ -152,7 +152,7 @@ def test_captured_step_host_issue_time():
         hip.set_compute('fp32')
 
 
-@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16')])
+@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16'), ('ess', 'mixed'), ('ess_supervised', 'mixed')])
 def test_data_parallel_captured_step_matches_eager(kind, mode):
     """Two ranks (sharing this box's GPU, gloo): the data-parallel step as [hipGraph | flat-gradient all-reduce | hipGraph] against
     the eager data-parallel step (bucketed reduces from inside the backward): first-step averaged gradients and weights bit for bit
@@ -206,7 +206,7 @@ def _run_rccl_worker(args, timeout):
     return lines
 
 
-@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16')])
+@pytest.mark.parametrize('kind,mode', [('ess', 'bf16'), ('ess', 'fp32'), ('ess_supervised', 'bf16'), ('ess', 'mixed'), ('ess_supervised', 'mixed')])
 def test_rccl_one_rank_dp_step_matches_plain(kind, mode):
     """The RCCL side of the data-parallel step on THIS box: a one-rank 'nccl' process group under ESS_DP_FORCE=1 (tests/dp_rccl_worker.py).
     (a) the eager step with bucketed all_reduce(AVG, async_op) calls issued from inside the backward, (b) the captured step as
