@@ -181,7 +181,7 @@ def _traffic_from_profiles(tag):
     tools/pmc_r4.py (rocprofv3 --pmc, separate passes, the guide's gfx950 unit corrections), committed as profiles/r5b_traffic.json (round 5, second session; r5 / r4 / r3 as fall-backs)
     (builder-side PMC passes over tools/traffic_probe.py, not re-measured in this run -- rocprofv3 cannot wrap a process from the
     inside); falls back to round 3's file; None when this shape / kernel was not profiled."""
-    for name in ('r5b_traffic.json', 'r5_traffic.json', 'r4_traffic.json', 'r3_traffic.json'):
+    for name in ('r6_traffic.json', 'r5b_traffic.json', 'r5_traffic.json', 'r4_traffic.json', 'r3_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 t = json.load(f).get(tag)
@@ -381,29 +381,36 @@ def roofline_blocks(args, device):
             ms = _timed(ev, stream, lambda: hip.conv_forward_h16(spec, x0, x1, pw, None, pb, out=out, out_fmt=hip.FMT_F16_C8))
             h_ms += cnt * ms; h_fl += cnt * 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout
             del x0, x1, out
-        hg_ms = hg_fl = 0.0
+        hg_ms = hg_fl = hg_ex = 0.0
         hg_levels = []
+        hilo_all = os.environ.get('ESS_MIXED_HILO', 'deepest') == 'all'
         for lvl, hid in enumerate((64, 128, 256)):
             H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
-            # the product launch of a lean time step: x as a [hi | lo] half pair (2 hid stored channels), h as a half copy, channel-blocked cells
-            spec = hip.conv_spec(B, H, W, 2 * hid, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, compute=hip.COMPUTE_F16)
-            w = (torch.randn(4 * hid, 3 * hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device)
+            # the product launch of a lean time step: x as a half copy -- at the deepest level a [hi | lo] pair (2 hid stored channels) --, h as a
+            # half copy, channel-blocked cells
+            xh = hilo_all or lvl == 2
+            Cx = hid * (2 if xh else 1)
+            spec = hip.conv_spec(B, H, W, Cx, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, compute=hip.COMPUTE_F16)
+            w = (torch.randn(4 * hid, Cx + hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(device)
             pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(4 * hid, generator=g).to(device))
-            x = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(device), hilo=True)
+            x = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(device), hilo=xh)
             h = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(device))
             c, co = hip.f32_c8_empty(B, hid, H, W, device).normal_(), hip.f32_c8_empty(B, hid, H, W, device)
             h16 = hip.f16_blocks_empty(B, hid, H, W, device)
             ms = _timed(ev, stream, lambda: hip.conv_forward_h16(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_h16=h16,
                                                                  out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8))
-            fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)  # ALGORITHMIC: the reference's cat(x, h) contraction; the launch contracts 3 hid stored channels
-            hg_levels.append({'level': lvl, 'hidden': hid, 'ms': round(ms, 4), 'algorithmic_tflops': round(fl / ms / 1e9, 1), 'executed_tflops': round(1.5 * fl / ms / 1e9, 1)})
-            hg_ms += ms; hg_fl += fl
+            fl = 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)  # ALGORITHMIC: the reference's cat(x, h) contraction; a pair makes the launch contract 3 hid stored channels
+            ex = fl * (Cx + hid) / (2 * hid)
+            hg_levels.append({'level': lvl, 'hidden': hid, 'x_pair': xh, 'ms': round(ms, 4), 'algorithmic_tflops': round(fl / ms / 1e9, 1), 'executed_tflops': round(ex / ms / 1e9, 1)})
+            hg_ms += ms; hg_fl += fl; hg_ex += ex
             del x, h, c, co, h16
         mixed_fwd = {'decoder_forward_launch_set': {'kernel': 'the 16 launches above on IEEE-half operands (H = true instantiations: v_mfma_f32_32x32x16_f16)',
+                                                    'traffic': _traffic_from_profiles(f'conv3x3_f16/bf16/{B}/{args.height}x{args.width}'),
                                                     'ms_per_launch_set': round(h_ms, 4), 'achieved': round(h_fl / h_ms / 1e9, 1), 'frac': round(h_fl / h_ms / 1e9 / peak, 4)},
-                     'convlstm_gate': {'kernel': 'conv_bf16_wide_kernel<2, 2, LSTM, H>: x as a [hi | lo] half pair (1.5x the stored K of the bf16 launch)',
+                     'convlstm_gate': {'kernel': 'conv_bf16_wide_kernel<2, 2, LSTM, H>: the three levels of a lean time step; x of the deepest level as a [hi | lo] half pair (1.5x the stored K of that launch)',
+                                       'traffic_product_form': _traffic_from_profiles(f'gate_mixed/bf16/{B}/{args.height}x{args.width}'),
                                        'ms_per_launch_set': round(hg_ms, 4), 'algorithmic_tflops': round(hg_fl / hg_ms / 1e9, 1),
-                                       'executed_tflops': round(1.5 * hg_fl / hg_ms / 1e9, 1), 'executed_frac': round(1.5 * hg_fl / hg_ms / 1e9 / peak, 4), 'per_level': hg_levels}}
+                                       'executed_tflops': round(hg_ex / hg_ms / 1e9, 1), 'executed_frac': round(hg_ex / hg_ms / 1e9 / peak, 4), 'per_level': hg_levels}}
     tag = f'{"bf16" if bf16 else args.compute}/{B}/{args.height}x{args.width}'  # (the PMC passes cover the bf16 instantiations; the half-operand flavour is the same code with v_mfma_f32_32x32x16_f16)
     conv_t = conv_fl / conv_ms / 1e9
     t_conv, t_gate, t_gru, t_wg, t_enc = [_traffic_from_profiles(g_ + '/' + tag) for g_ in ('conv3x3', 'gate', 'gru', 'wgrad', 'enc5x5s2')]

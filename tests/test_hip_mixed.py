@@ -269,3 +269,39 @@ def test_mixed_sequence_latents_vs_oracle(H, rec_type):
         assert e8 < 1e-3 and e8b < 1e-3 and e4 < 1.5e-3 and e_img < 3e-2, (e8, e8b, e4, e_img)
     finally:
         H.set_compute('fp32')
+
+
+def test_mixed_validation_epochs_and_val_step_vs_fp32(H):
+    """The validation path (reference training/ess_trainer.py:364-548) in the mixed configuration: BaseTrainer.validationEpochs runs
+    (sensor_a, sensor_b, cycle metrics), and one val_step's losses agree with the exact-fp32 HIP path on the same weights and batch to
+    half-operand accuracy (1e-2 relative; the bf16 configuration: several 1e-2)."""
+    from oracle import ess_oracle as O
+    from ess_amd.config.settings import synthetic_settings
+    from ess_amd.training.ess_trainer import ESSModel
+    B, T, C, Hh, W, K = 2, 3, 2, 96, 128, 11
+    out = {}
+    try:
+        for mode in ('fp32', 'mixed'):
+            H.set_compute(mode)
+            torch.manual_seed(6)
+            tr = ESSModel(synthetic_settings('ess', 'DSEC_events', (Hh, W), K, B, T, C, val_steps=2))
+            cfg = O.e2vid_config(num_bins=C)
+            tr.front_end_sensor_b.load_state_dict(O.synth_state_dict(O.e2vid_param_shapes(cfg), 151))
+            tr.task_backend.load_state_dict(O.synth_state_dict(O.semseg_param_shapes(256, K), 152, decoder_style=True))
+            tr.front_end_sensor_a.load_state_dict(O.synth_state_dict(O.style_encoder_param_shapes(1), 153))
+            for m in tr.models_dict.values():
+                m.eval()
+            ev, img, lab_a, lab_b = O.synth_batch(B, T, C, Hh, W, K, seed=900)
+            tr.resetValidationStatistics()
+            la, _ = tr.val_step([img.cuda(), lab_a.cuda()], 'sensor_a')
+            lb, _ = tr.val_step([ev.cuda(), lab_b.cuda()], 'sensor_b')
+            out[mode] = {k: v.item() for k, v in {**la, **lb}.items()}
+            if mode == 'mixed':
+                tr.validationEpochs()
+                assert set(tr.last_val_summary) == {'sensor_a', 'sensor_b'}
+                assert all(v == v for v in tr.last_val_summary['sensor_b'].values())
+        worst = max(abs(out['mixed'][k] - out['fp32'][k]) / max(abs(out['fp32'][k]), 5e-2) for k in out['fp32'])
+        print(f'mixed vs fp32 val_step losses: worst relative gap {worst:.2e} over {sorted(out["fp32"])}')
+        assert worst < 1e-2, (worst, out)
+    finally:
+        H.set_compute('fp32')

@@ -34,7 +34,7 @@ def test_events_to_voxel_grid_device_vs_oracle(case):
     assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('rtype,mode', [('convlstm', 'bf16'), ('convlstm', 'fp32'), ('convgru', 'bf16')])
+@pytest.mark.parametrize('rtype,mode', [('convlstm', 'bf16'), ('convlstm', 'fp32'), ('convgru', 'bf16'), ('convlstm', 'mixed'), ('convgru', 'mixed')])
 def test_streaming_reconstructor_eager_graph_and_reference_loop(rtype, mode):
     """Six windows of one sequence through StreamingReconstructor: (i) eager == the reference's loop of
     ImageReconstructor.update_reconstruction calls on the oracle-built voxel grids (1e-5: only the voxel grids differ in
@@ -74,7 +74,8 @@ def test_streaming_reconstructor_eager_graph_and_reference_loop(rtype, mode):
                 if rep == 0:
                     grid = O.events_to_voxel_grid(win, C, W, H)[None]
                     img_r, _, _ = rec.update_reconstruction(grid.cuda())
-                    assert (img_r - img_e).abs().max().item() < 1e-4
+                    # (mixed: the 1e-5 difference of the two voxel grids moves a few half roundings of the first layers: 1.4e-4 measured)
+                    assert (img_r - img_e).abs().max().item() < (3e-4 if mode == 'mixed' else 1e-4)
                     if mode == 'fp32':
                         with torch.no_grad():
                             img_o, states, _ = O.e2vid_step(sd, cfg, O.event_normalize(grid), states)

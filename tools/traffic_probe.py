@@ -125,4 +125,41 @@ for lvl, cin in enumerate((32, 64, 128)):
                  'count': 1, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * B * cin * Hs * Ws + 2 * B * cout * spec.H_out * spec.W_out + 2 * 25 * cin * cout,
                  'flops': 2.0 * B * spec.H_out * spec.W_out * 25 * cin * cout})
     del x8, o8
+# ---- round 6: the half-operand (ESS_COMPUTE_F16) instantiations as the mixed configuration's FORWARD launches them: the decoder's 3x3 set
+# (F16_C8 in, F16_C8 pre-norm out) and the lean ConvLSTM launches (x of the deepest level as a [hi | lo] pair: 1.5x the stored K)
+for (C0, C1, Cout, Hv, Wv, m0, cnt) in bench.decoder_conv3x3_layers(args):
+    spec = hip.conv_spec(B, Hv, Wv, C0, C1, Cout, 3, 1, 1, hip.SRC_NEAREST_UP2 if m0 else hip.SRC_DIRECT, hip.SRC_DIRECT, compute=hip.COMPUTE_F16)
+    x0 = hip.to_f16_c8(torch.randn(B, C0, Hv // (2 if m0 else 1), Wv // (2 if m0 else 1), generator=g).to(dev))
+    x1 = hip.to_f16_c8(torch.randn(B, C1, Hv, Wv, generator=g).to(dev)) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / (9 * (C0 + C1)) ** 0.5).to(dev)
+    pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(Cout, generator=g).to(dev))
+    out = hip.f16_blocks_empty(B, Cout, Hv, Wv, dev)
+    torch.cuda.synchronize()
+    for _ in range(WARM + REPS):
+        hip.conv_forward_h16(spec, x0, x1, pw, None, pb, out=out, out_fmt=hip.FMT_F16_C8)
+    torch.cuda.synchronize()
+    px_in = B * (C0 * (Hv * Wv // (4 if m0 else 1)) + C1 * Hv * Wv)
+    plan.append({'group': 'conv3x3_f16', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel|conv_bf16_poly_up2_kernel', 'layer': f'{C0}+{C1}->{Cout}@{Hv}x{Wv}' + (' up2' if m0 else ''),
+                 'count': cnt, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * px_in + 2 * B * Cout * Hv * Wv + 2 * 9 * (C0 + C1) * Cout,
+                 'flops': 2.0 * B * Hv * Wv * 9 * (C0 + C1) * Cout})
+    del x0, x1, out
+for lvl, hid in enumerate((64, 128, 256)):
+    H, W = args.height >> (lvl + 1), args.width >> (lvl + 1)
+    xh = lvl == 2  # (pairs at the deepest level only: the product's default)
+    Cx = hid * (2 if xh else 1)
+    spec = hip.conv_spec(B, H, W, Cx, hid, 4 * hid, 3, 1, 1, epi=hip.EPI_LSTM, hidden=hid, compute=hip.COMPUTE_F16)
+    w = (torch.randn(4 * hid, Cx + hid, 3, 3, generator=g) / (18 * hid) ** 0.5).to(dev)
+    pw, pb = hip.pack_weights(spec, w), hip.pack_rows(spec, torch.randn(4 * hid, generator=g).to(dev))
+    x = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(dev), hilo=xh)
+    h = hip.to_f16_c8(torch.randn(B, hid, H, W, generator=g).to(dev))
+    c = torch.randn(B, hid // 8, H, W, 8, generator=g).to(dev)
+    co, h16 = hip.f32_c8_empty(B, hid, H, W, dev), hip.f16_blocks_empty(B, hid, H, W, dev)
+    torch.cuda.synchronize()
+    for _ in range(WARM + REPS):
+        hip.conv_forward_h16(spec, x, h, pw, None, pb, aux0=c, out=None, out2=co, out_h16=h16, out_fmt=hip.FMT_F32_C8, aux_fmt=hip.FMT_F32_C8)
+    torch.cuda.synchronize()
+    n = B * hid * H * W
+    plan.append({'group': 'gate_mixed', 'kernel': 'conv_bf16_ws_k3s1_kernel|conv_bf16_wide_kernel', 'layer': f'level{lvl} hid{hid}@{H}x{W}' + (' x as [hi|lo]' if xh else ''),
+                 'count': 1, 'reps': REPS, 'warm': WARM, 'algorithmic_bytes': 2 * (2 + (1 if xh else 0)) * n + 4 * n + (4 + 2) * n + 2 * 9 * (Cx + hid) * 4 * hid,
+                 'flops': 2.0 * B * H * W * 9 * (2 * hid) * (4 * hid)})
 print('PLAN ' + json.dumps(plan))
