@@ -47,6 +47,24 @@ def test_conv_plan_and_validation_on_host(built_lib):
         hip.conv_spec(1, 8, 8, 4, 0, 4, 4, 1, 1)
     with pytest.raises(hip.EssHipError, match='LSTM'):
         hip.conv_spec(1, 8, 8, 4, 4, 12, 3, 1, 1, epi=hip.EPI_LSTM, hidden=4)
+    # ESS_COMPUTE_F16 (the mixed configuration's forward arithmetic) plans exactly like bf16: same tiles, chunks and pack sizes
+    sh = hip.conv_spec(8, 240, 320, 64, 64, 256, 3, 1, 1, epi=hip.EPI_LSTM, hidden=64, compute=hip.COMPUTE_F16)
+    assert (sh.plan.ck, sh.plan.cout_tile, sh.plan.packed_bytes, sh.plan.lds_bytes) == (sb.plan.ck, sb.plan.cout_tile, sb.plan.packed_bytes, sb.plan.lds_bytes)
+    # ... a [hi | lo] x operand is 2 C stored channels, a [hi | lo] copy of h' is requested through `act`
+    sx = hip.conv_spec(8, 60, 80, 512, 256, 1024, 3, 1, 1, epi=hip.EPI_LSTM, hidden=256, act=hip.LSTM_H_HILO, compute=hip.COMPUTE_F16)
+    assert sx.plan.n_chunks == 48
+    lib = hip.lib()
+    d = sh.desc_fmt(hip.FMT_BF16_C8, hip.FMT_F32_NCHW, hip.FMT_F32_NCHW)  # (half-operand convolutions read F16_C8, never BF16_C8)
+    plan = hip.EssConvPlan()
+    assert lib.ess_conv2d_plan(ctypes.byref(d), ctypes.byref(plan)) == -22 and b'F16_C8' in lib.ess_last_error()
+    lin = hip.conv_spec(2, 24, 40, 64, 0, 64, 3, 1, 1, compute=hip.COMPUTE_F16)
+    assert lib.ess_conv2d_plan(ctypes.byref(lin.desc_fmt(hip.FMT_F16_C8, hip.FMT_F16_C8_HILO, hip.FMT_F32_NCHW)), ctypes.byref(plan)) == 0
+    with pytest.raises(hip.EssHipError, match='HILO'):  # an output format of ESS_COMPUTE_F16 only
+        bad = hip.conv_spec(2, 24, 40, 64, 0, 64, 3, 1, 1, compute=hip.COMPUTE_BF16)
+        hip._check(lib.ess_conv2d_plan(ctypes.byref(bad.desc_fmt(hip.FMT_BF16_C8, hip.FMT_F16_C8_HILO, hip.FMT_F32_NCHW)), ctypes.byref(plan)), 'plan')
+    with pytest.raises(hip.EssHipError, match='pooled'):
+        hip.conv_spec(2, 24, 40, 64, 0, 64, 3, 1, 1, act=hip.ACT_SUMPOOL2, compute=hip.COMPUTE_F16)
+    assert lib.ess_version() == 110
 
 
 def test_product_refuses_cpu_tensors(built_lib):
@@ -457,7 +475,7 @@ def test_header_enums_match_the_binding():
             pairs[name] = int(val)
     mirrored = {n: v for n, v in pairs.items() if hasattr(hip, n)}
     assert len(mirrored) >= 15, sorted(mirrored)
-    assert {'FMT_F32_NCHW', 'FMT_BF16_C8', 'FMT_F32_C8', 'EPI_LSTM', 'SRC_ZERO_UP2', 'ACT_SUMPOOL2'} <= set(mirrored)
+    assert {'FMT_F32_NCHW', 'FMT_BF16_C8', 'FMT_F32_C8', 'EPI_LSTM', 'SRC_ZERO_UP2', 'ACT_SUMPOOL2', 'COMPUTE_F16', 'FMT_F16_C8_HILO', 'LSTM_H_HILO', 'GRU_H_HILO'} <= set(mirrored)
     wrong = {n: (v, getattr(hip, n)) for n, v in mirrored.items() if getattr(hip, n) != v}
     assert not wrong, wrong
 
