@@ -14,6 +14,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef ESS_REDUCE1_U
+#define ESS_REDUCE1_U 4
+#endif
 namespace {
 
 typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
@@ -361,8 +364,10 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
                                                         const u32x4n* __restrict__ dy, const float* __restrict__ stats,
                                                         double* sums, int hw, int nseg, int seg_stride, int CB, int C,
                                                         int per_sample_stats, int relu, int relu_from_y,
-                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
-  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr, int xcb = 0) {
+  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor; xcb > 0 (InstanceNorm, nseg = 1): x keeps xcb blocks per sample, a [hi | lo] half
+  // pair -- MODE 0 sums hi + lo, MODE 1 reads the hi parts)
+  const int xf16 = (relu >> 8) & 1;
   relu &= 0xff;
   __shared__ double redd[4 * 16];
   const int g = blockIdx.x, nsl = gridDim.y, sl = blockIdx.y;
@@ -388,28 +393,42 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
   double s0[8], s1[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s0[j] = 0; s1[j] = 0; }
-  constexpr int U = MODE == 0 ? 4 : 2;  // vectors per tensor in flight per thread
+  constexpr int U = MODE == 0 ? 4 : (ESS_REDUCE1_U);  // vectors per tensor in flight per thread
   for (int sgm = 0; sgm < nseg; ++sgm) {
     const size_t base = ((size_t)sgm * seg_stride + g) * hw;
+    const size_t xbase = xcb > 0 ? ((size_t)(g / CB) * xcb + cb) * hw : base, xlo = xbase + (size_t)CB * hw;
     for (int i = i0 + threadIdx.x; i < i1; i += 256 * U) {
-      u32x4n xv[U], gv[U], yv[U];
+      u32x4n xv[U], gv[U], yv[U], xl[MODE == 0 ? U : 1];
 #pragma unroll
       for (int u = 0; u < U; ++u) {  // clamped addresses: the loads carry no per-lane branch and are all in flight together
         const int ii = i + u * 256, ic = ii < i1 ? ii : i1 - 1;
-        xv[u] = x[base + ic];
+        xv[u] = x[xbase + ic];
+        if (MODE == 0 && xcb > 0) xl[u] = x[xlo + ic];
         if (MODE == 1) {
           gv[u] = dy[base + ic];
           if (relu && relu_from_y) yv[u] = y[base + ic];
         }
       }
+      // the U vectors of an iteration are summed in fp32 first (U <= 4 terms per channel: 2^-23 of a term), the running sums stay fp64:
+      // the fp64 conversions / adds per loaded vector were 32 half-rate VALU operations -- as many issue cycles as the loads' bytes
+      // take at 5 TB/s -- and the kernels streamed at 3.3-3.6 TB/s where the apply passes reach 5.5-6 (round 6)
+      float p0[8], p1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { p0[j] = 0.f; p1[j] = 0.f; }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (i + u * 256 >= i1) continue;
         float f[8];
         unpack8x(xv[u], f, xf16);
         if (MODE == 0) {
+          if (xcb > 0) {  // (uniform)
+            float l[8];
+            unpack8h(xl[u], l);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { s0[j] += f[j]; s1[j] += (double)f[j] * f[j]; }
+            for (int j = 0; j < 8; ++j) f[j] += l[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { p0[j] += f[j]; p1[j] = fmaf(f[j], f[j], p1[j]); }
         } else {
           float gg[8], yy[8];
           unpack8(gv[u], gg);
@@ -419,11 +438,13 @@ __global__ __launch_bounds__(256) void c8_reduce_kernel(const u32x4n* __restrict
             const float xh = (f[j] - mean[j]) * rstd[j];
             const bool off = relu && (relu_from_y ? yy[j] <= 0.f : (affine_mask ? f[j] * ma[j] + mb[j] <= 0.f : xh <= 0.f));
             const float gr = off ? 0.f : gg[j];
-            s0[j] += gr;
-            s1[j] += (double)gr * xh;
+            p0[j] += gr;
+            p1[j] = fmaf(gr, xh, p1[j]);
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0[j] += (double)p0[j]; s1[j] += (double)p1[j]; }
     }
   }
   // the 16 block sums with ONE barrier (per value: wave sum, then the waves in order -- the order block_sum_d uses; 16 calls of
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
 __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                               u32x4n* __restrict__ y, u32x4n* __restrict__ y16, float* __restrict__ stats,
                                                               const double* sums, int nsl, int CB, int C, int hw, float eps, int flags) {
-  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1;
+  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1, hilo = (flags >> 10) & 1;
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   double t0[8], t1[8];
   group_total8(sums, g, nsl, t0, t1);
@@ -544,14 +565,16 @@ __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __re
       if (cb * 8 + j < C) { stats[2 * ((size_t)n * C + cb * 8 + j)] = mean[j]; stats[2 * ((size_t)n * C + cb * 8 + j) + 1] = rstd[j]; }
   }
   const size_t base = (size_t)g * hw;
+  const size_t xbase = hilo ? ((size_t)n * 2 * CB + cb) * hw : base, xlo = xbase + (size_t)CB * hw;  // (a [hi | lo] x: 2 CB blocks per sample)
   constexpr int U = 4;
   const int stride = gridDim.y * 256;
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
-    u32x4n xv[U], rv[U];
+    u32x4n xv[U], rv[U], xl[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
-      xv[u] = x[base + ic];
+      xv[u] = x[xbase + ic];
+      if (hilo) xl[u] = x[xlo + ic];
       if (res) rv[u] = res[base + ic];
     }
 #pragma unroll
@@ -560,6 +583,12 @@ __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __re
       if (ii >= hw) continue;
       float f[8], rf[8];
       unpack8x(xv[u], f, xf16);
+      if (hilo) {  // (uniform)
+        float l[8];
+        unpack8h(xl[u], l);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += l[j];
+      }
       if (res) unpack8x(rv[u], rf, rf16);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -576,8 +605,8 @@ __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __re
 
 __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ dy,
                                                               const float* __restrict__ stats, const double* sums, int nsl,
-                                                              u32x4n* __restrict__ dx, int CB, int C, int hw, int relu) {
-  const int xf16 = relu >> 8;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor)
+                                                              u32x4n* __restrict__ dx, int CB, int C, int hw, int relu, int xcb = 0) {
+  const int xf16 = (relu >> 8) & 1;  // (flags: bit 0 = ReLU, bit 8 = x is an F16_C8 tensor; xcb > 0: x keeps xcb blocks per sample, the first CB are read)
   relu &= 0xff;
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   double t0[8], t1[8];
@@ -592,6 +621,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __re
     m2[j] = (float)(t1[j] / hw);
   }
   const size_t base = (size_t)g * hw;
+  const size_t xbase = xcb > 0 ? ((size_t)n * xcb + cb) * hw : base;
   constexpr int U = 3;
   const int stride = gridDim.y * 256;
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
@@ -599,7 +629,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_c8_kernel(const u32x4n* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
-      xv[u] = x[base + ic];
+      xv[u] = x[xbase + ic];
       gv[u] = dy[base + ic];
     }
 #pragma unroll
@@ -754,8 +784,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_c8_kernel(const u32x4n* __re
 }
 
 inline int split_for8(int groups, int hw) {
-  int s = (1024 + groups - 1) / groups;
-  const int maxs = (hw + 1023) / 1024;  // at least 1024 pixel vectors per slice
+  // workgroups the statistics pass aims at (x slices per group) and the smallest slice (ESS_NORM_SPLIT_WGS / ESS_NORM_SPLIT_MINV: tuning)
+  static const int target = [] { const char* e = getenv("ESS_NORM_SPLIT_WGS"); return e ? atoi(e) : 1024; }();
+  static const int minv = [] { const char* e = getenv("ESS_NORM_SPLIT_MINV"); return e ? atoi(e) : 1024; }();
+  int s = (target + groups - 1) / groups;
+  const int maxs = (hw + minv - 1) / minv;  // at least `minv` pixel vectors per slice
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
   return s < 1 ? 1 : s;
@@ -782,7 +815,7 @@ inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr
 }  // namespace
 
 // (sum, sum) pairs of doubles per group, slice and channel of the block; split_for8() keeps groups * slices <= 1024 + groups
-extern "C" size_t ess_norm_workspace_c8(int32_t groups) { return (size_t)(groups > 0 ? groups + 1024 : 0) * 8 * 16; }
+extern "C" size_t ess_norm_workspace_c8(int32_t groups) { return (size_t)(groups > 0 ? 64 * (size_t)groups + 4096 : 0) * 8 * 16; }  // (<= 64 slices per group)
 
 // "in_small_threads" (ESS_IN_SMALL_THREADS: 256 | 512 | 1024): threads of the fused single-plane InstanceNorm kernels on planes of
 // at most 5120 vectors (the decoder's 60 x 80 level).  Every setting computes the same statistics up to the summation order.
@@ -836,7 +869,6 @@ extern "C" int ess_instnorm_forward_c8_mixed(const void* x, const void* residual
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_forward_c8_mixed: relu must be 0 or 1");
   ESS_CHECK_ARG(x_fmt >= 0 && x_fmt <= 2, "instnorm_forward_c8_mixed: x_fmt is 0 (BF16_C8), 1 (F16_C8) or 2 (F16_C8 [hi | lo])");
   ESS_CHECK_ARG(al16(x, residual, y, y16), "instnorm_forward_c8_mixed: C8 tensors must be 16-byte aligned");
-  ESS_CHECK_ARG(x_fmt != 2 || hw <= 256 * MAXV, "instnorm_forward_c8_mixed: a [hi | lo] input exists for planes of at most %d pixels", 256 * MAXV);
   hipStream_t st = (hipStream_t)stream;
   const int flags = (relu & 1) | (x_fmt ? 0x100 : 0) | (res_f16 ? 0x200 : 0);
   const int CB = (C + 7) / 8, groups = N * CB;
@@ -855,9 +887,9 @@ extern "C" int ess_instnorm_forward_c8_mixed(const void* x, const void* residual
   if (rc) return rc;
   const int nsl = split_for8(groups, hw);
   hipLaunchKernelGGL((c8_reduce_kernel<0>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, nullptr, nullptr, (double*)workspace, hw, 1,
-                     0, CB, C, 1, flags & 0x100, 0);
+                     0, CB, C, 1, flags & 0x100, 0, nullptr, nullptr, x_fmt == 2 ? 2 * CB : 0);
   hipLaunchKernelGGL(in_apply_c8_mix_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, rs, ys, hs, stats,
-                     (const double*)workspace, nsl, CB, C, hw, eps, flags);
+                     (const double*)workspace, nsl, CB, C, hw, eps, flags | (x_fmt == 2 ? 0x400 : 0));
   return ess_launch_status("instnorm_forward_c8_mixed(split)");
 }
 
@@ -868,7 +900,7 @@ extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const flo
   ESS_CHECK_ARG(al16(x, dy, dx), "instnorm_backward_c8: BF16_C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   // x_f16 = 2: x is a [hi | lo] half pair ([N][2 CB][hw][8], the mixed configuration's first decoder layer): the hi parts are read
-  ESS_CHECK_ARG(x_f16 >= 0 && x_f16 <= 2 && (x_f16 != 2 || hw <= 256 * MAXV), "instnorm_backward_c8: x_f16 is 0, 1 or (planes of at most %d pixels) 2", 256 * MAXV);
+  ESS_CHECK_ARG(x_f16 >= 0 && x_f16 <= 2, "instnorm_backward_c8: x_f16 is 0 (BF16_C8), 1 (F16_C8) or 2 (a [hi | lo] half pair: its hi parts are read)");
   const int xcb = x_f16 == 2 ? 2 * ((C + 7) / 8) : 0;
   relu = (relu & 1) | (x_f16 ? 0x100 : 0);  // (the kernels' flag word)
   const int CB = (C + 7) / 8, groups = N * CB;
@@ -884,9 +916,9 @@ extern "C" int ess_instnorm_backward_c8(const void* x, const void* dy, const flo
   if (rc) return rc;
   const int nsl = split_for8(groups, hw);
   hipLaunchKernelGGL((c8_reduce_kernel<1>), dim3(groups, nsl), dim3(256), 0, st, xs, nullptr, gs, stats, (double*)workspace, hw, 1, 0, CB,
-                     C, 1, relu, 0);
+                     C, 1, relu, 0, nullptr, nullptr, xcb);
   hipLaunchKernelGGL(in_bwd_apply_c8_kernel, dim3(groups, chunks_for8(groups, hw)), dim3(256), 0, st, xs, gs, stats,
-                     (const double*)workspace, nsl, ds, CB, C, hw, relu);
+                     (const double*)workspace, nsl, ds, CB, C, hw, relu, xcb);
   return ess_launch_status("instnorm_backward_c8(split)");
 }
 

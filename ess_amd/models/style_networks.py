@@ -58,13 +58,13 @@ class INSResBlock(nn.Module):
 
     def forward(self, x, first=False):
         """first (mixed configuration): the block reads the event latents -- its first pre-norm tensor has channel means of 6-17 standard
-        deviations and leaves the convolution as a [hi | lo] half pair (planes of at most 5120 pixels: the fused norm kernels)"""
+        deviations and leaves the convolution as a [hi | lo] half pair"""
         c1, c2 = self.model[0], self.model[3]
         # x enters the graph ONCE: conv1 hands it through as the skip operand, so the skip gradient is added inside
         # conv1's data-gradient kernel instead of by a separate elementwise pass (functional.Conv2dFn.forward)
         pre = Fn.pre_norm_fmt() if hip.is_c8(x) else None  # (the conv outputs are pre-norm tensors: F16_C8 in the bf16 configuration)
         pre1 = pre
-        if first and pre == Fn.PRE_NORM and Fn.mixed() and x.shape[2] * x.shape[3] <= 5120 and c1.out_channels % 64 == 0:
+        if first and pre == Fn.PRE_NORM and Fn.mixed() and c1.out_channels % 64 == 0:
             pre1 = Fn.PRE_NORM_HILO
         y, skip = Fn.conv2d_passthrough(x, c1.weight, c1.bias, c1.stride[0], 1, out_c8=pre1, half=True)
         hx = hip.h16_of(x)
