@@ -195,11 +195,12 @@ template <int THREADS, int MV, bool HILO>
 __global__ __launch_bounds__(THREADS) void in_fwd_c8_mix_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                                 u32x4n* __restrict__ y, u32x4n* __restrict__ y16, float* __restrict__ stats,
                                                                 int CB, int C, int hw, float eps, int flags) {
-  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1;
+  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1, rpair = (flags >> 11) & 1;
   __shared__ float red[16 * 8];
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   const size_t base = (size_t)g * hw;
   const size_t xbase = HILO ? ((size_t)n * 2 * CB + cb) * hw : base, xlo = xbase + (size_t)CB * hw;
+  const size_t rbase = rpair ? ((size_t)n * 2 * CB + cb) * hw : base;  // (bit 11: the residual is a [hi | lo] half pair, its hi parts are added)
   u32x4n xv[MV], xl[HILO ? MV : 1];
   float s[8];
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(THREADS) void in_fwd_c8_mix_kernel(const u32x4n* __
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const int i = threadIdx.x + (k0 + u) * THREADS;
-        if (k0 + u < MV) rv[u] = res[base + (i < hw ? i : hw - 1)];
+        if (k0 + u < MV) rv[u] = res[rbase + (i < hw ? i : hw - 1)];
       }
     }
 #pragma unroll
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void in_apply_c8_kernel(const u32x4n* __restri
 __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __restrict__ x, const u32x4n* __restrict__ res,
                                                               u32x4n* __restrict__ y, u32x4n* __restrict__ y16, float* __restrict__ stats,
                                                               const double* sums, int nsl, int CB, int C, int hw, float eps, int flags) {
-  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1, hilo = (flags >> 10) & 1;
+  const int relu = flags & 1, xf16 = (flags >> 8) & 1, rf16 = (flags >> 9) & 1, hilo = (flags >> 10) & 1, rpair = (flags >> 11) & 1;
   const int g = blockIdx.x, n = g / CB, cb = g - n * CB;
   double t0[8], t1[8];
   group_total8(sums, g, nsl, t0, t1);
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __re
   }
   const size_t base = (size_t)g * hw;
   const size_t xbase = hilo ? ((size_t)n * 2 * CB + cb) * hw : base, xlo = xbase + (size_t)CB * hw;  // (a [hi | lo] x: 2 CB blocks per sample)
+  const size_t rbase = rpair ? ((size_t)n * 2 * CB + cb) * hw : base;
   constexpr int U = 4;
   const int stride = gridDim.y * 256;
   for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += stride * U) {
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void in_apply_c8_mix_kernel(const u32x4n* __re
       const int ii = i + u * stride, ic = ii < hw ? ii : hw - 1;
       xv[u] = x[xbase + ic];
       if (hilo) xl[u] = x[xlo + ic];
-      if (res) rv[u] = res[base + ic];
+      if (res) rv[u] = res[rbase + ic];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -868,9 +870,10 @@ extern "C" int ess_instnorm_forward_c8_mixed(const void* x, const void* residual
   ESS_CHECK_ARG(x && y16 && stats && N > 0 && C > 0 && hw > 0, "instnorm_forward_c8_mixed: bad arguments");
   ESS_CHECK_ARG(relu == 0 || relu == 1, "instnorm_forward_c8_mixed: relu must be 0 or 1");
   ESS_CHECK_ARG(x_fmt >= 0 && x_fmt <= 2, "instnorm_forward_c8_mixed: x_fmt is 0 (BF16_C8), 1 (F16_C8) or 2 (F16_C8 [hi | lo])");
+  ESS_CHECK_ARG(res_f16 >= 0 && res_f16 <= 2, "instnorm_forward_c8_mixed: res_f16 is 0 (BF16_C8), 1 (F16_C8) or 2 (a [hi | lo] half pair: its hi parts are added)");
   ESS_CHECK_ARG(al16(x, residual, y, y16), "instnorm_forward_c8_mixed: C8 tensors must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  const int flags = (relu & 1) | (x_fmt ? 0x100 : 0) | (res_f16 ? 0x200 : 0);
+  const int flags = (relu & 1) | (x_fmt ? 0x100 : 0) | (res_f16 ? 0x200 : 0) | (res_f16 == 2 ? 0x800 : 0);
   const int CB = (C + 7) / 8, groups = N * CB;
   const u32x4n* xs = (const u32x4n*)x; const u32x4n* rs = (const u32x4n*)residual; u32x4n* ys = (u32x4n*)y; u32x4n* hs = (u32x4n*)y16;
   if (hw <= 256 * MAXV) {

@@ -124,6 +124,14 @@ def _check_eval(mod, norm):
 _S2D_MODE = os.environ.get('ESS_CONV5_S2D', '1')[:1]  # (read once: 0 = never, 1 = where faster, 2 = wherever the form exists)
 
 
+def set_s2d_mode(mode):
+    """'0' | '1' | '2' (see _S2D_MODE) -> the previous value: pin one form of the encoder's 5x5 / stride-2 convolutions for a model whose
+    outputs must not depend on the batch size in the last bit (tests; a deployment that validates at B = 1 what it trained at B = 8)"""
+    global _S2D_MODE
+    prev, _S2D_MODE = _S2D_MODE, str(mode)[:1]
+    return prev
+
+
 def _s2d_spec(N, k, stride, pad, cin, cout, H, W, act):
     """The ESS_SRC_S2D spec of a 5x5 / stride-2 / pad-2 convolution where that form exists AND is the faster one for this launch
     (hip.s2d_preferred: it needs a launch that fills the chip), else None.  Switch ESS_CONV5_S2D: 0 = never, 2 = wherever it exists.

@@ -603,8 +603,8 @@ class InstanceNormFn(torch.autograd.Function):
             res = residual
             if residual is not None:
                 h = hip.h16_of(residual)
-                if h is not None:  # the skip operand's half values (a [hi | lo] latent: its hi parts, a plain copy of CB blocks per sample)
-                    res = h[0][:, :h[0].shape[1] // 2].contiguous() if h[1] else h[0]
+                if h is not None:  # the skip operand's half values (a [hi | lo] latent: the kernel adds its hi parts)
+                    res = h[0]
             y, y16, stats = hip.instnorm_forward_c8_mixed(xin, _channels(x), res, relu, eps, x_fmt)
             hip.attach_h16(y, y16, False)
             ctx.relu, ctx.x_f16 = relu, x_fmt

@@ -892,7 +892,9 @@ def instnorm_forward_c8_mixed(x, C, residual, relu, eps=1e-5, x_fmt=1, want_bf16
     stats = torch.empty(N * C, 2, dtype=torch.float32, device=x.device)
     L = lib()
     ws = workspace(L.ess_norm_workspace_c8(N * CB), x.device, 'norm8')
-    res_f16 = residual is not None and residual.dtype == torch.float16
+    res_f16 = 0
+    if residual is not None and residual.dtype == torch.float16:
+        res_f16 = 2 if residual.shape[1] == 2 * CB else 1  # (a [hi | lo] pair: twice the blocks; the kernel adds its hi parts)
     _check(L.ess_instnorm_forward_c8_mixed(ptr(x, x.dtype), ptr(residual, residual.dtype if residual is not None else torch.float16),
                                            ptr(y, torch.bfloat16), ptr(y16, torch.float16), ptr(stats), N, C, H * W, c_float(eps),
                                            int(relu), int(x_fmt), int(res_f16), c_void_p(ws.data_ptr()), c_size_t(ws.numel()), stream()),

@@ -256,7 +256,7 @@ int ess_instnorm_forward_c8(const void* x, const void* residual, void* y, float*
                             float eps, int32_t relu, int32_t x_f16, void* workspace, size_t workspace_bytes, ess_stream_t stream);
 /* InstanceNorm forward of the "mixed" configuration: as ess_instnorm_forward_c8, plus y16 = the result as an F16_C8 tensor (required;
  * what the next ESS_COMPUTE_F16 convolution reads), y (BF16_C8) optional; x_fmt: 0 BF16_C8, 1 F16_C8, 2 the [hi | lo] pair of
- * ESS_FMT_F16_C8_HILO (x = hi + lo); res_f16: the residual is an F16_C8 tensor.  The statistics
+ * ESS_FMT_F16_C8_HILO (x = hi + lo); res_f16: 0 the residual is BF16_C8, 1 F16_C8, 2 a [hi | lo] pair (its hi parts are added).  The statistics
  * are those of the values read.  ess_instnorm_backward_c8 takes the same x with x_f16 = x_fmt (2: the hi parts are read).     */
 int ess_instnorm_forward_c8_mixed(const void* x, const void* residual, void* y, void* y16, float* stats, int32_t N, int32_t C, int32_t hw,
                                   float eps, int32_t relu, int32_t x_fmt, int32_t res_f16, void* workspace, size_t workspace_bytes,

@@ -199,7 +199,7 @@ def test_instance_norm_mixed(H, case):
     r = torch.randn(N, C, Hh, W, generator=g)
     xs = H.to_f16_c8(x.cuda(), hilo=x_fmt == 2)
     xv = (unblock_hilo(xs, C) if x_fmt == 2 else unblock(xs, C).double())
-    rs = H.to_f16_c8(r.cuda()) if with_res else None
+    rs = H.to_f16_c8(r.cuda(), hilo=x_fmt == 2) if with_res else None  # (with a [hi | lo] x the skip operand comes as a pair too: its hi parts are added)
     y, y16, stats = H.instnorm_forward_c8_mixed(xs, C, rs, relu, 1e-5, x_fmt)
     ref = F.instance_norm(xv, eps=1e-5)
     if relu:

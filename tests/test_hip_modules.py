@@ -606,12 +606,12 @@ def test_full_size_encoder_properties():
                 # tap-paired kernel where it does not (B = 1): the same bf16 products in another fp32 summation order.  Bit-identical
                 # per sample with ONE form on both sides (switch 2: space-to-depth wherever it exists), bf16 rounding level otherwise.
                 assert all(relerr(x[3:4], y) < 2e-2 for x, y in zip(a, one)), f'{mode}: sample 3 depends on its batch'
-                import os
-                os.environ['ESS_CONV5_S2D'] = '2'
+                from ess_amd.e2vid.model.submodules import set_s2d_mode
+                prev = set_s2d_mode('2')
                 try:
                     a2, one2 = run(ev), run(ev[3:4].contiguous())
                 finally:
-                    del os.environ['ESS_CONV5_S2D']
+                    set_s2d_mode(prev)
                 assert all(torch.equal(x, y) for x, y in zip(a, a2)), 'forcing the space-to-depth form changes a launch that already took it'
                 assert all(torch.equal(x[3:4], y) for x, y in zip(a2, one2)), f'{mode}: sample 3 depends on its batch (one form on both sides)'
                 del a2, one2
@@ -620,17 +620,13 @@ def test_full_size_encoder_properties():
                 # (The 5x5 / stride-2 convolutions of the BF16_C8-only flow run as the space-to-depth 3x3 -- ESS_SRC_S2D, another summation
                 # order than the tap-paired kernel an fp32-staged step takes -- so the bit comparison is made with that form switched off,
                 # and the two forms are compared with each other at bf16 rounding level.)
-                import os
-                old = os.environ.get('ESS_CONV5_S2D')
-                os.environ['ESS_CONV5_S2D'] = '0'
+                from ess_amd.e2vid.model.submodules import set_s2d_mode
+                old = set_s2d_mode('0')
                 try:
                     a_pair = run(ev)
                     c = run(ev, strip_copies=True)
                 finally:
-                    if old is None:
-                        del os.environ['ESS_CONV5_S2D']
-                    else:
-                        os.environ['ESS_CONV5_S2D'] = old
+                    set_s2d_mode(old)
                 assert all(torch.equal(x, y) for x, y in zip(a_pair, c)), 'BF16_C8-staged and fp32-staged encoders differ'
                 assert all(relerr(x, y) < 2e-2 for x, y in zip(a, a_pair)), 'space-to-depth and tap-paired 5x5 / stride-2 forms differ'
                 del a_pair, c
