@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Timeline arithmetic on a rocprofv3 (rocpd sqlite) kernel trace of the captured step: how much of a step's wall time is covered by
+kernels, how much sits BETWEEN kernels (launch boundaries of dependent graph nodes), and which kernels are short enough that the boundary
+is comparable to them.
+usage: python tools/graph_timeline.py <results.db> [steps_to_use] > profiles/rN_graph_timeline.txt"""
+import collections
+import sqlite3
+import sys
+
+
+def dispatch_rows(cur):
+    names = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    for cand in ('kernels', 'kernel_dispatch'):
+        if cand in names:
+            cols = [r[1] for r in cur.execute(f'pragma table_info({cand})')]
+            if {'name', 'start', 'end'} <= set(cols):
+                return list(cur.execute(f'select name, start, end from {cand} order by start')), cand
+    # rocpd base tables: rocpd_kernel_dispatch_<guid> joined with rocpd_info_kernel_symbol_<guid>
+    disp = [n for n in names if n.startswith('rocpd_kernel_dispatch')]
+    sym = [n for n in names if n.startswith('rocpd_info_kernel_symbol')]
+    if disp and sym:
+        q = (f'select s.kernel_name, d.start, d.end from {disp[0]} d join {sym[0]} s on d.kernel_id = s.id order by d.start')
+        return list(cur.execute(q)), disp[0]
+    raise SystemExit('no dispatch table found; tables: ' + ', '.join(names))
+
+
+def main(path, steps=10):
+    cur = sqlite3.connect(path).cursor()
+    rows, src = dispatch_rows(cur)
+    print(f'# {path}: {len(rows)} dispatches from {src}')
+    # the captured step is the periodic part: find the period as the dispatch count between two launches of the rarest long kernel
+    names = [r[0] for r in rows]
+    cnt = collections.Counter(names)
+    # replayed steps: the tail of the trace; period = smallest p such that names[-p:] == names[-2p:-p]
+    period = None
+    for p in range(50, len(rows) // 3):
+        if names[-p:] == names[-2 * p:-p] and names[-2 * p:-p] == names[-3 * p:-2 * p]:
+            period = p
+            break
+    if period is None:
+        raise SystemExit('no periodic tail found')
+    use = rows[-period * steps:]
+    print(f'# period {period} dispatches per step; using the last {steps} steps')
+    t0, t1 = use[0][1], max(r[2] for r in use)
+    span = (t1 - t0) / steps
+    busy = 0
+    gaps = []
+    cur_end = use[0][1]
+    for _, s, e in use:
+        if s > cur_end:
+            gaps.append(s - cur_end)
+            busy_start = s
+        if e > cur_end:
+            busy += e - max(s, cur_end)
+            cur_end = e
+    ksum = sum(e - s for _, s, e in use)
+    print(f'wall per step        {span / 1e6:8.3f} ms')
+    print(f'kernel time per step {ksum / steps / 1e6:8.3f} ms (sum of durations)')
+    print(f'covered per step     {busy / steps / 1e6:8.3f} ms (union of the kernels\' intervals)')
+    print(f'uncovered per step   {sum(gaps) / steps / 1e6:8.3f} ms in {len(gaps) / steps:.0f} gaps')
+    edges = [0, 500, 1000, 2000, 3000, 5000, 10000, 20000, 1 << 60]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        g = [x for x in gaps if lo <= x < hi]
+        if g:
+            print(f'  gaps {lo / 1e3:5.1f} - {"inf" if hi > 1e9 else hi / 1e3:>5} us: {len(g) / steps:7.1f} per step, {sum(g) / steps / 1e6:7.3f} ms per step')
+    # per-kernel table of one step
+    agg = collections.defaultdict(lambda: [0, 0])
+    for n, s, e in use:
+        agg[n][0] += 1
+        agg[n][1] += e - s
+    print(f'\n{"calls/step":>10} {"ms/step":>9} {"avg_us":>8}  kernel')
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        short = n.replace('(anonymous namespace)::', '')
+        print(f'{c / steps:10.1f} {t / steps / 1e6:9.3f} {t / c / 1e3:8.2f}  {short[:120]}')
+    short_k = [(n, c, t) for n, (c, t) in agg.items() if t / c < 8000]
+    print(f'\nkernels under 8 us: {sum(c for _, c, _ in short_k) / steps:.0f} launches per step, {sum(t for _, _, t in short_k) / steps / 1e6:.3f} ms per step')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10)
