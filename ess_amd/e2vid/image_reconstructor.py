@@ -104,8 +104,11 @@ class ImageReconstructor:
                 B = events.shape[0]
                 prefix = self.model.forward_prefix(slices[:T - 1].reshape((T - 1) * B, C, events.shape[2], events.shape[3]))
             res = (None, None, None)
+            unet = getattr(self.model, 'unetrecurrent', None)
             for i in range(T):
                 last = i == T - 1
+                if unet is not None:
+                    unet.steps_left = T - 1 - i  # ('mixed': where the deepest level's operand pair is used -- unet._forward_mixed)
                 if slices is not None:
                     ev = slices[i]
                 else:
@@ -116,5 +119,9 @@ class ImageReconstructor:
                 if prefix is not None and not last:
                     B = events.shape[0]
                     pf = (prefix[0][i * B:(i + 1) * B], prefix[1][i * B:(i + 1) * B])
-                res = self._step(ev, need_image and last, not last, prefix=pf, final_lean=final_lean and last)
+                try:
+                    res = self._step(ev, need_image and last, not last, prefix=pf, final_lean=final_lean and last)
+                finally:
+                    if unet is not None:
+                        unet.steps_left = None
             return res

@@ -6,6 +6,8 @@ UNet (its non-recurrent sibling, selectable through the checkpoint's `arch`) and
 instantiated by load_model).  Channel plan and module names follow BaseUNet (unet.py:16-67) so the
 state_dict layout is identical.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -211,6 +213,13 @@ def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean
     # that level alone carries the effect (10 flips of 307200 against 13 with pairs at all three levels, 37 with none; latents: 11 with
     # the 1/8 latent alone, 13 with all, 40 with none); ESS_MIXED_HILO=all puts pairs at every level (+ 0.3 ms per time step at B = 8)
     hilo_all = os.environ.get('ESS_MIXED_HILO', 'deepest') == 'all'
+    # WHEN: the pair that feeds the deepest ConvLSTM matters on the LAST steps of a sequence only -- the state forgets what earlier steps
+    # rounded.  Same tool, `steps` section (T = 5; pair at the last 0 / 1 / 2 / 3 / 4 / 5 steps): 35 / 20 / 14 / 11 / 12 / 11 flips.  A caller
+    # that knows how many steps follow says so (ImageReconstructor.update_reconstruction_sequence sets steps_left); the pair is then
+    # used on the last pair_steps() steps (default 3, ESS_MIXED_PAIR_STEPS=all: every step).  A step whose position is unknown
+    # (streaming inference: every step's output is consumed) always uses it.
+    left, keep = self.steps_left, pair_steps()
+    paired = left is None or keep is None or left < keep
     final = not lean
     no_fp32 = lean or (lean_state and self.use_upsample_conv and self.norm != 'IN')
     head = self.head.forward_mixed(x, want_fp32=final)
@@ -220,7 +229,7 @@ def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean
     x = head
     for i, encoder in enumerate(self.encoders):
         deep = hilo_all or i == self.num_encoders - 1
-        x, state = encoder.forward_mixed(x, prev_states[i], lean=no_fp32, hilo_out=final and deep, x_hilo=deep)
+        x, state = encoder.forward_mixed(x, prev_states[i], lean=no_fp32, hilo_out=final and deep, x_hilo=deep and (paired or hilo_all))
         blocks.append(x)
         states.append(state)
     if lean:
@@ -238,6 +247,20 @@ def _unet_recurrent_forward_mixed(self, x, prev_states, encoder_only, lean, lean
 
 
 UNetRecurrent._forward_mixed = _unet_recurrent_forward_mixed
+UNetRecurrent.steps_left = None  # (time steps that follow the next forward() in its sequence; None: unknown)
+_PAIR_STEPS = os.environ.get('ESS_MIXED_PAIR_STEPS', '3')
+
+
+def pair_steps():
+    """Steps at the END of a sequence whose deepest-level x -> gates operand is a [hi | lo] pair in the 'mixed' configuration (None: all)."""
+    return None if _PAIR_STEPS == 'all' else int(_PAIR_STEPS)
+
+
+def set_pair_steps(k):
+    """-> previous setting ('all' or a count, as a string)."""
+    global _PAIR_STEPS
+    prev, _PAIR_STEPS = _PAIR_STEPS, str(k)
+    return prev
 
 
 class UNetDecoder(BaseUNet):

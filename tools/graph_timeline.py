@@ -2,7 +2,7 @@
 """Timeline arithmetic on a rocprofv3 (rocpd sqlite) kernel trace of the captured step: how much of a step's wall time is covered by
 kernels, how much sits BETWEEN kernels (launch boundaries of dependent graph nodes), and which kernels are short enough that the boundary
 is comparable to them.
-usage: python tools/graph_timeline.py <results.db> [steps_to_use] > profiles/rN_graph_timeline.txt"""
+usage: python tools/graph_timeline.py <results.db> [steps_to_use [marker-kernel substring]] > profiles/rN_graph_timeline.txt"""
 import collections
 import sqlite3
 import sys
@@ -24,25 +24,20 @@ def dispatch_rows(cur):
     raise SystemExit('no dispatch table found; tables: ' + ', '.join(names))
 
 
-def main(path, steps=10):
+def main(path, steps=10, marker_sub='evnorm_slices_reduce_kernel'):
     cur = sqlite3.connect(path).cursor()
     rows, src = dispatch_rows(cur)
     print(f'# {path}: {len(rows)} dispatches from {src}')
     # the captured step is the periodic part: find the period as the dispatch count between two launches of the rarest long kernel
     names = [r[0] for r in rows]
     cnt = collections.Counter(names)
-    # replayed steps: the tail of the trace; period = smallest p such that names[-p:] == names[-2p:-p]
-    period = None
-    for p in range(50, len(rows) // 3):
-        if names[-p:] == names[-2 * p:-p] and names[-2 * p:-p] == names[-3 * p:-2 * p]:
-            period = p
-            break
-    if period is None:
-        raise SystemExit('no periodic tail found')
-    use = rows[-period * steps:]
-    print(f'# period {period} dispatches per step; using the last {steps} steps')
-    t0, t1 = use[0][1], max(r[2] for r in use)
-    span = (t1 - t0) / steps
+    # step boundaries: a kernel that runs once per step, first (the event normalisation of the step's input by default); the two capture streams
+    # interleave differently from replay to replay, so the dispatch ORDER is not periodic -- the marker's start times are
+    marker = min((n for n in cnt if cnt[n] >= steps + 1 and marker_sub in n), key=lambda n: (cnt[n], n))
+    marks = [s for n, s, _ in rows if n == marker][-(steps + 1):]
+    use = [r for r in rows if marks[0] <= r[1] < marks[-1]]
+    print(f'# marker {marker[:80]} ({cnt[marker]} launches); {len(use) / steps:.1f} dispatches per step over the last {steps} steps')
+    span = (marks[-1] - marks[0]) / steps
     busy = 0
     gaps = []
     cur_end = use[0][1]
@@ -77,4 +72,4 @@ def main(path, steps=10):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10, *sys.argv[3:4])

@@ -247,3 +247,58 @@ if 'prenorm' in which:
         rep('  same, latents as ONE f16 operand', decoder3(lat32, hf, hf, ls, hf, hf))
     rep('bf16 ops, hi/lo latents, pre f16 except first layer fp32', decoder3(lat32, ident, bf, ['decoder_scale_1.0.model.0'], bf, bf))
     rep('bf16 ops, bf16 latents, pre f16 except first layer fp32', decoder3(lat32, bf, bf, ['decoder_scale_1.0.model.0'], bf, bf))
+
+# ---- python tools/hybrid_rounding_ablation.py steps: does the deepest level's exact x -> gates operand matter at EVERY time step, or only at
+# the last ones (the state forgets)?  Encoder f16 operands, x -> gates of level 2 exact at the last k of T steps; decoder = the product's
+# (half operands, the 1/8 latent as a pair, first pre-norm tensor fp32)
+if 'steps' in which:
+    def encoder_last(k_last, lvl_exact=2):
+        real = O.F
+        shim = types.SimpleNamespace(**{k: getattr(real, k) for k in dir(real) if not k.startswith('__')})
+        seen = {'n': 0}
+        def conv2d(x, w, b=None, *a, **k):
+            cin = x.shape[1]; ks = w.shape[2]
+            if ks == 3 and (w.shape[0] == 2 * cin or w.shape[0] == 4 * cin):
+                hid = w.shape[0] // 4
+                lvl = {64: 0, 128: 1, 256: 2}[hid]
+                xin = x[:, :hid]
+                exact = False
+                if lvl == lvl_exact:
+                    exact = seen['n'] >= T - k_last
+                    seen['n'] += 1
+                xr = xin if exact else hf(xin)
+                if cin > hid:
+                    xr = torch.cat([xr, hf(x[:, hid:])], 1)
+                return real.conv2d(xr, hf(w), b, *a, **k)
+            return real.conv2d(hf(x), hf(w), b, *a, **k)
+        shim.conv2d = conv2d
+        O.F = shim
+        try:
+            _, _, lat = O.reconstruct_sequence(sd_e, cfg, ev, T, skip_dead_work=True)
+        finally:
+            O.F = real
+        assert seen['n'] == T, seen
+        return lat
+    def decoder_prod(lat):
+        def ins(pfx, x, relu=True, res=None, f32pre=False):
+            y = F.conv2d(x, hf(sd[pfx + '.weight']), sd[pfx + '.bias'], padding=1)
+            if not f32pre: y = hf(y)
+            y = F.instance_norm(y, eps=1e-5)
+            if relu: y = torch.relu(y)
+            if res is not None: y = y + res
+            return hf(y)
+        with torch.no_grad():
+            x = lat[8]
+            for i in range(5):
+                y = ins(f'decoder_scale_1.{i}.model.0', x, True, f32pre=(i == 0))
+                x = ins(f'decoder_scale_1.{i}.model.3', y, False, res=hf(x))
+            up = lambda v: F.interpolate(v, scale_factor=2, mode='nearest')
+            x = ins('decoder_scale_1.5.model.0', x)
+            x = torch.cat([up(x), hf(lat[4])], 1)
+            x = ins('decoder_scale_2.1.model.0', ins('decoder_scale_2.0.model.0', x))
+            x = torch.cat([up(x), hf(lat[2])], 1)
+            x = ins('decoder_scale_3.1.model.0', ins('decoder_scale_3.0.model.0', x))
+            x = ins('decoder_scale_4.0.model.0', up(x))
+            return F.conv2d(x, hf(sd['decoder_scale_5.0.weight']), sd['decoder_scale_5.0.bias'])
+    for k_last in range(T + 1):
+        rep('x -> gates of level 2 exact at the last %d of %d steps' % (k_last, T), decoder_prod(encoder_last(k_last)))
