@@ -58,6 +58,14 @@ def main(path, steps=10, marker_sub='evnorm_slices_reduce_kernel'):
         g = [x for x in gaps if lo <= x < hi]
         if g:
             print(f'  gaps {lo / 1e3:5.1f} - {"inf" if hi > 1e9 else hi / 1e3:>5} us: {len(g) / steps:7.1f} per step, {sum(g) / steps / 1e6:7.3f} ms per step')
+    # how many kernels are in flight (the capture forks two branches; a persistent one-workgroup-per-CU kernel owns every CU, so a kernel of the
+    # other branch launched under it mostly WAITS -- its recorded duration then includes the wait)
+    ev = sorted([(s, 1) for _, s, _ in use] + [(e, -1) for _, _, e in use])
+    lvl, last, t_at = 0, ev[0][0], collections.Counter()
+    for x, d in ev:
+        t_at[lvl] += x - last
+        last, lvl = x, lvl + d
+    print('kernels in flight    ' + ', '.join(f'{k}: {t_at[k] / steps / 1e6:.3f} ms' for k in sorted(t_at)) + ' per step')
     # per-kernel table of one step
     agg = collections.defaultdict(lambda: [0, 0])
     for n, s, e in use:
