@@ -106,9 +106,10 @@ class BaseTrainer(object):
         self._fork_branches = os.environ.get('ESS_GRAPH_FORK', '1') != '0'  # independent branches on forked streams (trainers that have them)
         self._capturing = True
         try:
-            # (under a process group: thread-local error mode -- the collective backend's watchdog thread queries events while this
-            # thread captures, which the default global mode treats as a capture violation)
-            mode = {'capture_error_mode': 'thread_local'} if dp else {}
+            # (under a process group -- whether or not this step takes the data-parallel branches: thread-local error mode.  The
+            # collective backend's watchdog thread queries the events of earlier collectives while this thread captures, which the
+            # default global mode treats as a capture violation and the watchdog answers by aborting the process)
+            mode = {'capture_error_mode': 'thread_local'} if dp or D.group_initialized() else {}
             # data parallel, a trainer with two optimisers whose gradients complete one after the other (the UDA step: image encoder,
             # then decoder): THREE graphs -- [forwards + image-encoder backward] | [decoder task backward] | [optimisers] -- so that the
             # all-reduce of the first flat gradient, issued between the first two replays, runs on the collective's stream UNDER the

@@ -70,6 +70,11 @@ def force_dp(on=True):
     _FORCE = bool(on)
 
 
+def group_initialized():
+    """True when a torch.distributed process group exists in this process (its watchdog thread is then alive)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def dp_active():
     """True when the data-parallel code paths run: more than one rank, or a (one-rank) process group under ESS_DP_FORCE."""
     if not (dist.is_available() and dist.is_initialized()):
