@@ -278,6 +278,50 @@ def test_mixed_sequence_latents_vs_oracle(H, rec_type):
         H.set_compute('fp32')
 
 
+def test_mixed_pair_window_in_time(H):
+    """Where in a sequence the deepest level's x -> gates operand is a [hi | lo] pair (unet.pair_steps: the last three steps by default;
+    DESIGN.md section 5, tools/hybrid_rounding_ablation.py `steps`): the sequence call tells the network how many steps follow and
+    clears the mark afterwards; every setting stays inside the 1e-3 latent bar against the fp32 oracle, 'all' and a window as long as the
+    sequence are the same arithmetic (bit-equal), a shorter window differs by rounding only."""
+    from oracle import ess_oracle as O
+    from ess_amd.e2vid.image_reconstructor import ImageReconstructor
+    from ess_amd.e2vid.model.model import E2VIDRecurrent
+    from ess_amd.e2vid.model import unet
+    from ess_amd.e2vid.options.inference_options import default_options
+    from ess_amd import functional as Fn
+    B, T, C, Hh, W = 1, 5, 2, 96, 128
+    cfg = O.e2vid_config(num_bins=C)
+    sd_e = O.synth_state_dict(O.e2vid_param_shapes(cfg), 78)
+    ev, _, _, _ = O.synth_batch(B, T, C, Hh, W, 11, seed=6)
+    _, _, ref_lat = O.reconstruct_sequence(sd_e, cfg, ev, T)
+    H.set_compute('mixed')
+    prev = unet.set_pair_steps(3)
+    try:
+        model = E2VIDRecurrent(dict(cfg))
+        model.load_state_dict(sd_e)
+        model = model.cuda().eval()
+        rec = ImageReconstructor(model, Hh, W, C, torch.device('cuda:0'), default_options())
+        got = {}
+        for k in ('all', T, 3, 1, 0):
+            unet.set_pair_steps(k)
+            assert unet.pair_steps() == (None if k == 'all' else k)
+            rec.last_states_for_each_channel = {'grayscale': None}
+            with torch.no_grad():
+                _, _, lat = rec.update_reconstruction_sequence(ev.cuda(), T, need_image=False, final_lean=True)
+                h8 = H.h16_of(Fn.as_c8(lat[8], want_hilo=True))
+            assert model.unetrecurrent.steps_left is None
+            got[k] = unblock_hilo(h8[0], 256).float()
+            err = (got[k] - ref_lat[8]).abs().max().item()
+            print(f'mixed, pair on the last {k} of {T} steps: 1/8 latent max err {err:.2e}')
+            assert err < 1e-3, (k, err)
+        assert torch.equal(got['all'], got[T])
+        assert not torch.equal(got['all'], got[0])
+        assert (got['all'] - got[3]).abs().max().item() < 2e-4
+    finally:
+        unet.set_pair_steps(prev)
+        H.set_compute('fp32')
+
+
 def test_mixed_validation_epochs_and_val_step_vs_fp32(H):
     """The validation path (reference training/ess_trainer.py:364-548) in the mixed configuration: BaseTrainer.validationEpochs runs
     (sensor_a, sensor_b, cycle metrics), and one val_step's losses agree with the exact-fp32 HIP path on the same weights and batch to
