@@ -5,7 +5,8 @@
 // and epilogue, 167 us at B=8 / 480x640 against a ~35 us floor of its 157 MB output.  Here the K dimension is the filter itself:
 // row r = c * 5 + ky (10 rows for 2 channels) x 8 column slots (kx = 0..4, three zero weights), i.e. five 32x32x16 MFMAs per 32
 // pixels with K-step s, lane half h <-> row 2s + h.  A lane's B operand for one K-step is 8 CONSECUTIVE pixels of one input row
-// starting at its own pixel: four ds_read2_b32 from an fp32 tile (4-byte aligned at any x), converted to bf16 in registers.
+// starting at its own pixel: four dwords of a 16-bit tile staged in two copies one element apart (round 6; rounds 3-5 read an fp32 tile
+// and converted in registers, in the K loop).
 // The weights are read from the tap-paired pack the plan already prescribes for this descriptor (no format of its own) and
 // rearranged once per workgroup.  Epilogue: scale / shift / ReLU, BF16_C8 vectors (16-byte stores) and / or fp32 NCHW planes.
 #include "conv_bf16_common.h"
@@ -23,7 +24,12 @@ template <bool SC, int NC, bool H = false>
 __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a, int tiles_x, int tiles_y) {
   constexpr int R = 5 * NC, NS = (R + 1) / 2;
   typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
-  __shared__ float tile[NC * HT_IH * HT_IW];
+  // the input tile as 16-bit operand elements, converted ONCE while it is staged (a lane's B operand overlaps its neighbours' in 7 of 8
+  // pixels: converting in the K loop cost 8 conversions per lane and K-step -- 62 of the kernel's 71 us were that VALU work, the
+  // 157 MB output alone takes 33).  Two copies: copy q holds element i + q at halfword i, so the 8 consecutive elements starting at
+  // ANY element e are four aligned dwords of copy e & 1.
+  constexpr int TOT = NC * HT_IH * HT_IW, TPITCH = TOT + 8;
+  __shared__ __attribute__((aligned(16))) unsigned short tile16[2 * TPITCH];
   __shared__ __attribute__((aligned(16))) u32x4 wfrag[NS * 2 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, p = lane & 31;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -63,8 +69,15 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int i = tid + k * 256;
-      if (i < NC * HT_IH * HT_IW) tile[i] = ld[k];
+      if (i < TOT) {
+        unsigned short h;
+        if constexpr (H) h = __builtin_bit_cast(unsigned short, ess_f16_sat(ld[k]));
+        else h = __builtin_bit_cast(unsigned short, (__bf16)ld[k]);
+        tile16[i] = h;
+        if (i > 0) tile16[TPITCH + i - 1] = h;
+      }
     }
+    if (tid == 0) tile16[TPITCH + TOT - 1] = 0;
   }
   // per-channel scale / shift of this lane's rows (the packed vectors are padded to the 32-row tile)
   float sc[16], sh[16];
@@ -83,8 +96,11 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
   for (int s = 0; s < NS; ++s) {
     const int r = 2 * s + half, c = r / 5, ky = r - 5 * c;
     af[s] = wfrag[r * 32 + p];
-    roff[s] = r < R ? (c * HT_IH + ky) * HT_IW + p : p;  // (a row past the filter: zero weights on finite data)
+    // dword offset inside copy p & 1 of the lane's first element (rows start at even elements: HT_IW is even)
+    roff[s] = ((r < R ? (c * HT_IH + ky) * HT_IW : 0) + p - (p & 1)) >> 1;  // (a row past the filter: zero weights on finite data)
   }
+  const unsigned* t32 = (const unsigned*)(tile16 + (p & 1) * TPITCH);
+  static_assert(HT_IW % 2 == 0 && TPITCH % 2 == 0, "dword-aligned rows and copies");
   const bool relu = a.act == ESS_ACT_RELU;
   const bool out8 = a.fmt_out == ESS_FMT_BF16_C8;
   const int nb_all = (a.Cout + 7) >> 3;
@@ -103,11 +119,9 @@ __global__ __launch_bounds__(256) void conv_bf16_head5_kernel(const ConvKArgs a,
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float* src = tile + ly * HT_IW + roff[s];
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = src[j];
-      acc = ess_mfma16<H>(af[s], H ? pack8h(v) : pack8(v), acc);
+      const unsigned* src = t32 + ly * (HT_IW / 2) + roff[s];
+      const u32x4 b = {src[0], src[1], src[2], src[3]};
+      acc = ess_mfma16<H>(af[s], b, acc);
     }
     const bool inb = x < a.Wout;
     const unsigned pix = (unsigned)(y * a.Wout + x);
