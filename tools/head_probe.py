@@ -1,3 +1,5 @@
+"""The recurrent encoder's 5x5 head (conv_bf16_head.hip) alone, mixed configuration, B = 8 / 2 x 480 x 640, 200 back-to-back calls timed with
+events.  usage: python tools/head_probe.py <label>   (round 6: A/B of library variants built with ablation switches)"""
 import sys, torch
 sys.path.insert(0, '.')
 from ess_amd import hip
